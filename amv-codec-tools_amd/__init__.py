@@ -1,0 +1,246 @@
+"""amv-codec-tools_amd -- MI355X-native AMV codec hot path (video decode/encode, IMA ADPCM).
+
+The product is libamvhip.so (HIP kernels for gfx950 behind a C ABI, include/amvhip.h).  This
+module is the thin ctypes binding tests and bench.py use; it contains no codec arithmetic and
+no CPU fallback: importing it without the built library raises.
+
+The directory name is not a Python identifier; load it with `__graft_entry__.load_package()`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamvhip.so")
+
+OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_SPACE = 0, -1, -2, -3, -4
+ST_FORMAT, ST_OVERRUN, ST_TRUNCATED = 1, 2, 4
+FLAG_ZIGZAG_FIXED = 1
+QBIAS_AMV, QBIAS_MJPEG = 0, 128
+K_HUFFMAN, K_RECON, K_FDCT, K_PACK, K_ADPCM_DEC, K_ADPCM_ENC, K_SYNTH = range(7)
+
+_vp, _u8p = ctypes.c_void_p, ctypes.c_void_p
+_u32, _u64, _i32, _int = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int
+
+
+class AMVInfo(ctypes.Structure):  # include/amvhip.h, reference AMVDec.h:29-47
+    _fields_ = [("dwMicroSecPerFrame", ctypes.c_uint), ("dwWidth", ctypes.c_uint), ("dwHeight", ctypes.c_uint),
+                ("dwSpeed", ctypes.c_uint), ("dwTimeSec", ctypes.c_uint), ("dwTimeMin", ctypes.c_uint),
+                ("dwTimeHour", ctypes.c_uint), ("wFormatTag", ctypes.c_ushort), ("nChannels", ctypes.c_ushort),
+                ("nSamplesPerSec", ctypes.c_uint), ("nAvgBytesPerSec", ctypes.c_uint),
+                ("nBlockAlign", ctypes.c_ushort), ("wBitsPerSample", ctypes.c_ushort),
+                ("cbSize", ctypes.c_ushort), ("wSamplesPerBlock", ctypes.c_ushort)]
+
+
+class FRAMEBUFF(ctypes.Structure):  # AMVDec.h:50-57
+    _fields_ = [("videobuff", ctypes.POINTER(ctypes.c_ubyte)), ("audiobuff", ctypes.POINTER(ctypes.c_ubyte)),
+                ("videobufflen", ctypes.c_uint), ("audiobufflen", ctypes.c_uint), ("framenum", ctypes.c_int)]
+
+
+class VIDEOBUFF(ctypes.Structure):  # AMVDec.h:59-63
+    _fields_ = [("fbmpdat", ctypes.POINTER(ctypes.c_ubyte)), ("len", ctypes.c_uint)]
+
+
+class AUDIOBUFF(ctypes.Structure):  # AMVDec.h:67-71
+    _fields_ = [("audiodata", ctypes.POINTER(ctypes.c_short)), ("len", ctypes.c_uint)]
+
+
+class AMVDecoder(ctypes.Structure):  # AMVDec.h:74-91
+    _fields_ = [("amvfilename", ctypes.c_char_p), ("opened", ctypes.c_int), ("dataseekpos", ctypes.c_long),
+                ("fileseekpos", ctypes.c_long), ("amvinfo", AMVInfo), ("currentframe", ctypes.c_uint),
+                ("totalframe", ctypes.c_uint), ("framebuf", FRAMEBUFF), ("videobuf", VIDEOBUFF),
+                ("audiobuf", AUDIOBUFF)]
+
+
+class ADPCMChannelStatus(ctypes.Structure):  # AdpcmIma.h:11-18
+    _fields_ = [("predictor", ctypes.c_int), ("step_index", ctypes.c_short), ("step", ctypes.c_int),
+                ("prev_sample", ctypes.c_int)]
+
+
+class ADPCMContext(ctypes.Structure):  # AdpcmIma.h:20-25
+    _fields_ = [("channel", ctypes.c_int), ("status", ADPCMChannelStatus * 2), ("sample_buffer", ctypes.c_short * 32)]
+
+
+# every symbol include/amvhip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "PrepareForVideoDecode": (None, [ctypes.POINTER(AMVInfo)]),
+    "AmvJpegDecode": (_int, [ctypes.POINTER(AMVInfo), ctypes.POINTER(FRAMEBUFF), ctypes.POINTER(VIDEOBUFF)]),
+    "AdpcmImaDecodeFrame": (_int, [ctypes.POINTER(ADPCMContext), _vp, ctypes.POINTER(_int), _vp, _int]),
+    "AdpcmImaEncodeFrame": (_int, [ctypes.POINTER(ADPCMContext), _int, _int, _vp, _int, _vp]),
+    "AmvOpen": (ctypes.POINTER(AMVDecoder), [ctypes.c_char_p]),
+    "AmvClose": (None, [ctypes.POINTER(AMVDecoder)]),
+    "AmvReadNextFrame": (_int, [ctypes.POINTER(AMVDecoder)]),
+    "AmvRewindFrameStart": (_int, [ctypes.POINTER(AMVDecoder)]),
+    "AmvVideoDecode": (_int, [ctypes.POINTER(AMVDecoder)]),
+    "AmvAudioDecode": (_int, [ctypes.POINTER(AMVDecoder)]),
+    "decode_amv_frame": (_int, [_vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, _vp]),
+    "encode_amv_frame": (_int, [_vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, _int, _vp, ctypes.c_uint]),
+    "amvhip_create": (_int, [ctypes.POINTER(_vp), _int]),
+    "amvhip_destroy": (None, [_vp]),
+    "amvhip_last_error": (ctypes.c_char_p, [_vp]),
+    "amvhip_device": (_int, [_vp]),
+    "amvhip_stride": (_u32, [_u32]),
+    "amvhip_frame_bytes": (_u64, [_u32, _u32]),
+    "amvhip_encode_bound": (_u32, [_u32, _u32]),
+    "amvhip_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "amvhip_decode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "amvhip_huffman_decode_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "amvhip_reconstruct_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "amvhip_encode_batch_dev": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
+    "amvhip_encode_batch": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp]),
+    "amvhip_encode_coefs_dev": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "amvhip_adpcm_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "amvhip_adpcm_encode_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "amvhip_adpcm_decode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _u64, _vp, _vp]),
+    "amvhip_adpcm_encode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),
+    "amvhip_adpcm_wav_encode_frame": (_int, [_vp, _vp, _int, _vp, _vp, _int]),
+    "amvhip_synth_frames_dev": (_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "amvhip_synth_audio_dev": (_int, [_vp, _u32, _u64, _u64, _vp, _vp]),
+    "amvhip_prof_enable": (None, [_vp, _int]),
+    "amvhip_prof_reset": (None, [_vp]),
+    "amvhip_prof_read": (_int, [_vp, _int, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double)]),
+    "amvhip_kernel_name": (ctypes.c_char_p, [_int]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libamvhip.so and type every entry point.  Raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libamvhip.so is not built (%s). Run `python amv-codec-tools_amd/build.py`; there is no CPU fallback."
+                % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class AmvHipError(RuntimeError):
+    pass
+
+
+def _ptr(x):
+    """device/host address of a torch tensor, numpy array, bytes-like or int; None -> NULL"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if hasattr(x, "ctypes"):
+        return x.ctypes.data
+    return ctypes.cast(ctypes.c_char_p(bytes(x)), ctypes.c_void_p).value
+
+
+class Context:
+    """One amvhip_ctx.  Methods mirror the batch entry points of include/amvhip.h one to one;
+    arguments are torch tensors / numpy arrays (their addresses are passed through)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.amvhip_create(ctypes.byref(h), int(device))
+        if rc != OK:
+            raise AmvHipError("amvhip_create(device=%d) failed with %d: no usable HIP device" % (device, rc))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.amvhip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise AmvHipError("%s failed (%d): %s" % (what, rc, self.lib.amvhip_last_error(self.h).decode()))
+        return rc
+
+    # geometry
+    def stride(self, w):
+        return self.lib.amvhip_stride(w)
+
+    def frame_bytes(self, w, h):
+        return self.lib.amvhip_frame_bytes(w, h)
+
+    def encode_bound(self, w, h):
+        return self.lib.amvhip_encode_bound(w, h)
+
+    # device-resident
+    def decode_batch_dev(self, blob, blob_bytes, offs, lens, n, w, h, flags, out, status, stream=None):
+        return self._check(self.lib.amvhip_decode_batch_dev(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens), n,
+                                                            w, h, flags, _ptr(out), _ptr(status), stream), "decode_batch_dev")
+
+    def huffman_decode_dev(self, blob, blob_bytes, offs, lens, n, w, h, coef, status, nmcu_ok, stream=None):
+        return self._check(self.lib.amvhip_huffman_decode_dev(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens), n,
+                                                              w, h, _ptr(coef), _ptr(status), _ptr(nmcu_ok), stream),
+                           "huffman_decode_dev")
+
+    def reconstruct_dev(self, coef, nmcu_ok, n, w, h, flags, out, stream=None):
+        return self._check(self.lib.amvhip_reconstruct_dev(self.h, _ptr(coef), _ptr(nmcu_ok), n, w, h, flags,
+                                                           _ptr(out), stream), "reconstruct_dev")
+
+    def encode_batch_dev(self, pix, pix_stride, is_bgr, n, w, h, qbias, blob, blob_cap, offs, lens, stream=None):
+        return self._check(self.lib.amvhip_encode_batch_dev(self.h, _ptr(pix), pix_stride, is_bgr, n, w, h, qbias,
+                                                            _ptr(blob), blob_cap, _ptr(offs), _ptr(lens), stream),
+                           "encode_batch_dev")
+
+    def encode_coefs_dev(self, pix, pix_stride, is_bgr, n, w, h, qbias, coef, stream=None):
+        return self._check(self.lib.amvhip_encode_coefs_dev(self.h, _ptr(pix), pix_stride, is_bgr, n, w, h, qbias,
+                                                            _ptr(coef), stream), "encode_coefs_dev")
+
+    def adpcm_decode_batch_dev(self, blob, blob_bytes, offs, lens, n, pcm, pcm_offs, final_state=None, stream=None):
+        return self._check(self.lib.amvhip_adpcm_decode_batch_dev(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens),
+                                                                  n, _ptr(pcm), _ptr(pcm_offs), _ptr(final_state), stream),
+                           "adpcm_decode_batch_dev")
+
+    def adpcm_encode_batch_dev(self, pcm, pcm_offs, nsamp, n, step_in, blob, offs, stream=None):
+        return self._check(self.lib.amvhip_adpcm_encode_batch_dev(self.h, _ptr(pcm), _ptr(pcm_offs), _ptr(nsamp), n,
+                                                                  _ptr(step_in), _ptr(blob), _ptr(offs), stream),
+                           "adpcm_encode_batch_dev")
+
+    def synth_frames_dev(self, seed, first, n, w, h, rgb, stream=None):
+        return self._check(self.lib.amvhip_synth_frames_dev(self.h, seed, first, n, w, h, _ptr(rgb), stream), "synth_frames_dev")
+
+    def synth_audio_dev(self, seed, first, n, pcm, stream=None):
+        return self._check(self.lib.amvhip_synth_audio_dev(self.h, seed, first, n, _ptr(pcm), stream), "synth_audio_dev")
+
+    # host buffers
+    def decode_batch(self, blob, blob_bytes, offs, lens, n, w, h, flags, out, status):
+        return self._check(self.lib.amvhip_decode_batch(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens), n, w, h,
+                                                        flags, _ptr(out), _ptr(status)), "decode_batch")
+
+    def encode_batch(self, pix, pix_stride, is_bgr, n, w, h, qbias, blob, blob_cap, offs, lens):
+        return self._check(self.lib.amvhip_encode_batch(self.h, _ptr(pix), pix_stride, is_bgr, n, w, h, qbias, _ptr(blob),
+                                                        blob_cap, _ptr(offs), _ptr(lens)), "encode_batch")
+
+    def adpcm_decode_batch(self, blob, blob_bytes, offs, lens, n, pcm, pcm_samples, pcm_offs, final_state=None):
+        return self._check(self.lib.amvhip_adpcm_decode_batch(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens), n,
+                                                              _ptr(pcm), pcm_samples, _ptr(pcm_offs), _ptr(final_state)),
+                           "adpcm_decode_batch")
+
+    def adpcm_encode_batch(self, pcm, pcm_samples, pcm_offs, nsamp, n, step_in, blob, blob_bytes, offs):
+        return self._check(self.lib.amvhip_adpcm_encode_batch(self.h, _ptr(pcm), pcm_samples, _ptr(pcm_offs), _ptr(nsamp),
+                                                              n, _ptr(step_in), _ptr(blob), blob_bytes, _ptr(offs)),
+                           "adpcm_encode_batch")
+
+    # timing
+    def prof_enable(self, on=True):
+        self.lib.amvhip_prof_enable(self.h, 1 if on else 0)
+
+    def prof_reset(self):
+        self.lib.amvhip_prof_reset(self.h)
+
+    def prof_read(self, kernel):
+        n, ms = ctypes.c_uint64(), ctypes.c_double()
+        self.lib.amvhip_prof_read(self.h, kernel, ctypes.byref(n), ctypes.byref(ms))
+        return n.value, ms.value
+
+    def kernel_name(self, kernel):
+        return self.lib.amvhip_kernel_name(kernel).decode()

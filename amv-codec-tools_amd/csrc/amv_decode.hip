@@ -1,0 +1,407 @@
+// amv_decode.hip -- AMV video decode kernels for gfx950 (MI355X).
+//
+// What the reference computes (C-AMVDecoder/amvlib/AmvJpeg.c, cited per function below) is
+// one serial loop per frame: Huffman-decode an MCU, dequantise, IDCT, convert, store.  Here
+// the frame is cut at the only place the data allows:
+//
+//   amv_huffman_kernel      entropy stage.  Serial inside a frame (no restart markers, DC
+//                           predictors chain through the whole scan: AmvJpeg.c:1200-1221,1406),
+//                           so one LANE owns one frame and a wave walks 64 frames block by
+//                           block.  Each lane decodes into a private 128-byte LDS slot; after
+//                           every block the wave writes the 64 slots out as 64 whole 128-byte
+//                           lines (8 dwordx4 stores per lane) and clears them, so HBM sees
+//                           only full-line coalesced writes and no separate memset.
+//   amv_reconstruct_kernel  everything after it is data parallel: one wave per MCU-row
+//                           segment (<= 10 MCUs = 60 blocks), coefficients staged in LDS,
+//                           row and column IDCT passes one 8-point transform per lane,
+//                           YCbCr->BGR and the bottom-up store (AmvJpeg.c:789-840).
+//
+// Compiled with -fwrapv: the integer pipeline relies on two's-complement wrap exactly as the
+// reference's compiler output does.
+#include "amv_kernels.h"
+
+namespace amv {
+
+// ============================================================================================
+// entropy stage
+// ============================================================================================
+
+namespace {
+
+constexpr int kWave = 64;
+
+struct BitReader {
+    const uint8_t* base;  // 4-byte aligned address at or before the chunk
+    uint64_t guard;       // bytes readable from base
+    uint32_t p;           // next byte, relative to base
+    uint32_t end;         // one past the chunk's last byte, relative to base
+    uint64_t acc;         // unread bits, MSB first
+    int nbits;            // valid bits in acc
+    int pad;              // zero bits appended past the end of the chunk
+};
+
+__device__ __forceinline__ uint32_t load_word(const BitReader& r, uint32_t p) {
+    if (p >= r.end) return 0u;
+    const uint64_t off = (uint64_t)(p & ~3u);
+    if (off + 4 <= r.guard) return *reinterpret_cast<const uint32_t*>(r.base + off);
+    uint32_t w = 0;
+    for (int k = 0; k < 4; ++k)
+        if (off + k < r.guard) w |= (uint32_t)r.base[off + k] << (8 * k);
+    return w;
+}
+
+// ReadByte (AmvJpeg.c:1061-1071): every byte is data, and the byte after an FF is dropped
+// without being looked at.  Four bytes at a time when the aligned word holds no FF.
+__device__ __forceinline__ void refill(BitReader& r) {
+    while (r.nbits <= 32) {
+        const uint32_t p = r.p;
+        const uint32_t w = load_word(r, p);
+        const bool any_ff = ((~w - 0x01010101u) & w & 0x80808080u) != 0u;
+        if ((p & 3u) == 0u && p + 4u <= r.end && !any_ff) {
+            r.acc |= (uint64_t)__builtin_bswap32(w) << (32 - r.nbits);
+            r.nbits += 32;
+            r.p = p + 4u;
+        } else {
+            const bool in = p < r.end;
+            const uint32_t b = in ? ((w >> ((p & 3u) * 8u)) & 0xffu) : 0u;
+            r.pad += in ? 0 : 8;
+            r.acc |= (uint64_t)b << (56 - r.nbits);
+            r.nbits += 8;
+            r.p = p + 1u + (b == 0xffu ? 1u : 0u);
+        }
+    }
+}
+
+// One (run, size, value) element: DecodeElement, AmvJpeg.c:842-936, as two table lookups on the
+// next 16 bits instead of the reference's bit-by-bit walk.  Returns the symbol, or -1 when no
+// code of <= 16 bits matches (FUNC_FORMAT_ERROR, :887).
+__device__ __forceinline__ int decode_element(BitReader& r, const uint16_t* l1, const uint16_t* l2,
+                                              int& value) {
+    refill(r);
+    const uint32_t v = (uint32_t)(r.acc >> 32);
+    uint32_t e = l1[v >> (32 - kLut1Bits)];
+    if (e & 0x8000u) e = l2[((e & 0xffu) << kLut2Bits) | ((v >> (32 - kLut1Bits - kLut2Bits)) & ((1u << kLut2Bits) - 1u))];
+    const int len = (int)((e >> 8) & 31u);
+    if (len == 0) {
+        r.nbits -= 17;  // the reference has read 17 bits when it gives up
+        value = 0;
+        return -1;
+    }
+    const int sym = (int)(e & 0xffu);
+    const int size = sym & 15;
+    int val = 0;
+    if (size) {
+        const uint32_t mag = (v << len) >> (32 - size);
+        val = (int)mag;
+        if (mag < (1u << (size - 1))) val -= (1 << size) - 1;  // :924-933
+    }
+    r.acc <<= (len + size);
+    r.nbits -= (len + size);
+    value = val;
+    return sym;
+}
+
+// byte offset of coefficient k inside a lane's 128-byte slot; 16-byte granules are XOR-ed with
+// the lane so that lanes writing the same k land in different banks
+__device__ __forceinline__ uint32_t slot_offset(uint32_t lane, uint32_t k) {
+    return lane * 128u + ((((k >> 3) ^ lane) & 7u) << 4) + ((k & 7u) << 1);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kWave) void amv_huffman_kernel(
+    const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offs,
+    const uint32_t* __restrict__ lens, uint32_t n, uint32_t blocks_per_frame,
+    const HuffDecodeImage* __restrict__ img, int16_t* __restrict__ coef,
+    int32_t* __restrict__ status, uint32_t* __restrict__ nmcu_ok) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_l1[4 << kLut1Bits];
+    __shared__ __attribute__((aligned(16))) uint16_t s_l2[kLut2Pages << kLut2Bits];
+    __shared__ __attribute__((aligned(16))) uint4 s_slots[kWave * 8];
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t f0 = blockIdx.x * kWave;
+    const uint32_t frame = f0 + lane;
+
+    {   // table image -> LDS, slots cleared
+        const uint4* src = reinterpret_cast<const uint4*>(img);
+        uint4* d1 = reinterpret_cast<uint4*>(s_l1);
+        uint4* d2 = reinterpret_cast<uint4*>(s_l2);
+        constexpr int n1 = (int)(sizeof(s_l1) / 16), n2 = (int)(sizeof(s_l2) / 16);
+        for (int i = lane; i < n1; i += kWave) d1[i] = src[i];
+        for (int i = lane; i < n2; i += kWave) d2[i] = src[n1 + i];
+        for (int i = lane; i < kWave * 8; i += kWave) s_slots[i] = make_uint4(0, 0, 0, 0);
+    }
+
+    BitReader r;
+    bool live = frame < n;
+    uint32_t st = 0, mcu_done = 0;
+    {
+        uint64_t off = live ? offs[frame] : 0;
+        uint32_t len = live ? lens[frame] : 0;
+        if (off > blob_bytes) { off = blob_bytes; len = 0; }            // never read outside the blob
+        if ((uint64_t)len > blob_bytes - off) len = (uint32_t)(blob_bytes - off);
+        const uint32_t mis = (uint32_t)(off & 3u);
+        r.base = blob + (off - mis);
+        r.guard = blob_bytes - (off - mis);
+        r.p = mis + 2u;  // skip FF D8 (AmvJpeg.c:1527)
+        r.end = mis + len;
+        r.acc = 0;
+        r.nbits = 0;
+        r.pad = 0;
+    }
+    int pred0 = 0, pred1 = 0, pred2 = 0;  // ycoef/ucoef/vcoef, AmvJpeg.c:1511
+    char* slot_bytes = reinterpret_cast<char*>(s_slots);
+    __syncthreads();
+
+    uint32_t k6 = 0;  // block index inside the MCU
+    for (uint32_t b = 0; b < blocks_per_frame; ++b) {
+        if (live) {  // HufBlock, AmvJpeg.c:939-974, + DC prediction of DecodeMCUBlock :1200-1221
+            const int cls = k6 < 4 ? 0 : 1;
+            int val;
+            int sym = decode_element(r, s_l1 + (cls << kLut1Bits), s_l2, val);
+            if (sym < 0) {
+                st |= kStFormat;
+                live = false;
+            } else {
+                int dc;
+                if (k6 < 4) { pred0 = (int16_t)(pred0 + val); dc = pred0; }
+                else if (k6 == 4) { pred1 = (int16_t)(pred1 + val); dc = pred1; }
+                else { pred2 = (int16_t)(pred2 + val); dc = pred2; }
+                *reinterpret_cast<int16_t*>(slot_bytes + slot_offset(lane, 0)) = (int16_t)dc;
+                const uint16_t* ac = s_l1 + ((2 + cls) << kLut1Bits);
+                uint32_t k = 1;
+                while (k < 64) {
+                    sym = decode_element(r, ac, s_l2, val);
+                    if (sym < 0) { st |= kStFormat; live = false; break; }
+                    if (sym == 0) break;  // end of block, :959-964
+                    k += (uint32_t)(sym >> 4);
+                    if (k > 63) { st |= kStOverrun; live = false; break; }  // reference: out-of-bounds write
+                    *reinterpret_cast<int16_t*>(slot_bytes + slot_offset(lane, k)) = (int16_t)val;
+                    ++k;
+                }
+            }
+        }
+        __syncthreads();
+        // 64 slots -> 64 lines of the coefficient array, then clear
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint32_t c = i * kWave + lane;
+            const uint32_t s = c >> 3, part = c & 7u;
+            const uint32_t idx = s * 8u + (part ^ (s & 7u));
+            const uint4 v = s_slots[idx];
+            s_slots[idx] = make_uint4(0, 0, 0, 0);
+            if (f0 + s < n) {
+                uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)(f0 + s) * blocks_per_frame + b) * 64u);
+                dst[part] = v;
+            }
+        }
+        __syncthreads();
+        if (++k6 == 6) {
+            k6 = 0;
+            if (live) ++mcu_done;
+        }
+    }
+    if (frame < n) {
+        if (r.pad > r.nbits) st |= kStTruncated;  // consumed bits that the chunk does not hold
+        status[frame] = (int32_t)st;
+        nmcu_ok[frame] = mcu_done;
+    }
+}
+
+void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
+                    const uint32_t* lens, uint32_t n, const FrameGeom& g,
+                    const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
+                    uint32_t* nmcu_ok, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t grid = (n + kWave - 1) / kWave;
+    hipLaunchKernelGGL(amv_huffman_kernel, dim3(grid), dim3(kWave), 0, s, blob, blob_bytes, offs,
+                       lens, n, g.blocks, d_img, coef, status, nmcu_ok);
+}
+
+// ============================================================================================
+// reconstruction stage
+// ============================================================================================
+
+namespace {
+
+constexpr int kSegMcus = 10;           // MCUs per workgroup: 160 pixels of one MCU row
+constexpr int kRowPitch = 72;          // int32 per block in the row-pass buffer (64 + 8: column
+                                       // reads of 4 neighbouring blocks hit 32 distinct banks)
+
+// 8-point inverse DCT of AmvJpeg.c: idctrow (:1082-1128) when kColumn == false, idctcol
+// (:1130-1175, without its final clamp) when true.  The reference's all-AC-zero shortcuts
+// (:1087-1092, :1134-1140) are exact special cases of this arithmetic and are not branched on.
+template <bool kColumn>
+__device__ __forceinline__ void idct8(int (&v)[8]) {
+    constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565;
+    constexpr int kUp = kColumn ? 256 : 2048;    // <<8 / <<11
+    constexpr int kBias = kColumn ? 8192 : 128;
+    constexpr int kRound = kColumn ? 4 : 0;
+    constexpr int kDown = kColumn ? 3 : 0;
+    constexpr int kOut = kColumn ? 14 : 8;
+    int a0 = v[0] * kUp + kBias, a1 = v[4] * kUp;
+    int a2 = v[6], a3 = v[2], a4 = v[1], a5 = v[7], a6 = v[5], a7 = v[3], t;
+    t = W7 * (a4 + a5) + kRound;
+    a4 = (t + (W1 - W7) * a4) >> kDown;
+    a5 = (t - (W1 + W7) * a5) >> kDown;
+    t = W3 * (a6 + a7) + kRound;
+    a6 = (t - (W3 - W5) * a6) >> kDown;
+    a7 = (t - (W3 + W5) * a7) >> kDown;
+    t = a0 + a1;
+    a0 -= a1;
+    a1 = W6 * (a3 + a2) + kRound;
+    a2 = (a1 - (W2 + W6) * a2) >> kDown;
+    a3 = (a1 + (W2 - W6) * a3) >> kDown;
+    a1 = a4 + a6;
+    a4 -= a6;
+    a6 = a5 + a7;
+    a5 -= a7;
+    a7 = t + a3;
+    t -= a3;
+    a3 = a0 + a2;
+    a0 -= a2;
+    a2 = (181 * (a4 + a5) + 128) >> 8;
+    a4 = (181 * (a4 - a5) + 128) >> 8;
+    v[0] = (a7 + a1) >> kOut;
+    v[1] = (a3 + a2) >> kOut;
+    v[2] = (a0 + a4) >> kOut;
+    v[3] = (t + a6) >> kOut;
+    v[4] = (t - a6) >> kOut;
+    v[5] = (a0 - a4) >> kOut;
+    v[6] = (a3 - a2) >> kOut;
+    v[7] = (a7 - a1) >> kOut;
+}
+
+// iclp[] of AmvJpeg.c:1073-1080 (table spans -512..511; beyond it the reference reads out of
+// bounds, defined here as saturation)
+__device__ __forceinline__ int clamp_iclp(int x) { return min(max(x, -256), 255); }
+
+__device__ __forceinline__ uint32_t clamp_u8(int x) { return (uint32_t)min(max(x, 0), 255); }
+
+}  // namespace
+
+__global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
+    const int16_t* __restrict__ coef, const uint32_t* __restrict__ nmcu_ok, uint32_t n,
+    FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
+    // coefficient stage and pixel planes share one region: the planes are written only after
+    // the row pass has consumed every coefficient
+    __shared__ __attribute__((aligned(16))) int16_t s_c[kSegMcus * 6 * 64];
+    __shared__ __attribute__((aligned(16))) int s_rows[kSegMcus * 6 * kRowPitch];
+    __shared__ uint16_t s_tab[2][64];
+
+    const uint32_t lane = threadIdx.x;
+    uint32_t bid = blockIdx.x;
+    const uint32_t seg = bid % nseg;
+    bid /= nseg;
+    const uint32_t my = bid % g.mcu_rows;
+    const uint32_t f = bid / g.mcu_rows;
+    const uint32_t m0 = seg * kSegMcus;
+    const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
+    const uint32_t nb = cnt * 6;
+
+    {   // IQtIZzBlock's gather (AmvJpeg.c:1035-1042): natural position -> (scan index, step)
+        uint32_t scan = kScanOfNatural[lane];
+        if (lane == (uint32_t)kAmvlibQuirkNatural && !(flags & kFlagZigzagFixed)) scan = kAmvlibQuirkScan;
+        s_tab[0][lane] = (uint16_t)(scan | ((uint32_t)kQuantLuma[scan] << 8));
+        s_tab[1][lane] = (uint16_t)(scan | ((uint32_t)kQuantChroma[scan] << 8));
+    }
+    {   // stage this segment's coefficients: nb consecutive 128-byte blocks
+        const uint4* src = reinterpret_cast<const uint4*>(
+            coef + ((uint64_t)f * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u);
+        uint4* dst = reinterpret_cast<uint4*>(s_c);
+        for (uint32_t i = lane; i < nb * 8; i += kWave) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    // row pass: one (block, row) per lane
+    for (uint32_t t = lane; t < nb * 8; t += kWave) {
+        const uint32_t blk = t >> 3, r = t & 7u;
+        const uint16_t* tab = s_tab[(blk % 6u) >= 4u ? 1 : 0];
+        const int16_t* cb = s_c + blk * 64u;
+        int v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t e = tab[r * 8u + c];
+            v[c] = (int)cb[e & 0xffu] * (int)(e >> 8);
+        }
+        idct8<false>(v);
+        int* dst = s_rows + blk * kRowPitch + r * 8u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dst[c] = v[c];
+    }
+    __syncthreads();
+
+    // column pass: one (block, column) per lane; results go to 16-row Y and 8-row U/V planes
+    int16_t* s_y = s_c;                         // [16][kSegMcus*16]
+    int16_t* s_u = s_c + 16 * kSegMcus * 16;    // [8][kSegMcus*8]
+    int16_t* s_v = s_u + 8 * kSegMcus * 8;
+    constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;
+    for (uint32_t t = lane; t < nb * 8; t += kWave) {
+        const uint32_t blk = t >> 3, c = t & 7u;
+        const uint32_t m = blk / 6u, k6 = blk % 6u;
+        const int* src = s_rows + blk * kRowPitch + c;
+        int v[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) v[rr] = src[rr * 8];
+        idct8<true>(v);
+        if (k6 < 4) {  // GetYUV (AmvJpeg.c:754-787) + the +128 of IQtIZzBlock (:1023,1047)
+            int16_t* dst = s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u + c;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) dst[rr * kPitchY] = (int16_t)(clamp_iclp(v[rr]) + 128);
+        } else {
+            int16_t* dst = (k6 == 4 ? s_u : s_v) + m * 8u + c;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) dst[rr * kPitchC] = (int16_t)clamp_iclp(v[rr]);
+        }
+    }
+    __syncthreads();
+
+    // StoreBuffer (AmvJpeg.c:789-840): 4 pixels = 12 bytes = 3 dwords per lane step
+    const uint32_t ok = nmcu_ok[f];
+    const uint32_t groups = cnt * 4;
+    uint8_t* frame_out = out + (uint64_t)f * g.frame_bytes;
+    for (uint32_t t = lane; t < 16 * groups; t += kWave) {
+        const uint32_t i = t / groups, gi = t % groups;
+        const uint32_t row = my * 16u + i;
+        if (row >= g.height) break;                       // :798 (rows only grow with t)
+        const uint32_t lc = gi * 4u, gc = m0 * 16u + lc;
+        if (gc >= g.width) continue;                      // :803
+        const bool decoded = (my * g.mcu_cols + m0 + (gi >> 2)) < ok;
+        uint32_t bytes[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = s_y[i * kPitchY + lc + j];
+            const int u = s_u[(i >> 1) * kPitchC + ((lc + j) >> 1)];
+            const int w = s_v[(i >> 1) * kPitchC + ((lc + j) >> 1)];
+            const int rr = (y * 256 + 18 * u + 367 * w) >> 8;    // :808-810
+            const int gg = (y * 256 - 159 * u - 220 * w) >> 8;
+            const int bb = (y * 256 + 411 * u - 29 * w) >> 8;
+            bytes[3 * j + 0] = decoded ? clamp_u8(bb) : 0u;      // :829-831 B,G,R
+            bytes[3 * j + 1] = decoded ? clamp_u8(gg) : 0u;
+            bytes[3 * j + 2] = decoded ? clamp_u8(rr) : 0u;
+        }
+        uint8_t* dst = frame_out + (uint64_t)(g.height - 1u - row) * g.stride + gc * 3u;  // :800
+        if (gc + 4u <= g.width) {
+            uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                d32[q] = bytes[4 * q] | (bytes[4 * q + 1] << 8) | (bytes[4 * q + 2] << 16) | (bytes[4 * q + 3] << 24);
+        } else {
+            const uint32_t valid = (g.width - gc) * 3u;
+#pragma unroll
+            for (uint32_t q = 0; q < 12; ++q)
+                if (q < valid) dst[q] = (uint8_t)bytes[q];
+        }
+    }
+}
+
+void launch_reconstruct(const int16_t* coef, const uint32_t* nmcu_ok, uint32_t n,
+                        const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
+    const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
+    hipLaunchKernelGGL(amv_reconstruct_kernel, dim3((uint32_t)grid), dim3(kWave), 0, s, coef,
+                       nmcu_ok, n, g, nseg, flags, out);
+}
+
+}  // namespace amv

@@ -1,0 +1,53 @@
+// amv_kernels.h -- launch wrappers of the HIP kernels (internal to libamvhip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "amv_tables.h"
+
+namespace amv {
+
+// status bits, same values as AMVHIP_ST_* in include/amvhip.h
+enum : uint32_t { kStFormat = 1u, kStOverrun = 2u, kStTruncated = 4u };
+enum : uint32_t { kFlagZigzagFixed = 1u };
+
+// ---- decode -------------------------------------------------------------------------------
+// entropy stage: one lane per frame, coefficients staged per block in LDS and written out as
+// whole 128-byte lines.  coef: [n][blocks][64] int16, scan order, DC already predicted.
+void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
+                    const uint32_t* lens, uint32_t n, const FrameGeom& g,
+                    const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
+                    uint32_t* nmcu_ok, hipStream_t s);
+// dequantise + IDCT + YCbCr->BGR + flipped store: one wave per MCU-row segment
+void launch_reconstruct(const int16_t* coef, const uint32_t* nmcu_ok, uint32_t n,
+                        const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s);
+
+// ---- encode -------------------------------------------------------------------------------
+// colour conversion + level shift + forward DCT + quantise: coef [n][blocks][64] int16 scan order
+void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n,
+                    const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s);
+// entropy coder: one lane per frame, writes FFD8 + escaped scan + FFD9 into tmp[i*bound..]
+void launch_pack(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img,
+                 uint8_t* tmp, uint32_t bound, uint32_t* lens, hipStream_t s);
+// exclusive scan of lens -> offs (single workgroup), then gather tmp -> blob
+void launch_compact(const uint8_t* tmp, uint32_t bound, const uint32_t* lens, uint32_t n,
+                    uint64_t* offs, uint8_t* blob, uint64_t blob_cap, int32_t* overflow, hipStream_t s);
+
+// ---- ADPCM --------------------------------------------------------------------------------
+void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
+                         const uint32_t* lens, uint32_t n, int16_t* pcm, const uint64_t* pcm_offs,
+                         int32_t* final_state, hipStream_t s);
+// 89-way state map of every chunk + serial walk of the maps -> start[i] (reference step_index carry)
+void launch_adpcm_map(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,
+                      uint8_t* map, int32_t* start, hipStream_t s);
+// amvlib's IMA-WAV-layout frame encoder (AdpcmIma.c:43-160), one lane
+void launch_adpcm_wav_encode(const int16_t* samples, int groups, int32_t* state, uint8_t* frame, hipStream_t s);
+void launch_adpcm_encode(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp,
+                         uint32_t n, const int32_t* step_in, uint8_t* blob, const uint64_t* offs,
+                         hipStream_t s);
+
+// ---- synthetic sources ----------------------------------------------------------------------
+void launch_synth_frames(uint32_t seed, uint32_t first, uint32_t n, uint32_t w, uint32_t h,
+                         uint8_t* rgb, hipStream_t s);
+void launch_synth_audio(uint32_t seed, uint64_t first, uint64_t n, int16_t* pcm, hipStream_t s);
+
+}  // namespace amv

@@ -1,0 +1,558 @@
+// amvhip_api.hip -- host side of libamvhip.so: the batch C ABI of include/amvhip.h.
+//
+// Owns the context (device tables, grow-only workspace, event-based kernel timing) and turns
+// each C entry point into kernel launches on the caller's stream.  Nothing here computes codec
+// results on the CPU: if the device is missing the calls fail.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/amvhip.h"
+#include "amv_kernels.h"
+
+using namespace amv;
+
+namespace {
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfRec {
+    int kernel;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct amvhip_ctx {
+    int device = 0;
+    std::string err;
+    HuffDecodeImage* d_dec = nullptr;
+    HuffEncodeImage* d_enc = nullptr;
+    // workspace
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start;
+    // host-pointer staging
+    DevBuf h_in, h_offs, h_lens, h_out, h_status, h_aux;
+    // timing
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    uint64_t launches[AMVHIP_K_COUNT] = {};
+    double total_ms[AMVHIP_K_COUNT] = {};
+    std::mutex mu;
+};
+
+namespace {
+
+int fail(amvhip_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? AMVHIP_ERR_NOMEM : AMVHIP_ERR_DEVICE, \
+                        "%s: %s", #expr, hipGetErrorString(e_));                               \
+    } while (0)
+
+int ensure(amvhip_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return AMVHIP_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return AMVHIP_OK;
+}
+
+// ---- table images ---------------------------------------------------------------------------
+
+const uint8_t* symbols_of(int t) {
+    return t < 2 ? kHuffDcSymbols : (t == 2 ? kHuffAcLumaSymbols : kHuffAcChromaSymbols);
+}
+
+// canonical code assignment of JPEG Annex C (what AmvJpeg.c:1454-1481 and mjpeg.c:129-147 both
+// derive): codes of each length are consecutive, and the first code of length l+1 is
+// (last code of length l + 1) << 1
+void build_images(HuffDecodeImage& dec, HuffEncodeImage& enc) {
+    memset(&dec, 0, sizeof dec);
+    memset(&enc, 0, sizeof enc);
+    int pages = 0;
+    for (int t = 0; t < 4; ++t) {
+        const uint8_t* syms = symbols_of(t);
+        uint32_t code = 0;
+        int k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            for (int j = 0; j < kHuffCount[t][len - 1]; ++j, ++code) {
+                const uint32_t sym = syms[k++];
+                enc.code[t][sym] = code | ((uint32_t)len << 16);
+                const uint16_t entry = (uint16_t)(sym | ((uint32_t)len << 8));
+                if (len <= kLut1Bits) {
+                    const uint32_t lo = code << (kLut1Bits - len);
+                    for (uint32_t x = 0; x < (1u << (kLut1Bits - len)); ++x) dec.l1[t][lo + x] = entry;
+                } else {
+                    const int rest = len - kLut1Bits;  // 1..7
+                    const uint32_t prefix = code >> rest;
+                    if (!(dec.l1[t][prefix] & 0x8000u)) dec.l1[t][prefix] = (uint16_t)(0x8000u | (uint32_t)pages++);
+                    const uint32_t page = dec.l1[t][prefix] & 0xffu;
+                    const uint32_t lo = (code & ((1u << rest) - 1u)) << (kLut2Bits - rest);
+                    for (uint32_t x = 0; x < (1u << (kLut2Bits - rest)); ++x) dec.l2[page][lo + x] = entry;
+                }
+            }
+            code <<= 1;
+        }
+    }
+    if (pages > kLut2Pages) abort();  // static property of the K.3 tables (11 pages)
+}
+
+// ---- timing ---------------------------------------------------------------------------------
+
+struct Timed {
+    amvhip_ctx* c;
+    hipStream_t s;
+    ProfRec r{};
+    bool on;
+    Timed(amvhip_ctx* ctx, int kernel, hipStream_t st) : c(ctx), s(st), on(ctx->prof) {
+        if (!on) return;
+        r.kernel = kernel;
+        for (hipEvent_t* e : {&r.a, &r.b}) {
+            if (!c->pool.empty()) { *e = c->pool.back(); c->pool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
+        }
+        (void)hipEventRecord(r.a, s);
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        c->recs.push_back(r);
+    }
+};
+
+void drain(amvhip_ctx* c) {
+    for (ProfRec& r : c->recs) {
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->launches[r.kernel]++;
+            c->total_ms[r.kernel] += ms;
+        }
+        c->pool.push_back(r.a);
+        c->pool.push_back(r.b);
+    }
+    c->recs.clear();
+}
+
+int check_launch(amvhip_ctx* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, AMVHIP_ERR_DEVICE, "%s launch: %s", what, hipGetErrorString(e));
+    return AMVHIP_OK;
+}
+
+int use_device(amvhip_ctx* c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    return AMVHIP_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// context
+// =============================================================================================
+
+extern "C" int amvhip_create(amvhip_ctx** out, int device) {
+    if (!out) return AMVHIP_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return AMVHIP_ERR_DEVICE;
+    amvhip_ctx* c = new amvhip_ctx;
+    c->device = device;
+    static HuffDecodeImage dec;
+    static HuffEncodeImage enc;
+    static std::once_flag once;
+    std::call_once(once, [] { build_images(dec, enc); });
+    auto die = [&](int code) { amvhip_destroy(c); return code; };
+    if (hipSetDevice(device) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
+    if (hipMalloc((void**)&c->d_dec, sizeof dec) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
+    if (hipMalloc((void**)&c->d_enc, sizeof enc) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
+    if (hipMemcpy(c->d_dec, &dec, sizeof dec, hipMemcpyHostToDevice) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
+    if (hipMemcpy(c->d_enc, &enc, sizeof enc, hipMemcpyHostToDevice) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
+    *out = c;
+    return AMVHIP_OK;
+}
+
+extern "C" void amvhip_destroy(amvhip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    drain(c);
+    for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
+    for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
+                      &c->start, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux})
+        if (b->p) (void)hipFree(b->p);
+    if (c->d_dec) (void)hipFree(c->d_dec);
+    if (c->d_enc) (void)hipFree(c->d_enc);
+    delete c;
+}
+
+extern "C" const char* amvhip_last_error(const amvhip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" int amvhip_device(const amvhip_ctx* c) { return c ? c->device : -1; }
+
+extern "C" uint32_t amvhip_stride(uint32_t w) { return (w * 24 + 31) / 32 * 4; }
+extern "C" uint64_t amvhip_frame_bytes(uint32_t w, uint32_t h) { return (uint64_t)amvhip_stride(w) * h; }
+extern "C" uint32_t amvhip_encode_bound(uint32_t w, uint32_t h) {
+    // per coefficient at most a 16-bit code + 11 magnitude bits (< 4 bytes), doubled by FF escaping
+    return 4 + ((w + 15) / 16) * ((h + 15) / 16) * 6 * 64 * 4 * 2;
+}
+
+// =============================================================================================
+// video decode
+// =============================================================================================
+
+static int size_ok(uint32_t w, uint32_t h) { return w > 0 && h > 0 && w <= 16384 && h <= 16384; }
+
+extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
+                                         const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
+                                         uint32_t w, uint32_t h, int16_t* d_coef, int32_t* d_status,
+                                         uint32_t* d_nmcu_ok, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (n && (!d_blob || !d_offs || !d_lens || !d_coef || !d_status || !d_nmcu_ok)))
+        return fail(c, AMVHIP_ERR_ARG, "huffman_decode: bad argument");
+    if (((uintptr_t)d_blob & 3u) || ((uintptr_t)d_coef & 15u)) return fail(c, AMVHIP_ERR_ARG, "huffman_decode: blob must be 4-byte, coef 16-byte aligned");
+    if (int r = use_device(c)) return r;
+    const FrameGeom g = make_geom(w, h);
+    {
+        Timed t(c, AMVHIP_K_HUFFMAN, (hipStream_t)stream);
+        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, (hipStream_t)stream);
+    }
+    return check_launch(c, "huffman");
+}
+
+extern "C" int amvhip_reconstruct_dev(amvhip_ctx* c, const int16_t* d_coef, const uint32_t* d_nmcu_ok,
+                                      uint32_t n, uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out,
+                                      void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (n && (!d_coef || !d_nmcu_ok || !d_out))) return fail(c, AMVHIP_ERR_ARG, "reconstruct: bad argument");
+    if (((uintptr_t)d_out & 3u) || ((uintptr_t)d_coef & 15u)) return fail(c, AMVHIP_ERR_ARG, "reconstruct: out must be 4-byte, coef 16-byte aligned");
+    if (int r = use_device(c)) return r;
+    const FrameGeom g = make_geom(w, h);
+    if (g.stride != w * 3)  // row padding bytes stay zero as in AMVDec.c:283
+        HIP_TRY(c, hipMemsetAsync(d_out, 0, g.frame_bytes * n, (hipStream_t)stream));
+    {
+        Timed t(c, AMVHIP_K_RECON, (hipStream_t)stream);
+        launch_reconstruct(d_coef, d_nmcu_ok, n, g, flags, d_out, (hipStream_t)stream);
+    }
+    return check_launch(c, "reconstruct");
+}
+
+extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
+                                       const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
+                                       uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out,
+                                       int32_t* d_status, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h)) return fail(c, AMVHIP_ERR_ARG, "decode: bad size %ux%u", w, h);
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    const FrameGeom g = make_geom(w, h);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int r = ensure(c, c->coef, (size_t)n * g.blocks * 128)) return r;
+    if (int r = ensure(c, c->nmcu, (size_t)n * 4)) return r;
+    if (int r = amvhip_huffman_decode_dev(c, d_blob, blob_bytes, d_offs, d_lens, n, w, h, (int16_t*)c->coef.p,
+                                          d_status, (uint32_t*)c->nmcu.p, stream))
+        return r;
+    return amvhip_reconstruct_dev(c, (const int16_t*)c->coef.p, (const uint32_t*)c->nmcu.p, n, w, h, flags,
+                                  d_out, stream);
+}
+
+extern "C" int amvhip_decode_batch(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
+                                   const uint64_t* offs, const uint32_t* lens, uint32_t n, uint32_t w,
+                                   uint32_t h, uint32_t flags, uint8_t* out, int32_t* status) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (n && (!blob || !offs || !lens || !out))) return fail(c, AMVHIP_ERR_ARG, "decode: bad argument");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    const uint64_t fb = amvhip_frame_bytes(w, h);
+    if (int r = ensure(c, c->h_in, blob_bytes + 16)) return r;
+    if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
+    if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
+    if (int r = ensure(c, c->h_out, fb * n)) return r;
+    if (int r = ensure(c, c->h_status, (size_t)n * 4)) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, blob, blob_bytes, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    if (int r = amvhip_decode_batch_dev(c, (const uint8_t*)c->h_in.p, blob_bytes, (const uint64_t*)c->h_offs.p,
+                                        (const uint32_t*)c->h_lens.p, n, w, h, flags, (uint8_t*)c->h_out.p,
+                                        (int32_t*)c->h_status.p, nullptr))
+        return r;
+    HIP_TRY(c, hipMemcpyAsync(out, c->h_out.p, fb * n, hipMemcpyDeviceToHost, 0));
+    if (status) HIP_TRY(c, hipMemcpyAsync(status, c->h_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipStreamSynchronize(0));
+    return AMVHIP_OK;
+}
+
+// =============================================================================================
+// video encode
+// =============================================================================================
+
+extern "C" int amvhip_encode_coefs_dev(amvhip_ctx* c, const uint8_t* d_pix, uint32_t pix_stride, int is_bgr,
+                                       uint32_t n, uint32_t w, uint32_t h, uint32_t qbias, int16_t* d_coef,
+                                       void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (w & 1) || (h & 1) || pix_stride < w * 3 || qbias > 255 || (n && (!d_pix || !d_coef)))
+        return fail(c, AMVHIP_ERR_ARG, "encode: bad argument (width/height must be even)");
+    if ((uintptr_t)d_coef & 15u) return fail(c, AMVHIP_ERR_ARG, "encode: coef must be 16-byte aligned");
+    if (int r = use_device(c)) return r;
+    const FrameGeom g = make_geom(w, h);
+    {
+        Timed t(c, AMVHIP_K_FDCT, (hipStream_t)stream);
+        launch_forward(d_pix, pix_stride, is_bgr, n, g, qbias, d_coef, (hipStream_t)stream);
+    }
+    return check_launch(c, "forward");
+}
+
+extern "C" int amvhip_encode_batch_dev(amvhip_ctx* c, const uint8_t* d_pix, uint32_t pix_stride, int is_bgr,
+                                       uint32_t n, uint32_t w, uint32_t h, uint32_t qbias, uint8_t* d_blob,
+                                       uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (n && (!d_blob || !d_offs || !d_lens)) return fail(c, AMVHIP_ERR_ARG, "encode: null output");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    const FrameGeom g = make_geom(w, h);
+    const uint32_t bound = amvhip_encode_bound(w, h);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int r = ensure(c, c->coef, (size_t)n * g.blocks * 128)) return r;
+    if (int r = ensure(c, c->tmp, (size_t)n * bound)) return r;
+    if (int r = ensure(c, c->flag, 16)) return r;
+    if (int r = amvhip_encode_coefs_dev(c, d_pix, pix_stride, is_bgr, n, w, h, qbias, (int16_t*)c->coef.p, stream)) return r;
+    {
+        Timed t(c, AMVHIP_K_PACK, (hipStream_t)stream);
+        launch_pack((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens, (hipStream_t)stream);
+    }
+    if (int r = check_launch(c, "pack")) return r;
+    launch_compact((const uint8_t*)c->tmp.p, bound, d_lens, n, d_offs, d_blob, blob_cap, (int32_t*)c->flag.p,
+                   (hipStream_t)stream);
+    return check_launch(c, "compact");
+}
+
+extern "C" int amvhip_encode_batch(amvhip_ctx* c, const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n,
+                                   uint32_t w, uint32_t h, uint32_t qbias, uint8_t* blob, uint64_t blob_cap,
+                                   uint64_t* offs, uint32_t* lens) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (n && (!pix || !blob || !offs || !lens)) return fail(c, AMVHIP_ERR_ARG, "encode: null argument");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    const size_t in_bytes = (size_t)pix_stride * h * n;
+    const uint64_t dev_cap = (uint64_t)amvhip_encode_bound(w, h) * n;
+    if (int r = ensure(c, c->h_in, in_bytes)) return r;
+    if (int r = ensure(c, c->h_out, dev_cap)) return r;
+    if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
+    if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, pix, in_bytes, hipMemcpyHostToDevice, 0));
+    if (int r = amvhip_encode_batch_dev(c, (const uint8_t*)c->h_in.p, pix_stride, is_bgr, n, w, h, qbias,
+                                        (uint8_t*)c->h_out.p, dev_cap, (uint64_t*)c->h_offs.p,
+                                        (uint32_t*)c->h_lens.p, nullptr))
+        return r;
+    HIP_TRY(c, hipMemcpyAsync(offs, c->h_offs.p, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipMemcpyAsync(lens, c->h_lens.p, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipStreamSynchronize(0));
+    const uint64_t total = offs[n - 1] + lens[n - 1];
+    if (total > blob_cap) return fail(c, AMVHIP_ERR_SPACE, "encode: need %llu bytes, have %llu", (unsigned long long)total, (unsigned long long)blob_cap);
+    HIP_TRY(c, hipMemcpy(blob, c->h_out.p, total, hipMemcpyDeviceToHost));
+    return AMVHIP_OK;
+}
+
+// =============================================================================================
+// ADPCM
+// =============================================================================================
+
+extern "C" int amvhip_adpcm_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
+                                             const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
+                                             int16_t* d_pcm, const uint64_t* d_pcm_offs,
+                                             int32_t* d_final_state, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (n && (!d_blob || !d_offs || !d_lens || !d_pcm || !d_pcm_offs)) return fail(c, AMVHIP_ERR_ARG, "adpcm_decode: null argument");
+    if (int r = use_device(c)) return r;
+    {
+        Timed t(c, AMVHIP_K_ADPCM_DEC, (hipStream_t)stream);
+        launch_adpcm_decode(d_blob, blob_bytes, d_offs, d_lens, n, d_pcm, d_pcm_offs, d_final_state, (hipStream_t)stream);
+    }
+    return check_launch(c, "adpcm_decode");
+}
+
+extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm, const uint64_t* d_pcm_offs,
+                                             const uint32_t* d_nsamp, uint32_t n, const int32_t* d_step_in,
+                                             uint8_t* d_blob, const uint64_t* d_offs, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (n && (!d_pcm || !d_pcm_offs || !d_nsamp || !d_blob || !d_offs)) return fail(c, AMVHIP_ERR_ARG, "adpcm_encode: null argument");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    Timed t(c, AMVHIP_K_ADPCM_ENC, (hipStream_t)stream);
+    if (!d_step_in) {  // the reference's behaviour: step_index runs through the whole stream
+        if (int r = ensure(c, c->map, (size_t)n * 96)) return r;
+        if (int r = ensure(c, c->start, (size_t)n * 4)) return r;
+        launch_adpcm_map(d_pcm, d_pcm_offs, d_nsamp, n, (uint8_t*)c->map.p, (int32_t*)c->start.p, (hipStream_t)stream);
+        d_step_in = (const int32_t*)c->start.p;
+    }
+    launch_adpcm_encode(d_pcm, d_pcm_offs, d_nsamp, n, d_step_in, d_blob, d_offs, (hipStream_t)stream);
+    return check_launch(c, "adpcm_encode");
+}
+
+extern "C" int amvhip_adpcm_decode_batch(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
+                                         const uint64_t* offs, const uint32_t* lens, uint32_t n, int16_t* pcm,
+                                         uint64_t pcm_samples, const uint64_t* pcm_offs, int32_t* final_state) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (n && (!blob || !offs || !lens || !pcm || !pcm_offs)) return fail(c, AMVHIP_ERR_ARG, "adpcm_decode: null argument");
+    if (n == 0) return AMVHIP_OK;
+    for (uint32_t i = 0; i < n; ++i)
+        if (lens[i] > 8 && pcm_offs[i] + 2ull * (lens[i] - 8) > pcm_samples) return fail(c, AMVHIP_ERR_SPACE, "adpcm_decode: pcm too small for chunk %u", i);
+    if (int r = use_device(c)) return r;
+    if (int r = ensure(c, c->h_in, blob_bytes + 16)) return r;
+    if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
+    if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
+    if (int r = ensure(c, c->h_out, pcm_samples * 2)) return r;
+    if (int r = ensure(c, c->h_aux, (size_t)n * 8)) return r;
+    if (int r = ensure(c, c->h_status, (size_t)n * 8)) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, blob, blob_bytes, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_aux.p, pcm_offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_out.p, pcm, pcm_samples * 2, hipMemcpyHostToDevice, 0));  // keep untouched gaps
+    if (int r = amvhip_adpcm_decode_batch_dev(c, (const uint8_t*)c->h_in.p, blob_bytes, (const uint64_t*)c->h_offs.p,
+                                              (const uint32_t*)c->h_lens.p, n, (int16_t*)c->h_out.p,
+                                              (const uint64_t*)c->h_aux.p, (int32_t*)c->h_status.p, nullptr))
+        return r;
+    HIP_TRY(c, hipMemcpyAsync(pcm, c->h_out.p, pcm_samples * 2, hipMemcpyDeviceToHost, 0));
+    if (final_state) HIP_TRY(c, hipMemcpyAsync(final_state, c->h_status.p, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipStreamSynchronize(0));
+    return AMVHIP_OK;
+}
+
+extern "C" int amvhip_adpcm_encode_batch(amvhip_ctx* c, const int16_t* pcm, uint64_t pcm_samples,
+                                         const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,
+                                         const int32_t* step_in, uint8_t* blob, uint64_t blob_bytes,
+                                         const uint64_t* offs) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (n && (!pcm || !pcm_offs || !nsamp || !blob || !offs)) return fail(c, AMVHIP_ERR_ARG, "adpcm_encode: null argument");
+    if (n == 0) return AMVHIP_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (pcm_offs[i] + nsamp[i] > pcm_samples) return fail(c, AMVHIP_ERR_ARG, "adpcm_encode: chunk %u reads past pcm", i);
+        if (offs[i] + 8ull + (nsamp[i] >> 1) > blob_bytes) return fail(c, AMVHIP_ERR_SPACE, "adpcm_encode: blob too small for chunk %u", i);
+    }
+    if (int r = use_device(c)) return r;
+    if (int r = ensure(c, c->h_in, pcm_samples * 2 + 16)) return r;
+    if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
+    if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
+    if (int r = ensure(c, c->h_out, blob_bytes)) return r;
+    if (int r = ensure(c, c->h_aux, (size_t)n * 8)) return r;
+    if (int r = ensure(c, c->h_status, (size_t)n * 4)) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, pcm, pcm_samples * 2, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_aux.p, pcm_offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, nsamp, (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_out.p, blob, blob_bytes, hipMemcpyHostToDevice, 0));
+    if (step_in) HIP_TRY(c, hipMemcpyAsync(c->h_status.p, step_in, (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    if (int r = amvhip_adpcm_encode_batch_dev(c, (const int16_t*)c->h_in.p, (const uint64_t*)c->h_aux.p,
+                                              (const uint32_t*)c->h_lens.p, n,
+                                              step_in ? (const int32_t*)c->h_status.p : nullptr,
+                                              (uint8_t*)c->h_out.p, (const uint64_t*)c->h_offs.p, nullptr))
+        return r;
+    HIP_TRY(c, hipMemcpyAsync(blob, c->h_out.p, blob_bytes, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipStreamSynchronize(0));
+    return AMVHIP_OK;
+}
+
+extern "C" int amvhip_adpcm_wav_encode_frame(amvhip_ctx* c, const int16_t* samples, int frame_size,
+                                             int32_t state[2], uint8_t* frame, int buf_size) {
+    if (!c) return AMVHIP_ERR_ARG;
+    const int groups = frame_size / 8;   // AdpcmIma.c:105
+    if (!samples || !state || !frame || frame_size < 1 || buf_size < 4 + 4 * groups)
+        return fail(c, AMVHIP_ERR_ARG, "adpcm_wav_encode: bad argument");
+    if (int r = use_device(c)) return r;
+    const size_t ns = (size_t)1 + 8 * (size_t)groups;
+    if (int r = ensure(c, c->h_in, ns * 2)) return r;
+    if (int r = ensure(c, c->h_out, 4 + 4 * (size_t)groups)) return r;
+    if (int r = ensure(c, c->h_status, 8)) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, samples, ns * 2, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_status.p, state, 8, hipMemcpyHostToDevice, 0));
+    launch_adpcm_wav_encode((const int16_t*)c->h_in.p, groups, (int32_t*)c->h_status.p, (uint8_t*)c->h_out.p, nullptr);
+    if (int r = check_launch(c, "adpcm_wav_encode")) return r;
+    HIP_TRY(c, hipMemcpyAsync(frame, c->h_out.p, 4 + 4 * (size_t)groups, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipMemcpyAsync(state, c->h_status.p, 8, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipStreamSynchronize(0));
+    return 4 + 4 * groups;
+}
+
+// =============================================================================================
+// synthetic sources
+// =============================================================================================
+
+extern "C" int amvhip_synth_frames_dev(amvhip_ctx* c, uint32_t seed, uint32_t first, uint32_t n, uint32_t w,
+                                       uint32_t h, uint8_t* d_rgb, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (n && !d_rgb)) return fail(c, AMVHIP_ERR_ARG, "synth: bad argument");
+    if (int r = use_device(c)) return r;
+    {
+        Timed t(c, AMVHIP_K_SYNTH, (hipStream_t)stream);
+        launch_synth_frames(seed, first, n, w, h, d_rgb, (hipStream_t)stream);
+    }
+    return check_launch(c, "synth_frames");
+}
+
+extern "C" int amvhip_synth_audio_dev(amvhip_ctx* c, uint32_t seed, uint64_t first, uint64_t n, int16_t* d_pcm,
+                                      void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (n && !d_pcm) return fail(c, AMVHIP_ERR_ARG, "synth: bad argument");
+    if (int r = use_device(c)) return r;
+    launch_synth_audio(seed, first, n, d_pcm, (hipStream_t)stream);
+    return check_launch(c, "synth_audio");
+}
+
+// =============================================================================================
+// timing
+// =============================================================================================
+
+extern "C" void amvhip_prof_enable(amvhip_ctx* c, int on) { if (c) c->prof = on != 0; }
+
+extern "C" void amvhip_prof_reset(amvhip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    drain(c);
+    for (int k = 0; k < AMVHIP_K_COUNT; ++k) { c->launches[k] = 0; c->total_ms[k] = 0; }
+}
+
+extern "C" int amvhip_prof_read(amvhip_ctx* c, int kernel, uint64_t* launches, double* total_ms) {
+    if (!c || kernel < 0 || kernel >= AMVHIP_K_COUNT) return AMVHIP_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    drain(c);
+    if (launches) *launches = c->launches[kernel];
+    if (total_ms) *total_ms = c->total_ms[kernel];
+    return AMVHIP_OK;
+}
+
+extern "C" const char* amvhip_kernel_name(int kernel) {
+    switch (kernel) {
+        case AMVHIP_K_HUFFMAN: return "amv_huffman_kernel";
+        case AMVHIP_K_RECON: return "amv_reconstruct_kernel";
+        case AMVHIP_K_FDCT: return "amv_forward_kernel";
+        case AMVHIP_K_PACK: return "amv_pack_kernel";
+        case AMVHIP_K_ADPCM_DEC: return "amv_adpcm_decode_kernel";
+        case AMVHIP_K_ADPCM_ENC: return "amv_adpcm_encode_kernel";
+        case AMVHIP_K_SYNTH: return "amv_synth_frames_kernel";
+        default: return "";
+    }
+}

@@ -1,0 +1,332 @@
+/*
+ * amvlib_compat.c -- the amvlib call surface of the reference, in host C, on top of the
+ * batch C ABI of libamvhip (include/amvhip.h).
+ *
+ * Mirrors C-AMVDecoder/amvlib/AMVDec.c (AmvOpen :15, AmvClose :131, AmvReadNextFrame :150,
+ * AmvRewindFrameStart :240, AmvVideoDecode :259, AmvAudioDecode :288), AmvJpeg.c
+ * (PrepareForVideoDecode :1396, AmvJpegDecode :1515) and AdpcmIma.c (AdpcmImaDecodeFrame
+ * :206, AdpcmImaEncodeFrame :92): same names, arguments, ownership rules and return codes.
+ * Every codec computation goes to the GPU through the batch ABI; this file only moves
+ * buffers and walks the container.  One process-wide context is created on first use on
+ * the device named by AMVHIP_DEVICE (default 0); like amvlib, these entry points are not
+ * re-entrant.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#include "../../include/amvhip.h"
+
+static amvhip_ctx *g_ctx;
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+
+static void make_ctx(void)
+{
+    const char *e = getenv("AMVHIP_DEVICE");
+    if (amvhip_create(&g_ctx, e ? atoi(e) : 0) != AMVHIP_OK) g_ctx = NULL;
+}
+
+static amvhip_ctx *ctx(void)
+{
+    pthread_once(&g_once, make_ctx);
+    return g_ctx;
+}
+
+/* ---- AmvJpeg.h ------------------------------------------------------------------------- */
+
+void PrepareForVideoDecode(AMVInfo *info)
+{
+    (void)info; /* the reference rebuilt its constant tables here; ours live in the code object */
+}
+
+int AmvJpegDecode(AMVInfo *info, FRAMEBUFF *inbuff, VIDEOBUFF *video)
+{
+    amvhip_ctx *c;
+    uint64_t off = 0, need;
+    uint32_t len;
+    int32_t st = 0;
+    unsigned char *tmp;
+    int rc;
+
+    if (info == NULL) return -1;                                  /* AmvJpeg.c:1519 */
+    if (inbuff == NULL || video == NULL || inbuff->videobuff == NULL || video->fbmpdat == NULL) return -1;
+    if ((c = ctx()) == NULL) return -1;
+    len = inbuff->videobufflen;
+    need = amvhip_frame_bytes(info->dwWidth, info->dwHeight);
+    if (need == 0) return -1;
+    /* amvlib sizes the caller's buffer as W*H*3 (AMVDec.c:277); rows are padded to 4 bytes
+     * (AmvJpeg.c:1524), so decode into a full-stride frame and hand back what fits */
+    if (video->len != 0 && video->len < need) {
+        tmp = (unsigned char *)malloc(need);
+        if (tmp == NULL) return -1;
+        rc = amvhip_decode_batch(c, inbuff->videobuff, len, &off, &len, 1, info->dwWidth, info->dwHeight, 0, tmp, &st);
+        if (rc == AMVHIP_OK) memcpy(video->fbmpdat, tmp, video->len);
+        free(tmp);
+    } else {
+        rc = amvhip_decode_batch(c, inbuff->videobuff, len, &off, &len, 1, info->dwWidth, info->dwHeight, 0,
+                                 video->fbmpdat, &st);
+    }
+    return (rc == AMVHIP_OK && st == 0) ? 0 : -1;                 /* AmvJpeg.c:1531-1538 */
+}
+
+int decode_amv_frame(const unsigned char *chunk, unsigned int len, unsigned int width, unsigned int height,
+                     unsigned char *bgr_out)
+{
+    amvhip_ctx *c = ctx();
+    uint64_t off = 0;
+    int32_t st = 0;
+    if (c == NULL || chunk == NULL || bgr_out == NULL) return -1;
+    if (amvhip_decode_batch(c, chunk, len, &off, &len, 1, width, height, 0, bgr_out, &st) != AMVHIP_OK) return -1;
+    return st == 0 ? 0 : -1;
+}
+
+int encode_amv_frame(const unsigned char *pixels, unsigned int stride, unsigned int width, unsigned int height,
+                     int is_bgr, unsigned char *chunk_out, unsigned int cap)
+{
+    amvhip_ctx *c = ctx();
+    uint64_t off = 0;
+    uint32_t len = 0;
+    if (c == NULL || pixels == NULL || chunk_out == NULL) return -1;
+    if (amvhip_encode_batch(c, pixels, stride, is_bgr, 1, width, height, AMVHIP_QBIAS_AMV, chunk_out, cap, &off, &len) != AMVHIP_OK)
+        return -1;
+    return (int)len;
+}
+
+/* ---- AdpcmIma.h ------------------------------------------------------------------------ */
+
+int AdpcmImaDecodeFrame(ADPCMContext *c, void *data, int *data_size, unsigned char *buf, int buf_size)
+{
+    amvhip_ctx *h;
+    unsigned char *chunk;
+    uint64_t off = 0, pcm_off = 0;
+    uint32_t len;
+    int32_t fin[2] = { 0, 0 };
+    int n4, idx, rc;
+
+    if (data == NULL || !buf_size) return -1;                     /* AdpcmIma.c:216-217 */
+    if (c == NULL || buf == NULL || buf_size < 0) return -1;
+    if (c->channel == 2) return -1;                               /* AMV audio is mono; no stereo path here */
+    if ((h = ctx()) == NULL) return -1;
+    /* the reference consumes input 4 bytes at a time (AdpcmIma.c:225-237) and so reads up to 3
+     * bytes past buf_size; those bytes are taken as zero here */
+    n4 = (buf_size + 3) & ~3;
+    chunk = (unsigned char *)calloc(1, (size_t)n4 + 8);
+    if (chunk == NULL) return -1;
+    idx = c->status[0].step_index;
+    if (idx < 0) idx = 0;
+    if (idx > 88) idx = 88;
+    chunk[0] = (unsigned char)(c->status[0].predictor & 0xff);
+    chunk[1] = (unsigned char)((c->status[0].predictor >> 8) & 0xff);
+    chunk[2] = (unsigned char)idx;
+    memcpy(chunk + 8, buf, (size_t)buf_size);
+    len = (uint32_t)n4 + 8;
+    rc = amvhip_adpcm_decode_batch(h, chunk, len, &off, &len, 1, (int16_t *)data, 2ull * (uint64_t)n4, &pcm_off, fin);
+    free(chunk);
+    if (rc != AMVHIP_OK) return -1;
+    c->status[0].predictor = fin[0];
+    c->status[0].step_index = (short)fin[1];
+    if (data_size) *data_size = 4 * n4;                           /* :239 */
+    return n4;                                                    /* :241 src - buf */
+}
+
+int AdpcmImaEncodeFrame(ADPCMContext *c, int channels, int frame_size, unsigned char *frame, int buf_size, void *data)
+{
+    amvhip_ctx *h;
+    int32_t st[2];
+    int rc;
+    if (c == NULL || frame == NULL || data == NULL || channels != 1) return -1;
+    if ((h = ctx()) == NULL) return -1;
+    st[0] = c->status[0].prev_sample;
+    st[1] = c->status[0].step_index;
+    rc = amvhip_adpcm_wav_encode_frame(h, (const int16_t *)data, frame_size, st, frame, buf_size);
+    if (rc < 0) return -1;
+    c->status[0].prev_sample = st[0];
+    c->status[0].step_index = (short)st[1];
+    return rc;
+}
+
+/* ---- AMVDec.h: container reader --------------------------------------------------------
+ * On-disk layout (AMVHeader.h:18-139 with 32-bit DWORDs; offsets in bytes):
+ *   0 'RIFF' 8 'AMV ' 12 'LIST' 20 'hdrl' 24 'amvh' 32 us/frame 64 width 68 height 72 fps
+ *   84 sec 85 min 86 hour(u16) 88 'LIST' 96 'strl' 100 'strh' 164 'strf' 208 'LIST' 216 'strl'
+ *   220 'strh' 276 'strf' 284 WAVEFORMATEX fields 304 'LIST' 312 'movi' 316 first chunk      */
+
+#define AMV_HDR_BYTES 304
+
+static uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static int is4(const unsigned char *p, const char *cc) { return memcmp(p, cc, 4) == 0; }
+
+AMVDecoder *AmvOpen(const char *amvname)
+{
+    FILE *fp;
+    AMVDecoder *amv;
+    unsigned char h[AMV_HDR_BYTES + 12];
+    size_t got;
+
+    if (amvname == NULL) return NULL;
+    amv = (AMVDecoder *)calloc(1, sizeof(AMVDecoder));
+    if (amv == NULL) return NULL;
+    fp = fopen(amvname, "rb");
+    if (!fp) { free(amv); return NULL; }
+    got = fread(h, 1, sizeof h, fp);
+    fclose(fp);
+    /* AMVDec.c:50-93: every four-cc of the fixed header must match */
+    if (got != sizeof h || !is4(h, "RIFF") || !is4(h + 8, "AMV ") || !is4(h + 12, "LIST") || !is4(h + 20, "hdrl") ||
+        !is4(h + 24, "amvh") || !is4(h + 88, "LIST") || !is4(h + 96, "strl") || !is4(h + 100, "strh") ||
+        !is4(h + 164, "strf") || !is4(h + 208, "LIST") || !is4(h + 216, "strl") || !is4(h + 220, "strh") ||
+        !is4(h + 276, "strf") || !is4(h + 304, "LIST") || !is4(h + 312, "movi")) {
+        free(amv);
+        return NULL;
+    }
+    amv->amvinfo.dwMicroSecPerFrame = rd32(h + 32);               /* :95-101 */
+    amv->amvinfo.dwWidth = rd32(h + 64);
+    amv->amvinfo.dwHeight = rd32(h + 68);
+    amv->amvinfo.dwSpeed = rd32(h + 72);
+    amv->amvinfo.dwTimeSec = h[84];
+    amv->amvinfo.dwTimeMin = h[85];
+    amv->amvinfo.dwTimeHour = rd16(h + 86);
+    amv->amvinfo.wFormatTag = rd16(h + 284);                      /* :103-110 */
+    amv->amvinfo.nChannels = rd16(h + 286);
+    amv->amvinfo.nSamplesPerSec = rd32(h + 288);
+    amv->amvinfo.nAvgBytesPerSec = rd32(h + 292);
+    amv->amvinfo.nBlockAlign = rd16(h + 296);
+    amv->amvinfo.wBitsPerSample = rd16(h + 298);
+    amv->amvinfo.cbSize = rd16(h + 300);
+    amv->amvinfo.wSamplesPerBlock = rd16(h + 302);
+    amv->totalframe = (amv->amvinfo.dwTimeHour * 60 * 60 + amv->amvinfo.dwTimeMin * 60 + amv->amvinfo.dwTimeSec) *
+                      amv->amvinfo.dwSpeed;                        /* :112-114 */
+    amv->amvfilename = strdup(amvname);
+    amv->opened = 1;
+    amv->fileseekpos = AMV_HDR_BYTES + 12;
+    amv->dataseekpos = amv->fileseekpos;                          /* :117 */
+    return amv;
+}
+
+void AmvClose(AMVDecoder *amv)
+{
+    if (amv == NULL) return;                                      /* AMVDec.c:131-148 */
+    free(amv->amvfilename);
+    free(amv->framebuf.audiobuff);
+    free(amv->framebuf.videobuff);
+    free(amv->videobuf.fbmpdat);
+    free(amv->audiobuf.audiodata);
+    free(amv);
+}
+
+static int read_chunk(FILE *fp, AMVDecoder *amv, const char *cc, unsigned char **buf, unsigned int *len)
+{
+    unsigned char hd[8];
+    uint32_t n;
+    if (fread(hd, 1, 8, fp) != 8 || !is4(hd, cc)) return -1;
+    n = rd32(hd + 4);
+    free(*buf);
+    *buf = (unsigned char *)malloc(n ? n : 1);
+    if (*buf == NULL) return -1;
+    if (fread(*buf, 1, n, fp) != n) return -1;
+    *len = n;
+    amv->fileseekpos += 8 + (long)n;
+    return 0;
+}
+
+int AmvReadNextFrame(AMVDecoder *amv)
+{
+    FILE *fp;
+    FRAMEBUFF *fb;
+    unsigned char cc[8];
+    int rc = -1;
+
+    if (amv == NULL) return -1;                                   /* AMVDec.c:157-160 */
+    if (!amv->opened || amv->amvfilename == NULL) return -1;
+    fb = &amv->framebuf;
+    fp = fopen(amv->amvfilename, "rb");                           /* the reference reopens per frame, :164 */
+    if (fp == NULL) return -1;
+    if (fseek(fp, amv->fileseekpos, SEEK_SET) != 0 || fread(cc, 1, 8, fp) != 8) { fclose(fp); return -1; }
+    if (is4(cc, "AMV_") && is4(cc + 4, "END_")) {                 /* :173-190 end of stream */
+        free(fb->videobuff); fb->videobuff = NULL;
+        free(fb->audiobuff); fb->audiobuff = NULL;
+        fb->videobufflen = fb->audiobufflen = 0;
+        fb->framenum = -1;
+        amv->fileseekpos += 8;
+        fclose(fp);
+        return 0;
+    }
+    fseek(fp, amv->fileseekpos, SEEK_SET);
+    if (read_chunk(fp, amv, "00dc", &fb->videobuff, &fb->videobufflen) == 0 &&   /* :171,196-208 */
+        read_chunk(fp, amv, "01wb", &fb->audiobuff, &fb->audiobufflen) == 0) {   /* :213-231 */
+        fb->framenum++;                                           /* :233-234 */
+        amv->currentframe = (unsigned int)fb->framenum;
+        rc = 0;
+    }
+    fclose(fp);
+    return rc;
+}
+
+int AmvRewindFrameStart(AMVDecoder *amv)
+{
+    if (amv == NULL) return -1;                                   /* AMVDec.c:244-247 */
+    if (!amv->opened || amv->amvfilename == NULL) return -1;
+    amv->fileseekpos = amv->dataseekpos;                          /* :253 */
+    return 0;
+}
+
+int AmvVideoDecode(AMVDecoder *amv)
+{
+    FRAMEBUFF *fb;
+    VIDEOBUFF *vb;
+    uint64_t full;
+
+    if (amv == NULL) return -1;                                   /* AMVDec.c:265-268 */
+    if (!amv->opened) return -1;
+    fb = &amv->framebuf;
+    if (fb->videobuff == NULL || fb->videobufflen == 0) return -1; /* :271-272 */
+    vb = &amv->videobuf;
+    full = amvhip_frame_bytes(amv->amvinfo.dwWidth, amv->amvinfo.dwHeight);
+    vb->len = amv->amvinfo.dwHeight * amv->amvinfo.dwWidth * 3;   /* :277 */
+    free(vb->fbmpdat);
+    vb->fbmpdat = (unsigned char *)malloc(full > vb->len ? full : (vb->len ? vb->len : 1));
+    if (vb->fbmpdat == NULL) return -2;                           /* :281-282 */
+    memset(vb->fbmpdat, 0, full > vb->len ? full : vb->len);      /* :283 */
+    if (full > vb->len) {                                         /* room for the padded rows: decode in place */
+        unsigned int keep = vb->len;
+        int rc;
+        vb->len = (unsigned int)full;
+        rc = AmvJpegDecode(&amv->amvinfo, fb, vb);
+        vb->len = keep;
+        return rc;
+    }
+    return AmvJpegDecode(&amv->amvinfo, fb, vb);                  /* :285 */
+}
+
+int AmvAudioDecode(AMVDecoder *amv)
+{
+    FRAMEBUFF *fb;
+    AUDIOBUFF *ab;
+    ADPCMContext audio;
+    int rtn, declen = 0;
+
+    if (amv == NULL) return -1;                                   /* AMVDec.c:296-299 */
+    if (!amv->opened) return -1;
+    fb = &amv->framebuf;
+    if (fb->audiobuff == NULL || fb->audiobufflen == 0) return -1; /* :302-303 */
+    if (fb->audiobufflen <= 8) return -1;
+    ab = &amv->audiobuf;
+    memset(&audio, 0, sizeof audio);
+    audio.channel = amv->amvinfo.nChannels;
+    audio.status[0].predictor = (short)rd16(fb->audiobuff);       /* :312 */
+    audio.status[0].step_index = fb->audiobuff[2];                /* :313 */
+    audio.status[1] = audio.status[0];                            /* :316-317 */
+    ab->len = rd32(fb->audiobuff + 4) * 2;                        /* :319-321 */
+    if (ab->len < (fb->audiobufflen - 8) * 4) ab->len = (fb->audiobufflen - 8) * 4;  /* :322-323 */
+    free(ab->audiodata);
+    ab->audiodata = (short *)malloc((size_t)ab->len + 16);        /* :326 */
+    if (ab->audiodata == NULL) return -2;
+    memset(ab->audiodata, 0, ab->len);                            /* :329 */
+    rtn = AdpcmImaDecodeFrame(&audio, ab->audiodata, &declen, fb->audiobuff + 8, (int)fb->audiobufflen - 8);
+    if (rtn > 0) {                                                /* :333-337 */
+        ab->len = (unsigned int)declen;
+        return 0;
+    }
+    return rtn;
+}

@@ -1,0 +1,289 @@
+/*
+ * amvhip.h -- C ABI of libamvhip.so, the MI355X (gfx950) AMV codec hot path.
+ *
+ * Two surfaces, both plain C (no torch / C++ types in any signature):
+ *
+ *  1. The amvlib call surface of the reference (tomvanbraeckel/amv-codec-tools),
+ *     same names, argument meaning, struct layouts and return codes, so that a host
+ *     built against C-AMVDecoder/amvlib/{AMVDec.h,AmvJpeg.h,AdpcmIma.h} links against
+ *     this library instead of AmvLib.dll / the amvlib objects.  Each declaration cites
+ *     the reference interface it replaces (paths relative to the reference tree).
+ *
+ *  2. A batch surface (new): many independent chunks per call, device-resident
+ *     inputs/outputs, asynchronous on a caller-supplied HIP stream.  This is what the
+ *     AMVmuxer / a player loop should call when it has more than one frame in hand;
+ *     INTEGRATION.md shows the binding.
+ *
+ * Every entry point runs on the GPU.  There is no CPU fallback: if no HIP device is
+ * usable the calls fail (amvlib surface: -1 / NULL, batch surface: AMVHIP_ERR_DEVICE).
+ */
+#ifndef AMVHIP_H
+#define AMVHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* =====================================================================================
+ * 1. amvlib surface
+ * =================================================================================== */
+
+/* C-AMVDecoder/amvlib/AMVDec.h:29-47 */
+typedef struct _amv_important_header_data {
+    unsigned int dwMicroSecPerFrame;
+    unsigned int dwWidth;
+    unsigned int dwHeight;
+    unsigned int dwSpeed;
+    unsigned int dwTimeSec;
+    unsigned int dwTimeMin;
+    unsigned int dwTimeHour;
+    unsigned short wFormatTag;
+    unsigned short nChannels;
+    unsigned int nSamplesPerSec;
+    unsigned int nAvgBytesPerSec;
+    unsigned short nBlockAlign;
+    unsigned short wBitsPerSample;
+    unsigned short cbSize;
+    unsigned short wSamplesPerBlock;
+} AMVInfo;
+
+/* AMVDec.h:50-57 */
+typedef struct _frame_buffer_struct {
+    unsigned char *videobuff;
+    unsigned char *audiobuff;
+    unsigned int videobufflen;
+    unsigned int audiobufflen;
+    int framenum;
+} FRAMEBUFF;
+
+/* AMVDec.h:59-63 */
+typedef struct _video_buffer_struct {
+    unsigned char *fbmpdat;
+    unsigned int len;
+} VIDEOBUFF;
+
+/* AMVDec.h:65-71 */
+#define AUDIO_FILE_TYPE_PCM 0
+#define AUDIO_FILE_TYPE_ADPCM_IMA 1
+typedef struct _audio_buffer_struct {
+    short *audiodata;
+    unsigned int len;
+} AUDIOBUFF;
+
+/* AMVDec.h:74-91 */
+typedef struct _amv_decode_struct {
+    char *amvfilename;
+    int opened;
+    long dataseekpos;
+    long fileseekpos;
+    AMVInfo amvinfo;
+    unsigned int currentframe;
+    unsigned int totalframe;
+    FRAMEBUFF framebuf;
+    VIDEOBUFF videobuf;
+    AUDIOBUFF audiobuf;
+} AMVDecoder;
+
+/* C-AMVDecoder/amvlib/AdpcmIma.h:11-25 */
+typedef struct ADPCMChannelStatus {
+    int predictor;
+    short int step_index;
+    int step;
+    int prev_sample;
+} ADPCMChannelStatus;
+
+typedef struct ADPCMContext {
+    int channel;
+    ADPCMChannelStatus status[2];
+    short sample_buffer[32];
+} ADPCMContext;
+
+/* AmvJpeg.h:95-96 (AmvJpeg.c:1396,1515).  PrepareForVideoDecode rebuilt constant tables per
+ * frame in the reference; here the tables live in the code object and the call only
+ * validates its argument.  AmvJpegDecode: video->fbmpdat must hold
+ * ((dwWidth*24+31)/32)*4*dwHeight bytes; returns 0 ok, -1 on any decode error. */
+void PrepareForVideoDecode(AMVInfo *info);
+int AmvJpegDecode(AMVInfo *info, FRAMEBUFF *inbuff, VIDEOBUFF *video);
+
+/* AdpcmIma.h:28-32 (AdpcmIma.c:206,92).  Decode: mono AMV nibble order (high nibble first),
+ * returns bytes consumed (>0) or -1.  Encode: the reference's IMA-WAV-layout routine, which
+ * nothing in the reference calls; kept for ABI completeness. */
+int AdpcmImaDecodeFrame(ADPCMContext *c, void *data, int *data_size, unsigned char *buf, int buf_size);
+int AdpcmImaEncodeFrame(ADPCMContext *c, int channels, int frame_size, unsigned char *frame,
+                        int buf_size, void *data);
+
+/* AMVDec.h:94-109 (AMVDec.c:15,131,150,240,259,288,358,384).  The container reader is
+ * restated LP64-safe (the reference's AMVHeader.h uses `unsigned long` DWORDs). */
+AMVDecoder *AmvOpen(const char *amvname);
+void AmvClose(AMVDecoder *amv);
+int AmvReadNextFrame(AMVDecoder *amv);
+int AmvRewindFrameStart(AMVDecoder *amv);
+int AmvVideoDecode(AMVDecoder *amv);
+int AmvAudioDecode(AMVDecoder *amv);
+
+/* the names BASELINE.json's north_star uses; thin aliases of the single-frame paths.
+ * decode: chunk -> BGR24 (amvlib layout); encode: RGB24/BGR24 top-down -> chunk, returns length. */
+int decode_amv_frame(const unsigned char *chunk, unsigned int len, unsigned int width,
+                     unsigned int height, unsigned char *bgr_out);
+int encode_amv_frame(const unsigned char *pixels, unsigned int stride, unsigned int width,
+                     unsigned int height, int is_bgr, unsigned char *chunk_out, unsigned int cap);
+
+/* =====================================================================================
+ * 2. batch surface
+ * =================================================================================== */
+
+typedef struct amvhip_ctx amvhip_ctx;
+
+#define AMVHIP_OK 0
+#define AMVHIP_ERR_ARG -1     /* null pointer, zero/odd size, ... */
+#define AMVHIP_ERR_DEVICE -2  /* no usable HIP device / HIP call failed (see amvhip_last_error) */
+#define AMVHIP_ERR_NOMEM -3
+#define AMVHIP_ERR_SPACE -4   /* output capacity too small */
+
+/* per-frame decode status bits written to status[i] (0 = frame ok) */
+#define AMVHIP_ST_FORMAT 1u    /* invalid Huffman code (amvlib: FUNC_FORMAT_ERROR, AmvJpeg.c:887) */
+#define AMVHIP_ST_OVERRUN 2u   /* coefficient index ran past 63 (amvlib writes out of bounds there) */
+#define AMVHIP_ST_TRUNCATED 4u /* scan needs more bits than the chunk holds */
+
+/* decode flags */
+#define AMVHIP_FLAG_ZIGZAG_FIXED 1u /* standard zig-zag instead of amvlib's table (AmvJpeg.c:138) */
+
+/* encode quantiser bias in 1/256 of a step: 0 = the reference's AMV setting
+ * (mpegvideo_enc.c:492-496), 128 = its MJPEG setting (round to nearest, :488-490). */
+#define AMVHIP_QBIAS_AMV 0
+#define AMVHIP_QBIAS_MJPEG 128
+
+int amvhip_create(amvhip_ctx **ctx, int device);
+void amvhip_destroy(amvhip_ctx *ctx);
+const char *amvhip_last_error(const amvhip_ctx *ctx);
+int amvhip_device(const amvhip_ctx *ctx);
+
+/* geometry helpers (AmvJpeg.c:420,1524: stride; :1276-1284: MCU grid) */
+uint32_t amvhip_stride(uint32_t width);
+uint64_t amvhip_frame_bytes(uint32_t width, uint32_t height);
+uint32_t amvhip_encode_bound(uint32_t width, uint32_t height);
+
+/*
+ * Video decode, device-resident.  Replaces a loop of AmvVideoDecode/AmvJpegDecode calls
+ * (AMVDec.c:259-286, AmvJpeg.c:1515-1539) over n independent chunks.
+ *   d_blob     : all chunks back to back (each "FF D8" scan "FF D9"), blob_bytes long
+ *   d_offs[i]  : byte offset of chunk i in d_blob;  d_lens[i]: its length
+ *   d_out      : n * amvhip_frame_bytes(w,h); frame i is BGR24, row 0 = top, rows padded to
+ *                amvhip_stride(w); pixels of MCUs after a failing one are zero (AMVDec.c:283)
+ *   d_status   : n int32, AMVHIP_ST_* bits
+ *   stream     : hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue.
+ * Workspace is owned by ctx and grown on demand (a hipMalloc on first use of a larger
+ * batch; none in steady state).
+ */
+int amvhip_decode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_bytes,
+                            const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n,
+                            uint32_t width, uint32_t height, uint32_t flags,
+                            uint8_t *d_out, int32_t *d_status, void *stream);
+
+/* Same with host buffers: H2D, decode, D2H, synchronous. */
+int amvhip_decode_batch(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_bytes,
+                        const uint64_t *offs, const uint32_t *lens, uint32_t n,
+                        uint32_t width, uint32_t height, uint32_t flags,
+                        uint8_t *out, int32_t *status);
+
+/* Stage access for parity tests: entropy stage only.  d_coef: n * nmcu*6*64 int16,
+ * DC-predicted quantised coefficients in bitstream order (amvlib MCUBuffer,
+ * AmvJpeg.c:1200-1223); d_nmcu_ok: MCUs decoded before the first error. */
+int amvhip_huffman_decode_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_bytes,
+                              const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n,
+                              uint32_t width, uint32_t height,
+                              int16_t *d_coef, int32_t *d_status, uint32_t *d_nmcu_ok, void *stream);
+/* Stage access: dequantise + IDCT + colour + store from coefficients
+ * (IQtIZzBlock/Fast_IDCT/GetYUV/StoreBuffer, AmvJpeg.c:1010-1059,754-840). */
+int amvhip_reconstruct_dev(amvhip_ctx *ctx, const int16_t *d_coef, const uint32_t *d_nmcu_ok,
+                           uint32_t n, uint32_t width, uint32_t height, uint32_t flags,
+                           uint8_t *d_out, void *stream);
+
+/*
+ * Video encode, device-resident.  Replaces amv_encode_picture + the RGB front end
+ * (mjpegenc.c:454-472, imgconvert_template.h:654, mpegvideo_enc.c:3647, mjpegenc.c:379-450,
+ * :282-355) over n frames.
+ *   d_pix      : n frames, RGB24 (is_bgr=0) or BGR24 (is_bgr=1), top-down, pix_stride bytes/row,
+ *                frame i at d_pix + i*pix_stride*height; width and height must be even
+ *   d_blob     : output, n * amvhip_encode_bound(w,h) bytes capacity required (blob_cap);
+ *                chunks are written back to back in frame order
+ *   d_offs/d_lens : n entries written
+ */
+int amvhip_encode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_pix, uint32_t pix_stride, int is_bgr,
+                            uint32_t n, uint32_t width, uint32_t height, uint32_t qbias,
+                            uint8_t *d_blob, uint64_t blob_cap, uint64_t *d_offs, uint32_t *d_lens,
+                            void *stream);
+int amvhip_encode_batch(amvhip_ctx *ctx, const uint8_t *pix, uint32_t pix_stride, int is_bgr,
+                        uint32_t n, uint32_t width, uint32_t height, uint32_t qbias,
+                        uint8_t *blob, uint64_t blob_cap, uint64_t *offs, uint32_t *lens);
+/* Stage access: quantised coefficients (zig-zag order, not predicted), n*nmcu*6*64 int16 */
+int amvhip_encode_coefs_dev(amvhip_ctx *ctx, const uint8_t *d_pix, uint32_t pix_stride, int is_bgr,
+                            uint32_t n, uint32_t width, uint32_t height, uint32_t qbias,
+                            int16_t *d_coef, void *stream);
+
+/*
+ * IMA ADPCM, AMV chunk layout (AMVDec.c:312-320 + AdpcmIma.c:206-242; adpcm.c:461-498).
+ * decode: chunk i = {s16 predictor, u8 step_index, u8 0, u32 nsamples, nibbles}; writes
+ *         2*(len-8) samples at d_pcm + d_pcm_offs[i] (offsets in samples).
+ * encode: chunk i takes d_nsamp[i] (even) samples from d_pcm + d_pcm_offs[i] and writes
+ *         8 + nsamp/2 bytes at d_blob + d_offs[i].  step_index handling:
+ *         d_step_in != NULL : chunk i starts from d_step_in[i] (independent chunks);
+ *         d_step_in == NULL : the reference's behaviour, step_index carried from chunk i-1
+ *                             (chunk 0 starts at 0); chunks of one call form one stream.
+ */
+int amvhip_adpcm_decode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_bytes,
+                                  const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n,
+                                  int16_t *d_pcm, const uint64_t *d_pcm_offs,
+                                  int32_t *d_final_state /* optional: n x {predictor, step_index} */,
+                                  void *stream);
+int amvhip_adpcm_encode_batch_dev(amvhip_ctx *ctx, const int16_t *d_pcm, const uint64_t *d_pcm_offs,
+                                  const uint32_t *d_nsamp, uint32_t n, const int32_t *d_step_in,
+                                  uint8_t *d_blob, const uint64_t *d_offs, void *stream);
+/* host-buffer forms (H2D, kernel, D2H, synchronous).  pcm_samples / blob_bytes are the sizes of
+ * the whole pcm / blob arrays the offsets index into. */
+int amvhip_adpcm_decode_batch(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_bytes,
+                              const uint64_t *offs, const uint32_t *lens, uint32_t n,
+                              int16_t *pcm, uint64_t pcm_samples, const uint64_t *pcm_offs,
+                              int32_t *final_state);
+int amvhip_adpcm_encode_batch(amvhip_ctx *ctx, const int16_t *pcm, uint64_t pcm_samples,
+                              const uint64_t *pcm_offs, const uint32_t *nsamp, uint32_t n,
+                              const int32_t *step_in, uint8_t *blob, uint64_t blob_bytes,
+                              const uint64_t *offs);
+/* amvlib's IMA-WAV-layout encoder (AdpcmIma.c:43-160), one mono frame, host buffers; backs
+ * AdpcmImaEncodeFrame.  state = {prev_sample (out), step_index (in/out)}; returns bytes written. */
+int amvhip_adpcm_wav_encode_frame(amvhip_ctx *ctx, const int16_t *samples, int frame_size,
+                                  int32_t state[2], uint8_t *frame, int buf_size);
+
+/* Seeded synthetic sources of BASELINE.md section 4, generated on the device
+ * (integer-only; byte-identical to the CPU generator used by the parity tests). */
+int amvhip_synth_frames_dev(amvhip_ctx *ctx, uint32_t seed, uint32_t first_frame, uint32_t n,
+                            uint32_t width, uint32_t height, uint8_t *d_rgb, void *stream);
+int amvhip_synth_audio_dev(amvhip_ctx *ctx, uint32_t seed, uint64_t first_sample, uint64_t n,
+                           int16_t *d_pcm, void *stream);
+
+/*
+ * Kernel timing with HIP events recorded on the launch stream around every kernel
+ * launch (bench.py's roofline leg).  Off by default.  amvhip_prof_read synchronises the
+ * events recorded since the last reset and returns launches / summed milliseconds.
+ */
+#define AMVHIP_K_HUFFMAN 0
+#define AMVHIP_K_RECON 1
+#define AMVHIP_K_FDCT 2
+#define AMVHIP_K_PACK 3
+#define AMVHIP_K_ADPCM_DEC 4
+#define AMVHIP_K_ADPCM_ENC 5
+#define AMVHIP_K_SYNTH 6
+#define AMVHIP_K_COUNT 8
+void amvhip_prof_enable(amvhip_ctx *ctx, int on);
+void amvhip_prof_reset(amvhip_ctx *ctx);
+int amvhip_prof_read(amvhip_ctx *ctx, int kernel, uint64_t *launches, double *total_ms);
+const char *amvhip_kernel_name(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMVHIP_H */

@@ -1,0 +1,861 @@
+/*
+ * amv_oracle.c -- CPU restatement of the AMV codec hot path.  TEST INFRASTRUCTURE ONLY.
+ * See amv_oracle.h for the rules about who may load this and how it is pinned.
+ *
+ * Compile with -fwrapv (signed wrap-around is relied on, as the reference relies on
+ * two's-complement behaviour of its compiler).  Reference citations are file:line
+ * under /root/reference:
+ *   amvlib = C-AMVDecoder/amvlib, lavc = AMVmuxer/ffmpeg/libavcodec
+ */
+#include "amv_oracle.h"
+#include <string.h>
+#include <stdlib.h>
+#include <math.h>
+
+/* ------------------------------------------------------------------------------------
+ * constant tables (data of the format, amvlib/AmvJpeg.c:30-39,52-61,65-131,133-150)
+ * ---------------------------------------------------------------------------------- */
+static const uint8_t k_qt_luma[64] = { /* zig-zag order, AmvJpeg.c:30-39 */
+     8,  6,  6,  7,  6,  5,  8,  7,  7,  7,  9,  9,  8, 10, 12, 20,
+    13, 12, 11, 11, 12, 25, 18, 19, 15, 20, 29, 26, 31, 30, 29, 26,
+    28, 28, 32, 36, 46, 39, 32, 34, 44, 39, 28, 28, 40, 55, 41, 44,
+    48, 49, 52, 52, 52, 31, 39, 57, 61, 56, 50, 60, 46, 51, 52, 50 };
+static const uint8_t k_qt_chroma[64] = { /* zig-zag order, AmvJpeg.c:52-61 */
+     9,  9,  9, 12, 11, 12, 24, 13, 13, 24, 50, 33, 28, 33, 50, 50,
+    50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50,
+    50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50,
+    50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50 };
+
+/* JPEG K.3 tables: number of codes of each length 1..16, then the symbols (AmvJpeg.c:65-131) */
+static const uint8_t k_bits[4][16] = {
+    { 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0 },          /* DC luma   */
+    { 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0 },          /* DC chroma */
+    { 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d },       /* AC luma   */
+    { 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77 } };     /* AC chroma */
+static const uint8_t k_val_dc[12] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 };
+static const uint8_t k_val_ac_luma[162] = {
+    0x01,0x02,0x03,0x00,0x04,0x11,0x05,0x12,0x21,0x31,0x41,0x06,0x13,0x51,0x61,0x07,
+    0x22,0x71,0x14,0x32,0x81,0x91,0xa1,0x08,0x23,0x42,0xb1,0xc1,0x15,0x52,0xd1,0xf0,
+    0x24,0x33,0x62,0x72,0x82,0x09,0x0a,0x16,0x17,0x18,0x19,0x1a,0x25,0x26,0x27,0x28,
+    0x29,0x2a,0x34,0x35,0x36,0x37,0x38,0x39,0x3a,0x43,0x44,0x45,0x46,0x47,0x48,0x49,
+    0x4a,0x53,0x54,0x55,0x56,0x57,0x58,0x59,0x5a,0x63,0x64,0x65,0x66,0x67,0x68,0x69,
+    0x6a,0x73,0x74,0x75,0x76,0x77,0x78,0x79,0x7a,0x83,0x84,0x85,0x86,0x87,0x88,0x89,
+    0x8a,0x92,0x93,0x94,0x95,0x96,0x97,0x98,0x99,0x9a,0xa2,0xa3,0xa4,0xa5,0xa6,0xa7,
+    0xa8,0xa9,0xaa,0xb2,0xb3,0xb4,0xb5,0xb6,0xb7,0xb8,0xb9,0xba,0xc2,0xc3,0xc4,0xc5,
+    0xc6,0xc7,0xc8,0xc9,0xca,0xd2,0xd3,0xd4,0xd5,0xd6,0xd7,0xd8,0xd9,0xda,0xe1,0xe2,
+    0xe3,0xe4,0xe5,0xe6,0xe7,0xe8,0xe9,0xea,0xf1,0xf2,0xf3,0xf4,0xf5,0xf6,0xf7,0xf8,
+    0xf9,0xfa };
+static const uint8_t k_val_ac_chroma[162] = {
+    0x00,0x01,0x02,0x03,0x11,0x04,0x05,0x21,0x31,0x06,0x12,0x41,0x51,0x07,0x61,0x71,
+    0x13,0x22,0x32,0x81,0x08,0x14,0x42,0x91,0xa1,0xb1,0xc1,0x09,0x23,0x33,0x52,0xf0,
+    0x15,0x62,0x72,0xd1,0x0a,0x16,0x24,0x34,0xe1,0x25,0xf1,0x17,0x18,0x19,0x1a,0x26,
+    0x27,0x28,0x29,0x2a,0x35,0x36,0x37,0x38,0x39,0x3a,0x43,0x44,0x45,0x46,0x47,0x48,
+    0x49,0x4a,0x53,0x54,0x55,0x56,0x57,0x58,0x59,0x5a,0x63,0x64,0x65,0x66,0x67,0x68,
+    0x69,0x6a,0x73,0x74,0x75,0x76,0x77,0x78,0x79,0x7a,0x82,0x83,0x84,0x85,0x86,0x87,
+    0x88,0x89,0x8a,0x92,0x93,0x94,0x95,0x96,0x97,0x98,0x99,0x9a,0xa2,0xa3,0xa4,0xa5,
+    0xa6,0xa7,0xa8,0xa9,0xaa,0xb2,0xb3,0xb4,0xb5,0xb6,0xb7,0xb8,0xb9,0xba,0xc2,0xc3,
+    0xc4,0xc5,0xc6,0xc7,0xc8,0xc9,0xca,0xd2,0xd3,0xd4,0xd5,0xd6,0xd7,0xd8,0xd9,0xda,
+    0xe2,0xe3,0xe4,0xe5,0xe6,0xe7,0xe8,0xe9,0xea,0xf2,0xf3,0xf4,0xf5,0xf6,0xf7,0xf8,
+    0xf9,0xfa };
+static const uint8_t *const k_vals[4] = { k_val_dc, k_val_dc, k_val_ac_luma, k_val_ac_chroma };
+
+/* natural position (row, col) -> index in the bitstream's zig-zag order.
+ * amvlib's copy (AmvJpeg.c:133-143) has 37 at [3][4] where the standard has 31. */
+static const uint8_t k_zigzag_std[64] = {
+     0,  1,  5,  6, 14, 15, 27, 28,
+     2,  4,  7, 13, 16, 26, 29, 42,
+     3,  8, 12, 17, 25, 30, 41, 43,
+     9, 11, 18, 24, 31, 40, 44, 53,
+    10, 19, 23, 32, 39, 45, 52, 54,
+    20, 22, 33, 38, 46, 51, 55, 60,
+    21, 34, 37, 47, 50, 56, 59, 61,
+    35, 36, 48, 49, 57, 58, 62, 63 };
+#define AMVLIB_QUIRK_POS (3 * 8 + 4)
+#define AMVLIB_QUIRK_VAL 37
+
+static inline int zz_index(int nat, uint32_t flags)
+{
+    if (nat == AMVLIB_QUIRK_POS && !(flags & AMVO_FLAG_ZIGZAG_FIXED))
+        return AMVLIB_QUIRK_VAL;
+    return k_zigzag_std[nat];
+}
+
+/* ------------------------------------------------------------------------------------
+ * geometry
+ * ---------------------------------------------------------------------------------- */
+uint32_t amvo_stride(uint32_t w) { return (w * 24 + 31) / 32 * 4; }   /* AmvJpeg.c:420,1524 */
+uint32_t amvo_mcus_per_row(uint32_t w) { return (w + 15) / 16; }      /* AmvJpeg.c:1276-1281 */
+uint32_t amvo_mcu_rows(uint32_t h) { return (h + 15) / 16; }          /* AmvJpeg.c:1280-1284 */
+
+/* ------------------------------------------------------------------------------------
+ * canonical Huffman bounds, PrepareForVideoDecode AmvJpeg.c:1454-1481
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    uint16_t minc[16], maxc[16];
+    int16_t pos[16];
+    uint8_t cnt[16];
+} hufbounds;
+
+static void build_bounds(hufbounds *hb, const uint8_t bits[16])
+{
+    int i = 0, j;
+    memset(hb, 0, sizeof *hb);
+    for (j = 0; j < 16; j++) hb->cnt[j] = bits[j];
+    while (hb->cnt[i] == 0) i++;                       /* :1464 */
+    hb->minc[i] = 0;                                    /* :1471 */
+    hb->maxc[i] = (uint16_t)(hb->cnt[i] - 1);           /* :1472 */
+    for (j = i + 1; j < 16; j++) {                      /* :1473-1477 */
+        hb->minc[j] = (uint16_t)((hb->maxc[j - 1] + 1) << 1);
+        hb->maxc[j] = (uint16_t)(hb->minc[j] + hb->cnt[j] - 1);
+    }
+    hb->pos[0] = 0;                                     /* :1478-1480 */
+    for (j = 1; j < 16; j++) hb->pos[j] = (int16_t)(hb->cnt[j - 1] + hb->pos[j - 1]);
+}
+
+/* ------------------------------------------------------------------------------------
+ * bit reader: ReadByte AmvJpeg.c:1061-1071 and the BitPos/CurByte handling of
+ * DecodeElement :850-863.  Bytes past the chunk read as zero (flagged TRUNCATED).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    const uint8_t *buf;
+    uint32_t len, pos;
+    int bitpos;
+    unsigned cur;
+    uint64_t consumed, valid;
+} bitrd;
+
+static void rd_byte(bitrd *b)
+{
+    unsigned v = 0;
+    if (b->pos < b->len) { v = b->buf[b->pos]; b->valid += 8; }
+    b->pos++;
+    if (v == 0xff) b->pos++;            /* :1066-1067: the byte after FF is dropped unseen */
+    b->bitpos = 8;
+    b->cur = v;
+}
+
+static unsigned rd_bit(bitrd *b)
+{
+    unsigned bit;
+    if (b->bitpos < 1) rd_byte(b);
+    b->bitpos--;
+    bit = (b->cur >> b->bitpos) & 1u;
+    b->cur &= (1u << b->bitpos) - 1u;
+    b->consumed++;
+    return bit;
+}
+
+/* DecodeElement AmvJpeg.c:842-936 */
+static int decode_element(bitrd *b, const hufbounds *hb, const uint8_t *vals, int *run, int *val)
+{
+    int code = (int)rd_bit(b), len = 1, size, sym;
+    unsigned v = 0;
+    while (hb->cnt[len - 1] == 0 || code < hb->minc[len - 1] || code > hb->maxc[len - 1]) { /* :867-869 */
+        code = (code << 1) + (int)rd_bit(b);
+        len++;
+        if (len > 16) return AMVO_ST_FORMAT;                                               /* :887 */
+    }
+    sym = vals[(uint16_t)(code - hb->minc[len - 1] + hb->pos[len - 1])];                   /* :891-892 */
+    *run = sym >> 4;
+    size = sym & 15;
+    if (size == 0) { *val = 0; return 0; }                                                 /* :895-899 */
+    for (int i = 0; i < size; i++) v = (v << 1) | rd_bit(b);                               /* :902-922 */
+    if (v >> (size - 1)) *val = (int16_t)v;                                                /* :924-927 */
+    else *val = (int16_t)-(int)(((1u << size) - 1u) - v);                                  /* :928-933 */
+    return 0;
+}
+
+/* HufBlock AmvJpeg.c:939-974 */
+static int huf_block(bitrd *b, const hufbounds hb[4], int dctab, int actab, int16_t blk[64])
+{
+    int run, val, count = 0, st;
+    st = decode_element(b, &hb[dctab], k_vals[dctab], &run, &val);
+    if (st) return st;
+    blk[count++] = (int16_t)val;
+    while (count < 64) {
+        st = decode_element(b, &hb[actab], k_vals[actab], &run, &val);
+        if (st) return st;
+        if (run == 0 && val == 0) {              /* :959-964 end of block */
+            while (count < 64) blk[count++] = 0;
+        } else {
+            if (count + run > 63) return AMVO_ST_OVERRUN; /* reference writes out of bounds here */
+            for (int i = 0; i < run; i++) blk[count++] = 0;
+            blk[count++] = (int16_t)val;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * IDCT: Fast_IDCT / idctrow / idctcol, AmvJpeg.c:1050-1059,1082-1175; W1..W7 :145-150
+ * ---------------------------------------------------------------------------------- */
+#define W1 2841
+#define W2 2676
+#define W3 2408
+#define W5 1609
+#define W6 1108
+#define W7 565
+
+/* iclp[] (AmvJpeg.c:1073-1080) covers -512..511; outside it the reference reads out of
+ * bounds, defined here as saturation. */
+static inline int32_t iclp(int32_t i) { return i < -256 ? -256 : (i > 255 ? 255 : i); }
+
+static void idct_row(int32_t *blk) /* :1082-1128 */
+{
+    int32_t x0, x1, x2, x3, x4, x5, x6, x7, x8;
+    x1 = blk[4] * 2048; x2 = blk[6]; x3 = blk[2]; x4 = blk[1]; x5 = blk[7]; x6 = blk[5]; x7 = blk[3];
+    if (!(x1 | x2 | x3 | x4 | x5 | x6 | x7)) {                 /* :1087-1092 */
+        blk[0] = blk[1] = blk[2] = blk[3] = blk[4] = blk[5] = blk[6] = blk[7] = blk[0] * 8;
+        return;
+    }
+    x0 = blk[0] * 2048 + 128;
+    x8 = W7 * (x4 + x5);
+    x4 = x8 + (W1 - W7) * x4;
+    x5 = x8 - (W1 + W7) * x5;
+    x8 = W3 * (x6 + x7);
+    x6 = x8 - (W3 - W5) * x6;
+    x7 = x8 - (W3 + W5) * x7;
+    x8 = x0 + x1;
+    x0 -= x1;
+    x1 = W6 * (x3 + x2);
+    x2 = x1 - (W2 + W6) * x2;
+    x3 = x1 + (W2 - W6) * x3;
+    x1 = x4 + x6;
+    x4 -= x6;
+    x6 = x5 + x7;
+    x5 -= x7;
+    x7 = x8 + x3;
+    x8 -= x3;
+    x3 = x0 + x2;
+    x0 -= x2;
+    x2 = (181 * (x4 + x5) + 128) >> 8;
+    x4 = (181 * (x4 - x5) + 128) >> 8;
+    blk[0] = (x7 + x1) >> 8;
+    blk[1] = (x3 + x2) >> 8;
+    blk[2] = (x0 + x4) >> 8;
+    blk[3] = (x8 + x6) >> 8;
+    blk[4] = (x8 - x6) >> 8;
+    blk[5] = (x0 - x4) >> 8;
+    blk[6] = (x3 - x2) >> 8;
+    blk[7] = (x7 - x1) >> 8;
+}
+
+static void idct_col(int32_t *blk) /* :1130-1175 */
+{
+    int32_t x0, x1, x2, x3, x4, x5, x6, x7, x8;
+    x1 = blk[8 * 4] * 256; x2 = blk[8 * 6]; x3 = blk[8 * 2]; x4 = blk[8 * 1];
+    x5 = blk[8 * 7]; x6 = blk[8 * 5]; x7 = blk[8 * 3];
+    if (!(x1 | x2 | x3 | x4 | x5 | x6 | x7)) {                 /* :1134-1140 */
+        blk[8 * 0] = blk[8 * 1] = blk[8 * 2] = blk[8 * 3] = blk[8 * 4] = blk[8 * 5] =
+            blk[8 * 6] = blk[8 * 7] = iclp((blk[8 * 0] + 32) >> 6);
+        return;
+    }
+    x0 = blk[8 * 0] * 256 + 8192;
+    x8 = W7 * (x4 + x5) + 4;
+    x4 = (x8 + (W1 - W7) * x4) >> 3;
+    x5 = (x8 - (W1 + W7) * x5) >> 3;
+    x8 = W3 * (x6 + x7) + 4;
+    x6 = (x8 - (W3 - W5) * x6) >> 3;
+    x7 = (x8 - (W3 + W5) * x7) >> 3;
+    x8 = x0 + x1;
+    x0 -= x1;
+    x1 = W6 * (x3 + x2) + 4;
+    x2 = (x1 - (W2 + W6) * x2) >> 3;
+    x3 = (x1 + (W2 - W6) * x3) >> 3;
+    x1 = x4 + x6;
+    x4 -= x6;
+    x6 = x5 + x7;
+    x5 -= x7;
+    x7 = x8 + x3;
+    x8 -= x3;
+    x3 = x0 + x2;
+    x0 -= x2;
+    x2 = (181 * (x4 + x5) + 128) >> 8;
+    x4 = (181 * (x4 - x5) + 128) >> 8;
+    blk[8 * 0] = iclp((x7 + x1) >> 14);
+    blk[8 * 1] = iclp((x3 + x2) >> 14);
+    blk[8 * 2] = iclp((x0 + x4) >> 14);
+    blk[8 * 3] = iclp((x8 + x6) >> 14);
+    blk[8 * 4] = iclp((x8 - x6) >> 14);
+    blk[8 * 5] = iclp((x0 - x4) >> 14);
+    blk[8 * 6] = iclp((x3 - x2) >> 14);
+    blk[8 * 7] = iclp((x7 - x1) >> 14);
+}
+
+void amvo_idct_block(int32_t blk[64]) /* Fast_IDCT :1050-1059 */
+{
+    for (int i = 0; i < 8; i++) idct_row(blk + 8 * i);
+    for (int i = 0; i < 8; i++) idct_col(blk + i);
+}
+
+/* IQtIZzBlock AmvJpeg.c:1010-1048 */
+void amvo_dequant_idct_block(const int16_t coef[64], int comp, uint32_t flags, int32_t out[64])
+{
+    const uint8_t *qt = comp == 0 ? k_qt_luma : k_qt_chroma;   /* :1430,1434,1438 */
+    int32_t offset = comp == 0 ? 128 : 0;                      /* :1023,1027,1031 */
+    for (int i = 0; i < 64; i++) {
+        int tag = zz_index(i, flags);                          /* :1039 */
+        out[i] = (int32_t)coef[tag] * (int32_t)qt[tag];        /* :1040 */
+    }
+    amvo_idct_block(out);
+    for (int i = 0; i < 64; i++) out[i] += offset;             /* :1047 */
+}
+
+/* StoreBuffer's pixel maths AmvJpeg.c:805-831 */
+void amvo_yuv_to_bgr(int32_t y, int32_t u, int32_t v, uint8_t bgr[3])
+{
+    int32_t rr = (y * 256 + 18 * u + 367 * v) >> 8;
+    int32_t gg = (y * 256 - 159 * u - 220 * v) >> 8;
+    int32_t bb = (y * 256 + 411 * u - 29 * v) >> 8;
+    bgr[0] = (uint8_t)(bb < 0 ? 0 : (bb > 255 ? 255 : bb));
+    bgr[1] = (uint8_t)(gg < 0 ? 0 : (gg > 255 ? 255 : gg));
+    bgr[2] = (uint8_t)(rr < 0 ? 0 : (rr > 255 ? 255 : rr));
+}
+
+/* ------------------------------------------------------------------------------------
+ * frame decode: AmvJpegDecode AmvJpeg.c:1515-1539, Decode :1244-1287,
+ * DecodeMCUBlock :1177-1242, GetYUV :754-787, StoreBuffer :789-840
+ * ---------------------------------------------------------------------------------- */
+int amvo_decode_frame(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
+                      uint32_t flags, uint8_t *out, int16_t *coef_out,
+                      uint32_t *nmcu_ok, uint32_t *status)
+{
+    hufbounds hb[4];
+    bitrd b;
+    const uint32_t stride = amvo_stride(w);
+    const uint32_t mcw = amvo_mcus_per_row(w), mch = amvo_mcu_rows(h);
+    int16_t pred[3] = { 0, 0, 0 };                              /* :1511 */
+    uint32_t st = 0, mcu = 0;
+    static const int comp_of[6] = { 0, 0, 0, 0, 1, 2 };
+
+    for (int t = 0; t < 4; t++) build_bounds(&hb[t], k_bits[t]);
+    memset(out, 0, (size_t)stride * h);                         /* AMVDec.c:283 */
+    if (coef_out) memset(coef_out, 0, (size_t)mcw * mch * 6 * 64 * sizeof(int16_t));
+    memset(&b, 0, sizeof b);
+    b.buf = chunk; b.len = len; b.pos = 2;                      /* :1527 skip FF D8 */
+
+    for (uint32_t my = 0; my < mch && !st; my++) {
+        for (uint32_t mx = 0; mx < mcw; mx++) {
+            int16_t mcub[6][64];
+            int32_t px[6][64];
+            for (int k = 0; k < 6 && !st; k++) {                /* :1195-1224 */
+                int c = comp_of[k];
+                int r = huf_block(&b, hb, c ? 1 : 0, c ? 3 : 2, mcub[k]);
+                if (r) { st |= (uint32_t)r; break; }
+                mcub[k][0] = (int16_t)(mcub[k][0] + pred[c]);   /* :1200-1201 etc. */
+                pred[c] = mcub[k][0];
+            }
+            if (st) break;
+            if (coef_out) memcpy(coef_out + (size_t)mcu * 384, mcub, sizeof mcub);
+            for (int k = 0; k < 6; k++)                         /* :1266-1268 */
+                amvo_dequant_idct_block(mcub[k], comp_of[k], flags, px[k]);
+            /* GetYUV + StoreBuffer: Y tile is 16x16 from blocks 0..3, chroma is nearest (i/2, j/2) */
+            for (uint32_t i = 0; i < 16; i++) {
+                uint32_t row = my * 16 + i;
+                if (row >= h) break;                            /* :798,837-838 */
+                uint8_t *dst = out + (size_t)(h - 1 - row) * stride + (size_t)mx * 16 * 3; /* :800 */
+                for (uint32_t j = 0; j < 16; j++) {
+                    if (mx * 16 + j >= w) break;                /* :803,833-834 */
+                    int32_t y = px[(i >> 3) * 2 + (j >> 3)][(i & 7) * 8 + (j & 7)];
+                    int32_t u = px[4][(i >> 1) * 8 + (j >> 1)];
+                    int32_t v = px[5][(i >> 1) * 8 + (j >> 1)];
+                    amvo_yuv_to_bgr(y, u, v, dst + 3 * j);
+                }
+            }
+            mcu++;
+        }
+    }
+    if (b.consumed > b.valid) st |= AMVO_ST_TRUNCATED;
+    if (nmcu_ok) *nmcu_ok = mcu;
+    if (status) *status = st;
+    return st ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * IMA ADPCM
+ * ---------------------------------------------------------------------------------- */
+static const int8_t k_index_table[16] = { -1, -1, -1, -1, 2, 4, 6, 8, -1, -1, -1, -1, 2, 4, 6, 8 }; /* AdpcmIma.c:20-23 */
+static const int16_t k_step_table[89] = {                                                          /* AdpcmIma.c:29-39 */
+    7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 21, 23, 25, 28, 31, 34, 37, 41, 45,
+    50, 55, 60, 66, 73, 80, 88, 97, 107, 118, 130, 143, 157, 173, 190, 209, 230, 253, 279, 307,
+    337, 371, 408, 449, 494, 544, 598, 658, 724, 796, 876, 963, 1060, 1166, 1282, 1411, 1552, 1707, 1878, 2066,
+    2272, 2499, 2749, 3024, 3327, 3660, 4026, 4428, 4871, 5358, 5894, 6484, 7132, 7845, 8630, 9493, 10442, 11487, 12635, 13899,
+    15289, 16818, 18500, 20350, 22385, 24623, 27086, 29794, 32767 };
+
+static inline int clip_s16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+static inline int clip_idx(int v) { return v < 0 ? 0 : (v > 88 ? 88 : v); }
+
+/* AdpcmImaExpandNibble AdpcmIma.c:170-204 (shift = 3) */
+static int16_t expand_nibble(int *predictor, int *step_index, unsigned nibble)
+{
+    int step = k_step_table[*step_index];
+    int idx = clip_idx(*step_index + k_index_table[nibble]);
+    int diff = ((2 * (int)(nibble & 7) + 1) * step) >> 3;
+    int p = *predictor;
+    p = (nibble & 8) ? p - diff : p + diff;
+    p = clip_s16(p);
+    *predictor = p;
+    *step_index = idx;
+    return (int16_t)p;
+}
+
+int amvo_adpcm_decode_chunk(const uint8_t *chunk, uint32_t len, int16_t *pcm, uint32_t *nsamples_hdr)
+{
+    if (len <= 8) return -1;                                        /* AdpcmIma.c:216 (!buf_size) */
+    int predictor = (int16_t)(chunk[0] | (chunk[1] << 8));          /* AMVDec.c:312 */
+    int step_index = clip_idx(chunk[2]);                            /* AMVDec.c:313; >88 is out of bounds in the reference */
+    if (nsamples_hdr)
+        *nsamples_hdr = (uint32_t)chunk[4] | ((uint32_t)chunk[5] << 8) | ((uint32_t)chunk[6] << 16) | ((uint32_t)chunk[7] << 24);
+    uint32_t n = len - 8;
+    for (uint32_t i = 0; i < n; i++) {                              /* AdpcmIma.c:225-237, mono: high nibble first */
+        unsigned byte = chunk[8 + i];
+        *pcm++ = expand_nibble(&predictor, &step_index, byte >> 4);
+        *pcm++ = expand_nibble(&predictor, &step_index, byte & 15);
+    }
+    return (int)(2 * n);
+}
+
+/* adpcm_ima_compress_sample lavc/adpcm.c:219-227 (yamaha_difflookup :124-127) */
+static unsigned compress_sample(int *prev, int *step_index, int sample)
+{
+    int delta = sample - *prev;
+    int step = k_step_table[*step_index];
+    int q = abs(delta) * 4 / step;
+    unsigned nibble = (unsigned)(q > 7 ? 7 : q) + (delta < 0 ? 8u : 0u);
+    int look = 2 * (int)(nibble & 7) + 1;
+    if (nibble & 8) look = -look;
+    *prev = clip_s16(*prev + (step * look) / 8);
+    *step_index = clip_idx(*step_index + k_index_table[nibble]);
+    return nibble;
+}
+
+int amvo_adpcm_encode_chunk(const int16_t *samples, uint32_t nsamp, int *step_index, uint8_t *out)
+{
+    uint8_t *dst = out;
+    int prev = samples[0];                                          /* adpcm.c:464 */
+    uint32_t n = nsamp >> 1;
+    *dst++ = (uint8_t)(prev & 0xff); *dst++ = (uint8_t)((prev >> 8) & 0xff);           /* :465 */
+    *dst++ = (uint8_t)(*step_index & 0xff); *dst++ = (uint8_t)((*step_index >> 8) & 0xff); /* :466 */
+    *dst++ = (uint8_t)((n << 1) & 0xff); *dst++ = (uint8_t)(((n << 1) >> 8) & 0xff);   /* :479 */
+    *dst++ = (uint8_t)(((n << 1) >> 16) & 0xff); *dst++ = (uint8_t)(((n << 1) >> 24) & 0xff);
+    for (uint32_t i = 0; i < n; i++) {                              /* :489-493 */
+        unsigned hi = compress_sample(&prev, step_index, samples[2 * i]);
+        unsigned lo = compress_sample(&prev, step_index, samples[2 * i + 1]);
+        *dst++ = (uint8_t)((hi << 4) | (lo & 15));
+    }
+    return (int)(dst - out);
+}
+
+/* AdpcmImaCompressSample AdpcmIma.c:43-89: the quotient goes through an unsigned char before it
+ * is limited to 7 (:62-65) and the predicted delta uses the already updated step (:73) */
+static unsigned wav_compress(int *prev, int *step_index, int sample)
+{
+    int delta = sample - *prev, sign = 0, idx = *step_index, pd;
+    unsigned char nibble;
+    if (delta < 0) { sign = 1; delta = -delta; }
+    nibble = (unsigned char)((delta << 2) / k_step_table[clip_idx(idx)]);
+    if (nibble > 7) nibble = 7;
+    idx = clip_idx(idx + k_index_table[nibble]);
+    pd = (k_step_table[idx] * nibble) / 4 + k_step_table[idx] / 8;
+    *prev = clip_s16(sign ? *prev - pd : *prev + pd);
+    *step_index = idx;
+    return (unsigned)nibble + ((unsigned)sign << 3);
+}
+
+int amvo_adpcm_wav_encode_frame(const int16_t *samples, int frame_size, int32_t state[2], uint8_t *frame)
+{
+    uint8_t *dst = frame;                                           /* AdpcmIma.c:92-160, mono */
+    int n = frame_size / 8, prev = samples[0], idx = state[1];
+    *dst++ = (uint8_t)(prev & 0xff); *dst++ = (uint8_t)((prev >> 8) & 0xff);
+    *dst++ = (uint8_t)idx; *dst++ = 0;
+    samples++;
+    for (; n > 0; n--, samples += 8)
+        for (int k = 0; k < 4; k++) {
+            unsigned lo = wav_compress(&prev, &idx, samples[2 * k]) & 0x0f;
+            unsigned hi = wav_compress(&prev, &idx, samples[2 * k + 1]);
+            *dst++ = (uint8_t)(lo | ((hi << 4) & 0xf0));
+        }
+    state[0] = prev; state[1] = idx;
+    return (int)(dst - frame);
+}
+
+uint32_t amvo_adpcm_amv_pairs(uint32_t frame_size, uint32_t sample_rate, uint32_t *extra, uint64_t *samples_written)
+{
+    uint32_t n = frame_size >> 1;                                   /* adpcm.c:469-472 */
+    *extra += frame_size & 1;
+    n += *extra >> 1;
+    *extra &= 1;
+    uint32_t i = (uint32_t)((*samples_written + 2ull * n) % sample_rate);   /* :474 */
+    if (i && i + frame_size > sample_rate) n += (sample_rate - i) >> 1;    /* :476-477 */
+    *samples_written += 2ull * n;                                   /* :495 */
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------
+ * encoder front end: rgb24_to_yuvj420p lavc/imgconvert_template.h:654-, colorspace.h:30-97
+ * ---------------------------------------------------------------------------------- */
+#define SCALEBITS 10
+#define ONE_HALF (1 << (SCALEBITS - 1))
+#define FIXC(x) ((int)((x) * (1 << SCALEBITS) + 0.5))
+
+void amvo_rgb24_to_yuvj420p(const uint8_t *rgb, uint32_t src_stride, uint32_t w, uint32_t h,
+                            int bgr, uint8_t *yp, uint8_t *cb, uint8_t *cr)
+{
+    const int ro = bgr ? 2 : 0, bo = bgr ? 0 : 2;
+    for (uint32_t y = 0; y < h; y += 2) {
+        for (uint32_t x = 0; x < w; x += 2) {
+            int r1 = 0, g1 = 0, b1 = 0;
+            for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 2; dx++) {
+                    const uint8_t *p = rgb + (size_t)(y + dy) * src_stride + (size_t)(x + dx) * 3;
+                    int r = p[ro], g = p[1], b = p[bo];
+                    r1 += r; g1 += g; b1 += b;
+                    yp[(size_t)(y + dy) * w + x + dx] = (uint8_t)((FIXC(0.29900) * r + FIXC(0.58700) * g +
+                                                                   FIXC(0.11400) * b + ONE_HALF) >> SCALEBITS);
+                }
+            cb[(size_t)(y / 2) * (w / 2) + x / 2] = (uint8_t)(((-FIXC(0.16874) * r1 - FIXC(0.33126) * g1 + FIXC(0.50000) * b1 +
+                                                                (ONE_HALF << 2) - 1) >> (SCALEBITS + 2)) + 128);
+            cr[(size_t)(y / 2) * (w / 2) + x / 2] = (uint8_t)(((FIXC(0.50000) * r1 - FIXC(0.41869) * g1 - FIXC(0.08131) * b1 +
+                                                                (ONE_HALF << 2) - 1) >> (SCALEBITS + 2)) + 128);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * forward DCT: ff_jpeg_fdct_islow lavc/jfdctint.c:184-343 (CONST_BITS 13, PASS1_BITS 4)
+ * ---------------------------------------------------------------------------------- */
+#define CONST_BITS 13
+#define PASS1_BITS 4
+#define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+#define FIX_0_298631336 2446
+#define FIX_0_390180644 3196
+#define FIX_0_541196100 4433
+#define FIX_0_765366865 6270
+#define FIX_0_899976223 7373
+#define FIX_1_175875602 9633
+#define FIX_1_501321110 12299
+#define FIX_1_847759065 15137
+#define FIX_1_961570560 16069
+#define FIX_2_053119869 16819
+#define FIX_2_562915447 20995
+#define FIX_3_072711026 25172
+
+static void fdct_1d(int16_t *d, int stride, int pass)
+{
+    int32_t t0 = d[0] + d[7 * stride], t7 = d[0] - d[7 * stride];
+    int32_t t1 = d[stride] + d[6 * stride], t6 = d[stride] - d[6 * stride];
+    int32_t t2 = d[2 * stride] + d[5 * stride], t5 = d[2 * stride] - d[5 * stride];
+    int32_t t3 = d[3 * stride] + d[4 * stride], t4 = d[3 * stride] - d[4 * stride];
+    int32_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    int32_t z1, z2, z3, z4, z5;
+    const int sh = pass == 0 ? CONST_BITS - PASS1_BITS : CONST_BITS + PASS1_BITS;
+
+    if (pass == 0) {                                         /* jfdctint.c:214-215 */
+        d[0] = (int16_t)((t10 + t11) << PASS1_BITS);
+        d[4 * stride] = (int16_t)((t10 - t11) << PASS1_BITS);
+    } else {                                                 /* :296-297 */
+        d[0] = (int16_t)DESCALE(t10 + t11, PASS1_BITS);
+        d[4 * stride] = (int16_t)DESCALE(t10 - t11, PASS1_BITS);
+    }
+    z1 = (t12 + t13) * FIX_0_541196100;
+    d[2 * stride] = (int16_t)DESCALE(z1 + t13 * FIX_0_765366865, sh);
+    d[6 * stride] = (int16_t)DESCALE(z1 + t12 * -FIX_1_847759065, sh);
+
+    z1 = t4 + t7; z2 = t5 + t6; z3 = t4 + t6; z4 = t5 + t7;
+    z5 = (z3 + z4) * FIX_1_175875602;
+    t4 *= FIX_0_298631336; t5 *= FIX_2_053119869; t6 *= FIX_3_072711026; t7 *= FIX_1_501321110;
+    z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+    z3 += z5; z4 += z5;
+    d[7 * stride] = (int16_t)DESCALE(t4 + z1 + z3, sh);
+    d[5 * stride] = (int16_t)DESCALE(t5 + z2 + z4, sh);
+    d[3 * stride] = (int16_t)DESCALE(t6 + z2 + z3, sh);
+    d[1 * stride] = (int16_t)DESCALE(t7 + z1 + z4, sh);
+}
+
+void amvo_fdct_islow(int16_t blk[64])
+{
+    for (int r = 0; r < 8; r++) fdct_1d(blk + 8 * r, 1, 0);   /* row_fdct :184-258 */
+    for (int c = 0; c < 8; c++) fdct_1d(blk + c, 8, 1);       /* pass 2 :273-341 */
+}
+
+/* ------------------------------------------------------------------------------------
+ * quantiser: dct_quantize_c lavc/mpegvideo_enc.c:3647-3724 for AMV (bias 0, :492-496),
+ * qmat = (1<<QMAT_SHIFT)/(qscale*Q) with qscale 8 (:80-91, :2866-2877), QMAT_SHIFT 22
+ * (mpegvideo.h:51).  Differences, required to be decodable by amvlib:
+ * amvlib's fixed tables instead of mpeg1_default_intra*qscale>>3, and a true level
+ * shift, so DC may be negative and is rounded symmetrically.
+ * ---------------------------------------------------------------------------------- */
+#define QMAT_SHIFT 22
+
+void amvo_quantize_block(const int16_t dct[64], int comp, uint32_t qbias, int16_t zz[64])
+{
+    const uint8_t *qt = comp == 0 ? k_qt_luma : k_qt_chroma;
+    const int32_t bias = (int32_t)(qbias << (QMAT_SHIFT - 8));      /* :3679, QUANT_BIAS_SHIFT 8 */
+    for (int nat = 0; nat < 64; nat++) {
+        int i = k_zigzag_std[nat];
+        int32_t c = dct[nat];
+        if (i == 0) {
+            int32_t q = (int32_t)qt[0] << 3;                       /* :3670-3676: (b + q/2) / q */
+            int32_t a = (abs(c) + (q >> 1)) / q;
+            zz[0] = (int16_t)(c < 0 ? -a : a);
+        } else {
+            int32_t qmat = (int32_t)((1u << QMAT_SHIFT) / (8u * qt[i]));
+            int32_t level = c * qmat;                              /* :3702 */
+            int32_t a = ((level < 0 ? -level : level) + bias) >> QMAT_SHIFT; /* :3706-3712 */
+            zz[i] = (int16_t)(level < 0 ? -a : a);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * entropy coder: encode_block / ff_mjpeg_encode_dc lavc/mjpegenc.c:357-435,
+ * code assignment ff_mjpeg_build_huffman_codes lavc/mjpeg.c:129-147
+ * ---------------------------------------------------------------------------------- */
+typedef struct { uint8_t size[256]; uint16_t code[256]; } hufenc;
+
+static void build_enc(hufenc *he, const uint8_t bits[16], const uint8_t *vals)
+{
+    int code = 0, k = 0;
+    memset(he, 0, sizeof *he);
+    for (int i = 1; i <= 16; i++) {
+        for (int j = 0; j < bits[i - 1]; j++) {
+            int sym = vals[k++];
+            he->size[sym] = (uint8_t)i;
+            he->code[sym] = (uint16_t)code;
+            code++;
+        }
+        code <<= 1;
+    }
+}
+
+typedef struct { uint8_t *buf; size_t pos; uint32_t acc; int nacc; } bitwr;
+
+static void put_bits(bitwr *bw, int n, uint32_t v)
+{
+    for (int i = n - 1; i >= 0; i--) {
+        bw->acc = (bw->acc << 1) | ((v >> i) & 1u);
+        if (++bw->nacc == 8) { bw->buf[bw->pos++] = (uint8_t)bw->acc; bw->acc = 0; bw->nacc = 0; }
+    }
+}
+
+static int nbits_of(int v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
+
+static void encode_coef(bitwr *bw, const hufenc *he, int run, int val)
+{
+    int mant = val, nb;
+    if (val < 0) { val = -val; mant--; }                      /* mjpegenc.c:366-369,414-417 */
+    nb = nbits_of(val);
+    put_bits(bw, he->size[(run << 4) | nb], he->code[(run << 4) | nb]);
+    put_bits(bw, nb, (uint32_t)mant & ((1u << nb) - 1u));
+}
+
+static void encode_block(bitwr *bw, const hufenc *dc, const hufenc *ac, const int16_t zz[64], int16_t *pred)
+{
+    int diff = zz[0] - *pred, run = 0, last = 0;             /* :390-401 */
+    *pred = zz[0];
+    if (diff == 0) put_bits(bw, dc->size[0], dc->code[0]);    /* :362-363 */
+    else encode_coef(bw, dc, 0, diff);
+    for (int i = 63; i > 0; i--) if (zz[i]) { last = i; break; }
+    for (int i = 1; i <= last; i++) {                         /* :405-427 */
+        int v = zz[i];
+        if (v == 0) { run++; continue; }
+        while (run >= 16) { put_bits(bw, ac->size[0xf0], ac->code[0xf0]); run -= 16; }
+        encode_coef(bw, ac, run, v);
+        run = 0;
+    }
+    if (last < 63) put_bits(bw, ac->size[0], ac->code[0]);    /* :430-431 */
+}
+
+uint32_t amvo_encode_bound(uint32_t w, uint32_t h)
+{
+    /* worst case per coefficient: 16-bit code + 11 magnitude bits, doubled by FF escaping */
+    return 4 + amvo_mcus_per_row(w) * amvo_mcu_rows(h) * 6 * 64 * 4 * 2;
+}
+
+int amvo_encode_frame(const uint8_t *src, uint32_t src_stride, uint32_t w, uint32_t h, int bgr,
+                      uint32_t qbias, uint8_t *out, int16_t *coef_out)
+{
+    if (w == 0 || h == 0 || (w & 1) || (h & 1)) return -1;
+    const uint32_t mcw = amvo_mcus_per_row(w), mch = amvo_mcu_rows(h);
+    const uint32_t cw = w / 2, ch = h / 2;
+    uint8_t *yp = (uint8_t *)malloc((size_t)w * h + 2 * (size_t)cw * ch);
+    uint8_t *cb = yp + (size_t)w * h, *cr = cb + (size_t)cw * ch;
+    uint8_t *raw = (uint8_t *)malloc(amvo_encode_bound(w, h));
+    hufenc he[4];
+    bitwr bw = { raw, 0, 0, 0 };
+    int16_t pred[3] = { 0, 0, 0 };
+    uint32_t mcu = 0;
+
+    for (int t = 0; t < 4; t++) build_enc(&he[t], k_bits[t], k_vals[t]);
+    amvo_rgb24_to_yuvj420p(src, src_stride, w, h, bgr, yp, cb, cr);
+
+    for (uint32_t my = 0; my < mch; my++)
+        for (uint32_t mx = 0; mx < mcw; mx++, mcu++)
+            for (int k = 0; k < 6; k++) {                     /* block order Y0..Y3,Cb,Cr mjpegenc.c:437-450 */
+                int16_t blk[64], zz[64];
+                const uint8_t *plane = k < 4 ? yp : (k == 4 ? cb : cr);
+                const uint32_t pw = k < 4 ? w : cw, ph = k < 4 ? h : ch;
+                const uint32_t bx = k < 4 ? mx * 16 + (k & 1) * 8 : mx * 8;
+                const uint32_t by = k < 4 ? my * 16 + (k >> 1) * 8 : my * 8;
+                for (uint32_t i = 0; i < 8; i++)
+                    for (uint32_t j = 0; j < 8; j++) {
+                        /* the bitstream holds the picture bottom-up (amv_encode_picture mjpegenc.c:454-472);
+                         * rows/columns beyond the picture replicate the nearest edge sample */
+                        uint32_t r = by + i, c = bx + j;
+                        uint32_t sy = r < ph ? ph - 1 - r : 0;
+                        uint32_t sx = c < pw ? c : pw - 1;
+                        blk[i * 8 + j] = (int16_t)((int)plane[(size_t)sy * pw + sx] - 128);
+                    }
+                amvo_fdct_islow(blk);
+                amvo_quantize_block(blk, k < 4 ? 0 : 1, qbias, zz);
+                if (coef_out) memcpy(coef_out + ((size_t)mcu * 6 + k) * 64, zz, sizeof zz);
+                encode_block(&bw, k < 4 ? &he[0] : &he[1], k < 4 ? &he[2] : &he[3], zz, &pred[k < 4 ? 0 : k - 3]);
+            }
+    if (bw.nacc) put_bits(&bw, 8 - bw.nacc, (1u << (8 - bw.nacc)) - 1u);  /* ff_mjpeg_encode_stuffing :338-343 */
+
+    size_t o = 0;
+    out[o++] = 0xff; out[o++] = 0xd8;                          /* SOI only, :201-204 */
+    for (size_t i = 0; i < bw.pos; i++) {                      /* escape_FF :282-336 */
+        out[o++] = raw[i];
+        if (raw[i] == 0xff) out[o++] = 0;
+    }
+    out[o++] = 0xff; out[o++] = 0xd9;                          /* EOI :354 */
+    free(raw);
+    free(yp);
+    return (int)o;
+}
+
+/* ------------------------------------------------------------------------------------
+ * synthetic sources: integer only, so every platform and the
+ * HIP generator produce the same bytes.
+ * ---------------------------------------------------------------------------------- */
+static const int16_t k_sin_q[65] = { /* round(16384*sin(2*pi*i/256)), i = 0..64 */
+    0, 402, 804, 1205, 1606, 2006, 2404, 2801, 3196, 3590, 3981, 4370, 4756, 5139, 5520, 5897,
+    6270, 6639, 7005, 7366, 7723, 8076, 8423, 8765, 9102, 9434, 9760, 10080, 10394, 10702, 11003, 11297,
+    11585, 11866, 12140, 12406, 12665, 12916, 13160, 13395, 13623, 13842, 14053, 14256, 14449, 14635, 14811, 14978,
+    15137, 15286, 15426, 15557, 15679, 15791, 15893, 15986, 16069, 16143, 16207, 16261, 16305, 16340, 16364, 16379,
+    16384 };
+
+static inline int32_t isin(uint32_t a) /* a in 1/256 turns */
+{
+    a &= 255;
+    uint32_t q = a & 63;
+    switch (a >> 6) {
+    case 0: return k_sin_q[q];
+    case 1: return k_sin_q[64 - q];
+    case 2: return -k_sin_q[q];
+    default: return -k_sin_q[64 - q];
+    }
+}
+static inline int32_t icos(uint32_t a) { return isin(a + 64); }
+
+static inline uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+static inline int tri(uint32_t v) { v &= 511; return (int)(v < 256 ? v : 511 - v); }
+static inline uint8_t clip_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+void amvo_synth_frame(uint32_t seed, uint32_t t, uint32_t w, uint32_t h, uint8_t *rgb)
+{
+    const int cx = (int)w / 2, cy = (int)h / 2;
+    const int rad = (int)h * 3 / 8, cell = (int)w / 10 > 0 ? (int)w / 10 : 1;
+    const int32_t s = isin(t * 2), c = icos(t * 2);
+    /* moving gradients are scaled so that their slope in 1/256ths per pixel is the same at every size */
+    const uint32_t gx = 512u * 256u / w, gy = 512u * 256u / h;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            int r = 48 + (tri(((x * gx) >> 8) + t * 3) * 5 >> 3);
+            int g = 48 + (tri(((y * gy) >> 8) + t * 2) * 5 >> 3);
+            int b = 48 + (tri((((x * gx) + (y * gy)) >> 9) + t * 5) * 5 >> 3);
+            int dx = (int)x - cx, dy = (int)y - cy;
+            if (dx * dx + dy * dy < rad * rad) {            /* rotating checker inside a disc */
+                int u = (dx * c + dy * s) >> 14, v = (dy * c - dx * s) >> 14;
+                int chk = (((u + 4096) / cell) ^ ((v + 4096) / cell)) & 1;
+                r = chk ? 230 - (r >> 3) : 25 + (r >> 3);
+                g = chk ? 230 - (g >> 3) : 25 + (g >> 3);
+                b = chk ? 230 - (b >> 3) : 25 + (b >> 3);
+            }
+            uint32_t n = mix32(seed ^ mix32(t * 0x9e3779b9u + y * 65537u + x));
+            uint8_t *p = rgb + ((size_t)y * w + x) * 3;    /* 5 % uniform noise: +-12 of 255 */
+            p[0] = clip_u8(r + (int)(n % 25u) - 12);
+            p[1] = clip_u8(g + (int)((n >> 8) % 25u) - 12);
+            p[2] = clip_u8(b + (int)((n >> 16) % 25u) - 12);
+        }
+}
+
+void amvo_synth_audio(uint32_t seed, uint64_t first, uint32_t n, int16_t *pcm)
+{
+    for (uint32_t k = 0; k < n; k++) {                     /* three sines + noise, 22050 Hz mono */
+        uint64_t i = first + k;
+        int32_t v = (6000 * isin((uint32_t)((i * 1301u) >> 8)) +     /* ~437 Hz  */
+                     3000 * isin((uint32_t)((i * 3907u) >> 8)) +     /* ~1314 Hz */
+                     1500 * isin((uint32_t)((i * 9973u) >> 8))) >> 14; /* ~3355 Hz */
+        uint32_t r = mix32(seed ^ mix32((uint32_t)i * 0x85ebca6bu + (uint32_t)(i >> 32)));
+        v += (int)(r % 401u) - 200;
+        pcm[k] = (int16_t)clip_s16(v);
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * helpers
+ * ---------------------------------------------------------------------------------- */
+uint64_t amvo_fnv1a64(uint64_t hsh, const uint8_t *p, size_t n)
+{
+    for (size_t i = 0; i < n; i++) { hsh ^= p[i]; hsh *= 0x100000001b3ull; }
+    return hsh;
+}
+
+double amvo_psnr(const uint8_t *a, const uint8_t *b, size_t n)
+{
+    double se = 0;
+    for (size_t i = 0; i < n; i++) { double d = (double)a[i] - (double)b[i]; se += d * d; }
+    if (se == 0) return 99.0;
+    return 10.0 * log10(255.0 * 255.0 * (double)n / se);
+}
+
+int amvo_decode_batch(const uint8_t *blob, const uint64_t *offs, const uint32_t *lens, uint32_t n,
+                      uint32_t w, uint32_t h, uint32_t flags, uint8_t *out, int32_t *status, int threads)
+{
+    const size_t fsz = (size_t)amvo_stride(w) * h;
+    int bad = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 16) reduction(+ : bad)
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t st = 0;
+        amvo_decode_frame(blob + offs[i], lens[i], w, h, flags, out + fsz * i, NULL, NULL, &st);
+        if (status) status[i] = (int32_t)st;
+        bad += st != 0;
+    }
+    return bad;
+}
+
+int amvo_synth_encode_batch(uint32_t seed, uint32_t first_frame, uint32_t n, uint32_t w, uint32_t h,
+                            uint32_t qbias, uint8_t *blob, uint64_t cap, uint64_t *offs, uint32_t *lens, int threads)
+{
+    const uint32_t bound = amvo_encode_bound(w, h);
+    int fail = 0;
+    if (threads < 1) threads = 1;
+    uint8_t **tmp = (uint8_t **)calloc(n, sizeof *tmp);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 16)
+    for (uint32_t i = 0; i < n; i++) {
+        uint8_t *rgb = (uint8_t *)malloc((size_t)w * h * 3);
+        uint8_t *buf = (uint8_t *)malloc(bound);
+        amvo_synth_frame(seed, first_frame + i, w, h, rgb);
+        int l = amvo_encode_frame(rgb, w * 3, w, h, 0, qbias, buf, NULL);
+        lens[i] = l < 0 ? 0 : (uint32_t)l;
+        tmp[i] = (uint8_t *)realloc(buf, lens[i] ? lens[i] : 1);
+        free(rgb);
+    }
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        offs[i] = o;
+        if (o + lens[i] > cap) fail = 1;
+        else memcpy(blob + o, tmp[i], lens[i]);
+        o += lens[i];
+        free(tmp[i]);
+    }
+    free(tmp);
+    return fail ? -1 : 0;
+}

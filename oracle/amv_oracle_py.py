@@ -1,0 +1,212 @@
+"""ctypes binding of the CPU oracle (oracle/libamvoracle.so) and, when present, of the reference
+build oracle/_ref/libamvref.so.  TEST INFRASTRUCTURE ONLY: imported by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg, never by the product package.
+"""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libamvoracle.so")
+REF = os.path.join(HERE, "_ref", "libamvref.so")
+
+ST_FORMAT, ST_OVERRUN, ST_TRUNCATED = 1, 2, 4
+FLAG_ZIGZAG_FIXED = 1
+FNV_BASIS = 0xCBF29CE484222325
+# the seed the survey's harness actually used for its chained FNV-1a-64 (SURVEY.md section 8c:
+# "seed 1469598103934665603"; it is the standard basis with its last decimal digit missing)
+SURVEY_FNV_SEED = 1469598103934665603
+
+_vp, _u32, _u64, _int = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+
+
+def build(force=False):
+    """make -C oracle (the restatement always; _ref only where /root/reference exists)"""
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(
+            os.path.getmtime(os.path.join(HERE, f)) for f in ("amv_oracle.c", "amv_oracle.h", "Makefile")):
+        subprocess.run(["make", "-C", HERE, "-s", "libamvoracle.so"], check=True)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(REF)):
+        subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(LIB)
+        sig = {
+            "amvo_stride": (_u32, [_u32]),
+            "amvo_mcus_per_row": (_u32, [_u32]),
+            "amvo_mcu_rows": (_u32, [_u32]),
+            "amvo_decode_frame": (_int, [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+            "amvo_dequant_idct_block": (None, [_vp, _int, _u32, _vp]),
+            "amvo_idct_block": (None, [_vp]),
+            "amvo_yuv_to_bgr": (None, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]),
+            "amvo_adpcm_decode_chunk": (_int, [_vp, _u32, _vp, _vp]),
+            "amvo_adpcm_encode_chunk": (_int, [_vp, _u32, ctypes.POINTER(_int), _vp]),
+            "amvo_adpcm_wav_encode_frame": (_int, [_vp, _int, _vp, _vp]),
+            "amvo_adpcm_amv_pairs": (_u32, [_u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),
+            "amvo_rgb24_to_yuvj420p": (None, [_vp, _u32, _u32, _u32, _int, _vp, _vp, _vp]),
+            "amvo_fdct_islow": (None, [_vp]),
+            "amvo_quantize_block": (None, [_vp, _int, _u32, _vp]),
+            "amvo_encode_frame": (_int, [_vp, _u32, _u32, _u32, _int, _u32, _vp, _vp]),
+            "amvo_encode_bound": (_u32, [_u32, _u32]),
+            "amvo_synth_frame": (None, [_u32, _u32, _u32, _u32, _vp]),
+            "amvo_synth_audio": (None, [_u32, _u64, _u32, _vp]),
+            "amvo_fnv1a64": (_u64, [_u64, _vp, ctypes.c_size_t]),
+            "amvo_psnr": (ctypes.c_double, [_vp, _vp, ctypes.c_size_t]),
+            "amvo_decode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _int]),
+            "amvo_synth_encode_batch": (_int, [_u32, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _int]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+_ref = None
+
+
+def ref():
+    """oracle/_ref/libamvref.so (reference AdpcmIma.c + jfdctint.c) or None when not built"""
+    global _ref
+    if _ref is None and os.path.exists(REF):
+        R = ctypes.CDLL(REF)
+        R.AdpcmImaDecodeFrame.restype = _int
+        R.AdpcmImaDecodeFrame.argtypes = [_vp, _vp, _vp, _vp, _int]
+        R.AdpcmImaEncodeFrame.restype = _int
+        R.AdpcmImaEncodeFrame.argtypes = [_vp, _int, _int, _vp, _int, _vp]
+        R.ff_jpeg_fdct_islow.restype = None
+        R.ff_jpeg_fdct_islow.argtypes = [_vp]
+        _ref = R
+    return _ref
+
+
+class RefADPCMChannelStatus(ctypes.Structure):  # reference AdpcmIma.h:11-18
+    _fields_ = [("predictor", ctypes.c_int), ("step_index", ctypes.c_short), ("step", ctypes.c_int),
+                ("prev_sample", ctypes.c_int)]
+
+
+class RefADPCMContext(ctypes.Structure):  # reference AdpcmIma.h:20-25
+    _fields_ = [("channel", ctypes.c_int), ("status", RefADPCMChannelStatus * 2), ("sample_buffer", ctypes.c_short * 32)]
+
+
+# ---- convenience wrappers (numpy in / numpy out) -------------------------------------------
+
+def stride(w):
+    return lib().amvo_stride(w)
+
+
+def nmcu(w, h):
+    return lib().amvo_mcus_per_row(w) * lib().amvo_mcu_rows(h)
+
+
+def decode_frame(chunk, w, h, flags=0, want_coef=False):
+    """-> (bgr[h, stride] uint8, status, nmcu_ok[, coef[nmcu*6, 64] int16])"""
+    L = lib()
+    chunk = bytes(chunk)
+    out = np.zeros((h, L.amvo_stride(w)), np.uint8)
+    coef = np.zeros((nmcu(w, h) * 6, 64), np.int16) if want_coef else None
+    ok, st = _u32(), _u32()
+    L.amvo_decode_frame(chunk, len(chunk), w, h, flags, out.ctypes.data, coef.ctypes.data if want_coef else None,
+                        ctypes.byref(ok), ctypes.byref(st))
+    return (out, st.value, ok.value, coef) if want_coef else (out, st.value, ok.value)
+
+
+def encode_frame(pix, w, h, bgr=False, qbias=0, want_coef=False):
+    """pix: [h, w, 3] uint8 contiguous -> chunk bytes[, coef]"""
+    L = lib()
+    pix = np.ascontiguousarray(pix, np.uint8)
+    buf = np.zeros(L.amvo_encode_bound(w, h), np.uint8)
+    coef = np.zeros((nmcu(w, h) * 6, 64), np.int16) if want_coef else None
+    n = L.amvo_encode_frame(pix.ctypes.data, w * 3, w, h, 1 if bgr else 0, qbias, buf.ctypes.data,
+                            coef.ctypes.data if want_coef else None)
+    if n < 0:
+        raise ValueError("amvo_encode_frame rejected %dx%d" % (w, h))
+    return (bytes(buf[:n]), coef) if want_coef else bytes(buf[:n])
+
+
+def synth_frame(seed, t, w, h):
+    rgb = np.zeros((h, w, 3), np.uint8)
+    lib().amvo_synth_frame(seed, t, w, h, rgb.ctypes.data)
+    return rgb
+
+
+def synth_audio(seed, first, n):
+    pcm = np.zeros(n, np.int16)
+    lib().amvo_synth_audio(seed, first, n, pcm.ctypes.data)
+    return pcm
+
+
+def adpcm_decode_chunk(chunk):
+    chunk = bytes(chunk)
+    pcm = np.zeros(max(2 * (len(chunk) - 8), 0) + 8, np.int16)
+    hdr = _u32()
+    n = lib().amvo_adpcm_decode_chunk(chunk, len(chunk), pcm.ctypes.data, ctypes.byref(hdr))
+    return (pcm[:n].copy() if n > 0 else pcm[:0]), hdr.value
+
+
+def adpcm_encode_chunk(samples, step_index):
+    samples = np.ascontiguousarray(samples, np.int16)
+    out = np.zeros(8 + len(samples) // 2, np.uint8)
+    si = _int(step_index)
+    n = lib().amvo_adpcm_encode_chunk(samples.ctypes.data, len(samples), ctypes.byref(si), out.ctypes.data)
+    return bytes(out[:n]), si.value
+
+
+def fnv1a64(h, arr):
+    arr = np.ascontiguousarray(arr)
+    return lib().amvo_fnv1a64(h, arr.ctypes.data, arr.nbytes)
+
+
+def psnr(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().amvo_psnr(a.ctypes.data, b.ctypes.data, a.size)
+
+
+def synth_stream(seed, first, n, w, h, qbias=0, threads=1):
+    """seeded synthetic clip encoded by the oracle's encoder -> (blob uint8, offs uint64, lens uint32)"""
+    L = lib()
+    cap = int(L.amvo_encode_bound(w, h)) * n
+    cap = min(cap, max(1 << 20, n * w * h))  # real chunks are ~0.2 B/pixel
+    blob = np.zeros(cap, np.uint8)
+    offs = np.zeros(n, np.uint64)
+    lens = np.zeros(n, np.uint32)
+    rc = L.amvo_synth_encode_batch(seed, first, n, w, h, qbias, blob.ctypes.data, cap, offs.ctypes.data,
+                                   lens.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError("synthetic stream did not fit its buffer")
+    total = int(offs[-1] + lens[-1]) if n else 0
+    return blob[:total + 16].copy(), offs, lens
+
+
+def decode_batch(blob, offs, lens, w, h, flags=0, threads=1):
+    L = lib()
+    n = len(lens)
+    out = np.zeros((n, h, L.amvo_stride(w)), np.uint8)
+    st = np.zeros(n, np.int32)
+    L.amvo_decode_batch(blob.ctypes.data, offs.ctypes.data, lens.ctypes.data, n, w, h, flags, out.ctypes.data,
+                        st.ctypes.data, threads)
+    return out, st
+
+
+def parse_amv(data):
+    """walk an AMV file: -> (info dict, [video chunks], [audio chunks])  (reference AMVDec.c:150-238)"""
+    info = {"us_per_frame": struct.unpack_from("<I", data, 32)[0], "width": struct.unpack_from("<I", data, 64)[0],
+            "height": struct.unpack_from("<I", data, 68)[0], "fps": struct.unpack_from("<I", data, 72)[0],
+            "sample_rate": struct.unpack_from("<I", data, 288)[0]}
+    p = data.find(b"movi") + 4
+    vids, auds = [], []
+    while p + 8 <= len(data) and data[p:p + 4] != b"AMV_":
+        n = struct.unpack_from("<I", data, p + 4)[0]
+        (vids if data[p:p + 4] == b"00dc" else auds).append(data[p + 8:p + 8 + n])
+        p += 8 + n
+    return info, vids, auds

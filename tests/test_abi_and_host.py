@@ -1,0 +1,114 @@
+"""No-GPU checks of the product library: it builds for gfx950, loads, exports every symbol that
+include/amvhip.h declares with the struct layouts of the reference headers, its pure host logic
+(the container walker) works, and every codec entry point FAILS LOUDLY without a device instead
+of falling back to a CPU path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "amvhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^[A-Za-z_][\w \*]*?[\s\*](\w+)\s*\([^;{]*\)\s*;", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_and_binding_agree(pkg):
+    declared = _declared_functions()
+    assert len(declared) >= 35
+    assert sorted(pkg.SYMBOLS) == declared
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    for name in _declared_functions():
+        assert name in exported, name
+        assert getattr(lib, name) is not None
+
+
+def test_code_object_is_gfx950(pkg):
+    data = open(pkg.LIB_PATH, "rb").read()
+    assert b"gfx950" in data and b"amv_huffman_kernel" in data and b"amv_reconstruct_kernel" in data
+
+
+def test_struct_layouts_match_reference_headers(pkg):
+    # C-AMVDecoder/amvlib/AMVDec.h:29-91 and AdpcmIma.h:11-25 on LP64
+    assert ctypes.sizeof(pkg.AMVInfo) == 48
+    assert ctypes.sizeof(pkg.FRAMEBUFF) == 32 and ctypes.sizeof(pkg.VIDEOBUFF) == 16 and ctypes.sizeof(pkg.AUDIOBUFF) == 16
+    assert ctypes.sizeof(pkg.ADPCMChannelStatus) == 16 and ctypes.sizeof(pkg.ADPCMContext) == 100
+    assert pkg.AMVDecoder.amvinfo.offset == 32 and pkg.AMVDecoder.framebuf.offset == 88
+
+
+def test_geometry_helpers(pkg, orc):
+    lib = pkg.load_library()
+    for w, h in ((160, 120), (320, 240), (128, 96), (130, 98), (176, 144), (1, 1)):
+        assert lib.amvhip_stride(w) == orc.stride(w) == (w * 24 + 31) // 32 * 4
+        assert lib.amvhip_frame_bytes(w, h) == orc.stride(w) * h
+        assert lib.amvhip_encode_bound(w, h) == orc.lib().amvo_encode_bound(w, h)
+
+
+def test_container_reader_is_host_only(pkg, amv1):
+    """AmvOpen / AmvReadNextFrame / AmvRewindFrameStart / AmvClose (AMVDec.c:15-257) need no GPU"""
+    lib = pkg.load_library()
+    assert not lib.AmvOpen(None)
+    assert not lib.AmvOpen(b"/nonexistent.amv")
+    assert not lib.AmvOpen(__file__.encode())            # not an AMV: header four-ccs do not match
+    amv = lib.AmvOpen(amv1["path"].encode())
+    assert amv
+    d = amv.contents
+    i = d.amvinfo
+    assert (i.dwWidth, i.dwHeight, i.dwSpeed, i.dwMicroSecPerFrame) == (128, 96, 12, 83333)
+    assert (i.dwTimeSec, i.dwTimeMin, i.dwTimeHour) == (21, 0, 0) and d.totalframe == 252
+    assert (i.nChannels, i.nSamplesPerSec, i.wBitsPerSample) == (1, 16000, 16)
+    assert d.dataseekpos == 316 and d.opened == 1
+    for k in range(252):
+        assert lib.AmvReadNextFrame(amv) == 0
+        fb = d.framebuf
+        assert fb.framenum == k + 1 and d.currentframe == k + 1   # AMVDec.c:233-234 counts from 1
+        assert ctypes.string_at(fb.videobuff, fb.videobufflen) == amv1["video"][k]
+        assert ctypes.string_at(fb.audiobuff, fb.audiobufflen) == amv1["audio"][k]
+    assert lib.AmvReadNextFrame(amv) == 0 and d.framebuf.framenum == -1 and not d.framebuf.videobuff   # AMV_END_
+    assert lib.AmvRewindFrameStart(amv) == 0 and d.fileseekpos == 316
+    assert lib.AmvReadNextFrame(amv) == 0 and d.framebuf.videobufflen == len(amv1["video"][0])
+    lib.AmvClose(amv)
+    lib.AmvClose(None)
+    assert lib.AmvReadNextFrame(None) == -1 and lib.AmvVideoDecode(None) == -1 and lib.AmvAudioDecode(None) == -1
+
+
+def test_no_cpu_fallback(pkg, amv1):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the loud-failure path is for boxes without one")
+    lib = pkg.load_library()
+    h = ctypes.c_void_p()
+    assert lib.amvhip_create(ctypes.byref(h), 0) == pkg.ERR_DEVICE and not h
+    with pytest.raises(pkg.AmvHipError):
+        pkg.Context(0)
+    out = np.zeros(128 * 96 * 3, np.uint8)
+    chunk = amv1["video"][0]
+    assert lib.decode_amv_frame(chunk, len(chunk), 128, 96, out.ctypes.data) == -1 and not out.any()
+    amv = lib.AmvOpen(amv1["path"].encode())
+    assert lib.AmvReadNextFrame(amv) == 0
+    assert lib.AmvVideoDecode(amv) == -1 and lib.AmvAudioDecode(amv) == -1
+    lib.AmvClose(amv)
+
+
+def test_product_never_touches_the_oracle():
+    """the oracle is test infrastructure: nothing under the package or include/ may name it"""
+    for base in ("amv-codec-tools_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "amvo_" not in text and "libamvoracle" not in text and "amv_oracle" not in text, os.path.join(dirpath, f)
+    out = subprocess.run(["ldd", os.path.join(ROOT, "amv-codec-tools_amd", "libamvhip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out

@@ -1,0 +1,192 @@
+"""Pins of the CPU oracle (no GPU).  The oracle is trusted by the GPU parity tests only because
+these pass:
+  * video decode  -- the reference's own fixture AMV1.amv must hash to the values amvlib itself
+                     produced, quirk on and off;
+  * audio decode, amvlib's WAV encoder, forward DCT -- bit-equal to oracle/_ref/libamvref.so,
+                     which is compiled from the reference's AdpcmIma.c and jfdctint.c;
+  * committed golden vectors of the synthetic clips (tests/golden/synth_golden.json).
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SEED
+
+AMVLIB_HASH = 0xADC922C6366237B5        # amvlib over all 252 frames of AMV1.amv
+AMVLIB_HASH_FIXED_ZZ = 0xA3F28348069FCE7C  # same with Zig_Zag[3][4]=31
+AMV1_PCM_BYTES = 672504                 # decoded audio of AMV1.amv
+
+
+def test_amv1_header(amv1):
+    # reference AmvLibTest prints these: 128x96, 12 fps, 16 kHz mono, 252+252 chunks
+    assert (amv1["info"]["width"], amv1["info"]["height"], amv1["info"]["fps"]) == (128, 96, 12)
+    assert amv1["info"]["sample_rate"] == 16000 and amv1["info"]["us_per_frame"] == 83333
+    assert len(amv1["video"]) == 252 and len(amv1["audio"]) == 252
+    sizes = [len(v) for v in amv1["video"]]
+    assert (min(sizes), max(sizes)) == (1410, 2924) and sum(sizes) == 606456
+
+
+@pytest.mark.parametrize("flags,want", [(0, AMVLIB_HASH), (1, AMVLIB_HASH_FIXED_ZZ)])
+def test_video_decode_pinned_by_amvlib_hash(orc, amv1, flags, want):
+    h = orc.SURVEY_FNV_SEED
+    for chunk in amv1["video"]:
+        out, st, ok = orc.decode_frame(chunk, 128, 96, flags)
+        assert st == 0 and ok == 48
+        h = orc.fnv1a64(h, out)
+    assert h == want
+
+
+def test_audio_decode_matches_reference_build(orc, amv1):
+    R = orc.ref()
+    total = 0
+    for a in amv1["audio"]:
+        mine, hdr = orc.adpcm_decode_chunk(a)
+        total += mine.size * 2
+        assert mine.size == 2 * (len(a) - 8) and 0 <= mine.size - hdr <= 1   # header counts samples, payload is whole bytes
+        if R is None:
+            continue
+        c = orc.RefADPCMContext()
+        c.channel = 1
+        c.status[0].predictor = int(np.frombuffer(a[:2], "<i2")[0])
+        c.status[0].step_index = a[2]
+        pcm = np.zeros(4096, np.int16)
+        dl = ctypes.c_int(0)
+        buf = (ctypes.c_ubyte * (len(a) + 8)).from_buffer_copy(a + b"\0" * 8)
+        R.AdpcmImaDecodeFrame(ctypes.byref(c), pcm.ctypes.data, ctypes.byref(dl), ctypes.byref(buf, 8), len(a) - 8)
+        assert (pcm[:mine.size] == mine).all()
+    assert total == AMV1_PCM_BYTES
+
+
+def test_fdct_matches_reference_build(orc):
+    R = orc.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    rng = np.random.default_rng(7)
+    for it in range(5000):
+        lo, hi = ((-128, 128), (-255, 256), (0, 256))[it % 3]
+        a = rng.integers(lo, hi, 64).astype(np.int16)
+        b = a.copy()
+        R.ff_jpeg_fdct_islow(a.ctypes.data)
+        orc.lib().amvo_fdct_islow(b.ctypes.data)
+        assert (a == b).all()
+
+
+def test_wav_layout_encoder_matches_reference_build(orc):
+    R = orc.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    rng = np.random.default_rng(11)
+    for it in range(40):
+        fs = 8 * int(rng.integers(1, 200))
+        x = (rng.integers(-32768, 32768, fs + 1) if it % 2 else orc.synth_audio(SEED, it * 999, fs + 1) * 4).astype(np.int16)
+        idx = int(rng.integers(0, 89))
+        c = orc.RefADPCMContext()
+        c.status[0].step_index = idx
+        want = np.zeros(4 + fs // 2 + 16, np.uint8)
+        n = R.AdpcmImaEncodeFrame(ctypes.byref(c), 1, fs, want.ctypes.data, want.size, x.ctypes.data)
+        got = np.zeros_like(want)
+        st = np.array([0, idx], np.int32)
+        m = orc.lib().amvo_adpcm_wav_encode_frame(x.ctypes.data, fs, st.ctypes.data, got.ctypes.data)
+        assert n == m == 4 + fs // 2 and (want[:n] == got[:n]).all()
+        assert (st[0], st[1]) == (c.status[0].prev_sample, c.status[0].step_index)
+
+
+def test_idct_dc_shortcuts_are_identities(orc):
+    """amvlib's all-AC-zero shortcuts (AmvJpeg.c:1087-1092,1134-1140) equal the full butterflies, so
+    the HIP kernel may drop them: the oracle keeps the shortcuts, here they are compared with a
+    numpy restatement that never takes them (exhaustive over every dequantised DC value)."""
+    W1, W2, W3, W5, W6, W7 = 2841, 2676, 2408, 1609, 1108, 565
+
+    def full(b, col):
+        b = b.astype(np.int64)
+        up, bias, rnd, dn, out = (256, 8192, 4, 3, 14) if col else (2048, 128, 0, 0, 8)
+        x0 = b[0] * up + bias; x1 = b[4] * up; x2, x3, x4, x5, x6, x7 = b[6], b[2], b[1], b[7], b[5], b[3]
+        x8 = W7 * (x4 + x5) + rnd; x4 = (x8 + (W1 - W7) * x4) >> dn; x5 = (x8 - (W1 + W7) * x5) >> dn
+        x8 = W3 * (x6 + x7) + rnd; x6 = (x8 - (W3 - W5) * x6) >> dn; x7 = (x8 - (W3 + W5) * x7) >> dn
+        x8 = x0 + x1; x0 = x0 - x1; x1 = W6 * (x3 + x2) + rnd
+        x2 = (x1 - (W2 + W6) * x2) >> dn; x3 = (x1 + (W2 - W6) * x3) >> dn
+        x1 = x4 + x6; x4 = x4 - x6; x6 = x5 + x7; x5 = x5 - x7
+        x7 = x8 + x3; x8 = x8 - x3; x3 = x0 + x2; x0 = x0 - x2
+        x2 = (181 * (x4 + x5) + 128) >> 8; x4 = (181 * (x4 - x5) + 128) >> 8
+        return np.stack([x7 + x1, x3 + x2, x0 + x4, x8 + x6, x8 - x6, x0 - x4, x3 - x2, x7 - x1]) >> out
+
+    dcs = np.arange(-2048 * 9, 2048 * 9 + 1, dtype=np.int64)      # every DC * step the tables allow
+    z = np.zeros((8, dcs.size), np.int64); z[0] = dcs
+    rows = full(z, False)                                            # row pass of a DC-only block
+    assert (rows == dcs * 8).all()
+    cols = np.clip(full(np.concatenate([rows[:1], np.zeros((7, dcs.size), np.int64)]), True), -256, 255)
+    blk = np.zeros(64, np.int32)
+    for i in range(0, dcs.size, 97):                                 # and the oracle agrees
+        blk[:] = 0; blk[0] = dcs[i]
+        orc.lib().amvo_idct_block(blk.ctypes.data)
+        assert (blk == cols[0, i]).all()
+
+
+def test_error_semantics(orc):
+    w, h = 160, 120
+    chunk = orc.encode_frame(orc.synth_frame(SEED, 3, w, h), w, h)
+    good, st, ok = orc.decode_frame(chunk, w, h)
+    assert st == 0 and ok == 80
+    # truncated: zero-extended, flagged, still every MCU attempted
+    out, st, ok = orc.decode_frame(chunk[:len(chunk) // 2], w, h)
+    assert st & orc.ST_TRUNCATED
+    # a run of ones is not a Huffman code: FORMAT, decoding stops, later MCUs stay zero (AMVDec.c:283)
+    bad = bytearray(chunk); bad[300:340] = b"\xff\x00" * 20
+    out, st, ok = orc.decode_frame(bytes(bad), w, h)
+    assert st & orc.ST_FORMAT and ok < 80
+    row0_mcu = ok // 10
+    assert not out[: h - 16 * (row0_mcu + 1)].any()                  # rows of undecoded MCU rows (stored bottom-up)
+    assert (out[h - 16 * row0_mcu:] == good[h - 16 * row0_mcu:]).all()
+
+
+def test_encode_round_trip_quality(orc):
+    """encode -> bit-exact decoder -> PSNR against the RGB source.  amvlib's colour matrix
+    (AmvJpeg.c:808-810) is not the inverse of FFmpeg's RGB->YCbCr (colorspace.h), which bounds the
+    figure; the thresholds are the measured values of the oracle minus 0.3 dB."""
+    for (w, h), lo_amv, lo_mjpeg in (((160, 120), 25.4, 25.9), ((320, 240), 26.6, 27.3)):
+        ps = {0: [], 128: []}
+        for t in (0, 50, 190):
+            src = orc.synth_frame(SEED, t, w, h)
+            for qb in ps:
+                out, st, ok = orc.decode_frame(orc.encode_frame(src, w, h, qbias=qb), w, h, orc.FLAG_ZIGZAG_FIXED)
+                assert st == 0
+                ps[qb].append(orc.psnr(src, out[:, : w * 3].reshape(h, w, 3)[:, :, ::-1]))
+        assert np.mean(ps[0]) > lo_amv and np.mean(ps[128]) > lo_mjpeg, (w, h, np.mean(ps[0]), np.mean(ps[128]))
+
+
+def test_adpcm_round_trip_and_framing(orc):
+    pcm = orc.synth_audio(SEED, 0, 1378 * 4)
+    idx, dec = 0, []
+    for k in range(4):
+        chunk, idx = orc.adpcm_encode_chunk(pcm[1378 * k: 1378 * (k + 1)], idx)
+        assert len(chunk) == 8 + 689 and int.from_bytes(chunk[4:8], "little") == 1378
+        dec.append(orc.adpcm_decode_chunk(chunk)[0])
+    dec = np.concatenate(dec).astype(np.float64)
+    err = dec - pcm
+    snr = 10 * np.log10((pcm.astype(np.float64) ** 2).sum() / (err ** 2).sum())
+    assert snr > 20, snr
+    # adpcm.c:469-477 framing: 22050 Hz / 16 fps -> frame_size 1378, pairs 689 with the 1 Hz resync
+    extra, written = ctypes.c_uint32(0), ctypes.c_uint64(0)
+    pairs = [orc.lib().amvo_adpcm_amv_pairs(1378, 22050, ctypes.byref(extra), ctypes.byref(written)) for _ in range(32)]
+    assert pairs[0] == 689 and sum(pairs) * 2 == written.value and written.value % 22050 == 0
+
+
+def test_synthetic_golden_vectors(orc):
+    """committed fixtures: tests/golden/synth_golden.json (made by tests/golden/make_golden.py)"""
+    gold = json.load(open(os.path.join(GOLDEN, "synth_golden.json")))
+    for case in gold["video"]:
+        w, h, t = case["w"], case["h"], case["frame"]
+        src = orc.synth_frame(gold["seed"], t, w, h)
+        assert "%016x" % orc.fnv1a64(orc.FNV_BASIS, src) == case["rgb_fnv"]
+        chunk = orc.encode_frame(src, w, h, qbias=case["qbias"])
+        assert len(chunk) == case["chunk_len"] and "%016x" % orc.fnv1a64(orc.FNV_BASIS, np.frombuffer(chunk, np.uint8)) == case["chunk_fnv"]
+        out, st, ok = orc.decode_frame(chunk, w, h, case["flags"])
+        assert st == 0 and "%016x" % orc.fnv1a64(orc.FNV_BASIS, out) == case["bgr_fnv"]
+    a = gold["audio"]
+    pcm = orc.synth_audio(gold["seed"], a["first"], a["n"])
+    chunk, idx = orc.adpcm_encode_chunk(pcm, a["step_in"])
+    assert "%016x" % orc.fnv1a64(orc.FNV_BASIS, pcm) == a["pcm_fnv"] and idx == a["step_out"]
+    assert "%016x" % orc.fnv1a64(orc.FNV_BASIS, np.frombuffer(chunk, np.uint8)) == a["chunk_fnv"]
