@@ -1,0 +1,83 @@
+"""The N>1 path on CPU: world_size 2 (and 3, uneven split) over gloo.  The frame-range scatter /
+gather that bench.py and a multi-GPU host use is exercised end to end; the per-rank decode is the
+oracle here because this container has no GPU (on the GPU box the same ranges go to the HIP path)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, SEED
+
+W, H, N = 160, 120, 21
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = entry.load_oracle()
+        sh = entry._load("amv_codec_tools_amd.sharding", os.path.join(entry.PKG_DIR, "sharding.py"))
+        dev = torch.device("cpu")
+        blob = offs = lens = None
+        if rank == 0:
+            blob, offs, lens = orc.synth_stream(SEED, 0, N, W, H)
+        my_blob, my_offs, my_lens, first = sh.scatter_stream(blob, offs, lens, dev)
+        lo, hi = sh.frame_range(N, rank, world)
+        assert first == lo and my_lens.numel() == hi - lo
+        b = my_blob.numpy()
+        frames = np.zeros((hi - lo, H, orc.stride(W)), np.uint8)
+        for i in range(hi - lo):
+            o, ln = int(my_offs[i]), int(my_lens[i])
+            out, st, _ = orc.decode_frame(b[o:o + ln].tobytes(), W, H)
+            assert st == 0
+            frames[i] = out
+        full = sh.gather_frames(torch.from_numpy(frames), N)
+        slow = sh.max_over_ranks(float(rank + 1), dev)
+        total = sh.sum_over_ranks(float(hi - lo), dev)
+        assert slow == float(world) and total == float(N)
+        if rank == 0:
+            want, _ = orc.decode_batch(blob, offs, lens, W, H)
+            q.put(bool((full.numpy() == want).all()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_scatter_decode_gather(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_frame_ranges_cover_everything():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    sh = entry._load("amv_codec_tools_amd.sharding", os.path.join(entry.PKG_DIR, "sharding.py"))
+    for n in (0, 1, 7, 8, 10000, 10001):
+        for g in (1, 2, 3, 4, 8):
+            rs = [sh.frame_range(n, r, g) for r in range(g)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(g - 1))
+            assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
