@@ -10,13 +10,14 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamvhip.so")
+LIB_PATH = os.environ.get("AMVHIP_LIB") or os.path.join(_HERE, "libamvhip.so")   # override: kernel experiments
 
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_SPACE = 0, -1, -2, -3, -4
 ST_FORMAT, ST_OVERRUN, ST_TRUNCATED = 1, 2, 4
 FLAG_ZIGZAG_FIXED = 1
 QBIAS_AMV, QBIAS_MJPEG = 0, 128
-K_HUFFMAN, K_RECON, K_FDCT, K_PACK, K_ADPCM_DEC, K_ADPCM_ENC, K_SYNTH = range(7)
+K_HUFFMAN, K_RECON, K_FDCT, K_PACK, K_ADPCM_DEC, K_ADPCM_ENC, K_SYNTH, K_HUFFMAN_SERIAL, K_UNSTUFF = range(9)
+ENTROPY_AUTO, ENTROPY_SERIAL = 0, 1
 
 _vp, _u8p = ctypes.c_void_p, ctypes.c_void_p
 _u32, _u64, _i32, _int = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int
@@ -95,6 +96,8 @@ SYMBOLS = {
     "amvhip_adpcm_wav_encode_frame": (_int, [_vp, _vp, _int, _vp, _vp, _int]),
     "amvhip_synth_frames_dev": (_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_synth_audio_dev": (_int, [_vp, _u32, _u64, _u64, _vp, _vp]),
+    "amvhip_set_entropy_mode": (_int, [_vp, _int]),
+    "amvhip_entropy_stats": (_int, [_vp, _int, _vp]),
     "amvhip_prof_enable": (None, [_vp, _int]),
     "amvhip_prof_reset": (None, [_vp]),
     "amvhip_prof_read": (_int, [_vp, _int, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double)]),
@@ -229,6 +232,17 @@ class Context:
         return self._check(self.lib.amvhip_adpcm_encode_batch(self.h, _ptr(pcm), pcm_samples, _ptr(pcm_offs), _ptr(nsamp),
                                                               n, _ptr(step_in), _ptr(blob), blob_bytes, _ptr(offs)),
                            "adpcm_encode_batch")
+
+    def set_entropy_mode(self, mode):
+        return self._check(self.lib.amvhip_set_entropy_mode(self.h, mode), "set_entropy_mode")
+
+    def entropy_stats(self, enable=True):
+        out = (ctypes.c_uint64 * 10)()
+        self._check(self.lib.amvhip_entropy_stats(self.h, 1 if enable else 0, out), "entropy_stats")
+        waves = max(out[9], 1)
+        return {"frames": out[0], "rounds": out[1], "max_rounds": out[2], "waves": out[9],
+                "clocks_per_wave": {"zero": out[4] / waves, "first_walk": out[5] / waves, "sync_rounds": out[6] / waves,
+                                    "write": out[7] / waves, "dc": out[8] / waves}}
 
     # timing
     def prof_enable(self, on=True):

@@ -113,14 +113,21 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
     const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offs,
     const uint32_t* __restrict__ lens, uint32_t n, uint32_t blocks_per_frame,
     const HuffDecodeImage* __restrict__ img, int16_t* __restrict__ coef,
-    int32_t* __restrict__ status, uint32_t* __restrict__ nmcu_ok) {
+    int32_t* __restrict__ status, uint32_t* __restrict__ nmcu_ok,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
     __shared__ __attribute__((aligned(16))) uint16_t s_l1[4 << kLut1Bits];
     __shared__ __attribute__((aligned(16))) uint16_t s_l2[kLut2Pages << kLut2Bits];
     __shared__ __attribute__((aligned(16))) uint4 s_slots[kWave * 8];
+    __shared__ uint32_t s_frame[kWave];
 
+    // with a list (frames the wave-per-frame kernel handed back) this kernel decodes
+    // list[0 .. *list_count); without one, frames 0 .. n
     const uint32_t lane = threadIdx.x;
     const uint32_t f0 = blockIdx.x * kWave;
-    const uint32_t frame = f0 + lane;
+    if (list) n = *list_count;
+    if (f0 >= n) return;
+    const uint32_t frame = f0 + lane < n ? (list ? list[f0 + lane] : f0 + lane) : 0xffffffffu;
+    s_frame[lane] = frame;
 
     {   // table image -> LDS, slots cleared
         const uint4* src = reinterpret_cast<const uint4*>(img);
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
     }
 
     BitReader r;
-    bool live = frame < n;
+    bool live = frame != 0xffffffffu;
     uint32_t st = 0, mcu_done = 0;
     {
         uint64_t off = live ? offs[frame] : 0;
@@ -190,8 +197,9 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
             const uint32_t idx = s * 8u + (part ^ (s & 7u));
             const uint4 v = s_slots[idx];
             s_slots[idx] = make_uint4(0, 0, 0, 0);
-            if (f0 + s < n) {
-                uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)(f0 + s) * blocks_per_frame + b) * 64u);
+            const uint32_t fr = s_frame[s];
+            if (fr != 0xffffffffu) {
+                uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)fr * blocks_per_frame + b) * 64u);
                 dst[part] = v;
             }
         }
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
             if (live) ++mcu_done;
         }
     }
-    if (frame < n) {
+    if (frame != 0xffffffffu) {
         if (r.pad > r.nbits) st |= kStTruncated;  // consumed bits that the chunk does not hold
         status[frame] = (int32_t)st;
         nmcu_ok[frame] = mcu_done;
@@ -211,11 +219,11 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
 void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
                     const uint32_t* lens, uint32_t n, const FrameGeom& g,
                     const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
-                    uint32_t* nmcu_ok, hipStream_t s) {
+                    uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, hipStream_t s) {
     if (n == 0) return;
-    const uint32_t grid = (n + kWave - 1) / kWave;
+    const uint32_t grid = (n + kWave - 1) / kWave;   // with a list: upper bound, surplus groups exit at once
     hipLaunchKernelGGL(amv_huffman_kernel, dim3(grid), dim3(kWave), 0, s, blob, blob_bytes, offs,
-                       lens, n, g.blocks, d_img, coef, status, nmcu_ok);
+                       lens, n, g.blocks, d_img, coef, status, nmcu_ok, list, list_count);
 }
 
 // ============================================================================================

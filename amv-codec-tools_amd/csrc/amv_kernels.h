@@ -16,7 +16,17 @@ enum : uint32_t { kFlagZigzagFixed = 1u };
 void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
                     const uint32_t* lens, uint32_t n, const FrameGeom& g,
                     const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
-                    uint32_t* nmcu_ok, hipStream_t s);
+                    uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, hipStream_t s);
+// entropy stage with parallelism inside a frame (amv_decode_sync.hip): unstuff into a workspace
+// (cap_words words per frame, ws_bytes[i] = unstuffed length or ~0 when the frame is handed to
+// launch_huffman through retry_list / *retry_count), then L lanes per frame synchronise and decode.
+void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
+                    uint32_t cap_words, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
+                    hipStream_t s);
+void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const FrameGeom& g, uint32_t cap_words,
+                         int lanes_per_frame, const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
+                         uint32_t* nmcu_ok, unsigned long long* stats, hipStream_t s);
+bool huffman_sync_fits(const FrameGeom& g, int lanes_per_frame);
 // dequantise + IDCT + YCbCr->BGR + flipped store: one wave per MCU-row segment
 void launch_reconstruct(const int16_t* coef, const uint32_t* nmcu_ok, uint32_t n,
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s);

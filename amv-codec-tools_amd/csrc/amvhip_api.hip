@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -38,7 +39,10 @@ struct amvhip_ctx {
     HuffDecodeImage* d_dec = nullptr;
     HuffEncodeImage* d_enc = nullptr;
     // workspace
-    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start;
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes;
+    int sync_lanes = 16;
+    bool want_stats = false;
+    int entropy_mode = AMVHIP_ENTROPY_AUTO;
     // host-pointer staging
     DevBuf h_in, h_offs, h_lens, h_out, h_status, h_aux;
     // timing
@@ -119,6 +123,22 @@ void build_images(HuffDecodeImage& dec, HuffEncodeImage& enc) {
         }
     }
     if (pages > kLut2Pages) abort();  // static property of the K.3 tables (11 pages)
+    // skip copies
+    int page_table[kLut2Pages];
+    for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < (1 << kLut1Bits); ++i)
+            if (dec.l1[t][i] & 0x8000u) page_table[dec.l1[t][i] & 0xffu] = t;
+    auto skip = [](uint16_t e, int t) -> uint16_t {
+        const uint32_t len = (e >> 8) & 31u, sym = e & 0xffu;
+        if (len == 0) return 0;
+        const uint32_t adv = t < 2 ? 1u : (sym == 0 ? 64u : (sym >> 4) + 1u);
+        return (uint16_t)((len + (sym & 15u)) | (adv << 8));
+    };
+    for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < (1 << kLut1Bits); ++i)
+            dec.s1[t][i] = (dec.l1[t][i] & 0x8000u) ? dec.l1[t][i] : skip(dec.l1[t][i], t);
+    for (int pg = 0; pg < pages; ++pg)
+        for (int i = 0; i < (1 << kLut2Bits); ++i) dec.s2[pg][i] = skip(dec.l2[pg][i], page_table[pg]);
 }
 
 // ---- timing ---------------------------------------------------------------------------------
@@ -188,6 +208,10 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
     std::call_once(once, [] { build_images(dec, enc); });
     auto die = [&](int code) { amvhip_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
+    if (const char* e = getenv("AMVHIP_SYNC_LANES")) {   // tuning knob: lanes per frame of the entropy kernel
+        const int v = atoi(e);
+        if (v == 8 || v == 16 || v == 32 || v == 64) c->sync_lanes = v;
+    }
     if (hipMalloc((void**)&c->d_dec, sizeof dec) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
     if (hipMalloc((void**)&c->d_enc, sizeof enc) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
     if (hipMemcpy(c->d_dec, &dec, sizeof dec, hipMemcpyHostToDevice) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
@@ -202,7 +226,7 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     drain(c);
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux})
+                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -234,10 +258,42 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
         return fail(c, AMVHIP_ERR_ARG, "huffman_decode: bad argument");
     if (((uintptr_t)d_blob & 3u) || ((uintptr_t)d_coef & 15u)) return fail(c, AMVHIP_ERR_ARG, "huffman_decode: blob must be 4-byte, coef 16-byte aligned");
     if (int r = use_device(c)) return r;
+    if (n == 0) return AMVHIP_OK;
     const FrameGeom g = make_geom(w, h);
+    hipStream_t st = (hipStream_t)stream;
+    // workspace window per frame for the unstuffed scan: ~4x the 0.2 B/pixel AMV streams run at
+    uint32_t cap_bytes = ((w * h * 3u / 4u) + 255u) & ~255u;
+    if (cap_bytes < 4096u) cap_bytes = 4096u;
+    const uint32_t cap_words = cap_bytes / 4u;
+    const bool sync_ok = c->entropy_mode != AMVHIP_ENTROPY_SERIAL && huffman_sync_fits(g, c->sync_lanes);
+    if (!sync_ok) {
+        Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
+        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, nullptr, nullptr, st);
+        return check_launch(c, "huffman");
+    }
+    if (int r = ensure(c, c->retry, ((size_t)n + 4) * 4)) return r;
+    if (int r = ensure(c, c->ws, (size_t)n * cap_bytes)) return r;
+    if (int r = ensure(c, c->ws_bytes, (size_t)n * 4)) return r;
+    uint32_t* retry_count = (uint32_t*)c->retry.p;
+    uint32_t* retry_list = retry_count + 4;
+    HIP_TRY(c, hipMemsetAsync(retry_count, 0, 16, st));
     {
-        Timed t(c, AMVHIP_K_HUFFMAN, (hipStream_t)stream);
-        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, (hipStream_t)stream);
+        Timed t(c, AMVHIP_K_UNSTUFF, st);
+        launch_unstuff(d_blob, blob_bytes, d_offs, d_lens, n, cap_words, (uint32_t*)c->ws.p, (uint32_t*)c->ws_bytes.p,
+                       retry_list, retry_count, st);
+    }
+    if (int r = check_launch(c, "unstuff")) return r;
+    {
+        Timed t(c, AMVHIP_K_HUFFMAN, st);
+        launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, g, cap_words, c->sync_lanes,
+                            c->d_dec, d_coef, d_status, d_nmcu_ok,
+                            c->want_stats ? (unsigned long long*)c->stats.p : nullptr, st);
+    }
+    if (int r = check_launch(c, "huffman_sync")) return r;
+    {   // frames handed back (oversize chunks, long FF runs): usually none, the kernel exits at once
+        Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
+        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, retry_list,
+                       retry_count, st);
     }
     return check_launch(c, "huffman");
 }
@@ -526,6 +582,26 @@ extern "C" int amvhip_synth_audio_dev(amvhip_ctx* c, uint32_t seed, uint64_t fir
 // timing
 // =============================================================================================
 
+extern "C" int amvhip_set_entropy_mode(amvhip_ctx* c, int mode) {
+    if (!c || (mode != AMVHIP_ENTROPY_AUTO && mode != AMVHIP_ENTROPY_SERIAL)) return AMVHIP_ERR_ARG;
+    c->entropy_mode = mode;
+    return AMVHIP_OK;
+}
+
+extern "C" int amvhip_entropy_stats(amvhip_ctx* c, int enable, uint64_t out[10]) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (int r = use_device(c)) return r;
+    if (int r = ensure(c, c->stats, 128)) return r;
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (out) {
+        if (c->want_stats) HIP_TRY(c, hipMemcpy(out, c->stats.p, 80, hipMemcpyDeviceToHost));
+        else memset(out, 0, 80);
+    }
+    HIP_TRY(c, hipMemset(c->stats.p, 0, 128));
+    c->want_stats = enable != 0;
+    return AMVHIP_OK;
+}
+
 extern "C" void amvhip_prof_enable(amvhip_ctx* c, int on) { if (c) c->prof = on != 0; }
 
 extern "C" void amvhip_prof_reset(amvhip_ctx* c) {
@@ -546,7 +622,9 @@ extern "C" int amvhip_prof_read(amvhip_ctx* c, int kernel, uint64_t* launches, d
 
 extern "C" const char* amvhip_kernel_name(int kernel) {
     switch (kernel) {
-        case AMVHIP_K_HUFFMAN: return "amv_huffman_kernel";
+        case AMVHIP_K_HUFFMAN: return "amv_huffman_sync_kernel";
+        case AMVHIP_K_UNSTUFF: return "amv_unstuff_kernel";
+        case AMVHIP_K_HUFFMAN_SERIAL: return "amv_huffman_kernel";
         case AMVHIP_K_RECON: return "amv_reconstruct_kernel";
         case AMVHIP_K_FDCT: return "amv_forward_kernel";
         case AMVHIP_K_PACK: return "amv_pack_kernel";

@@ -132,8 +132,12 @@ def main():
     elapsed = sh.max_over_ranks(elapsed, dev)
     total_frames = sh.sum_over_ranks(float(n * args.steps), dev)
 
+    ctx.entropy_stats(True)          # one extra, untimed step: how many synchronisation rounds the frames needed
+    step()
+    sync = ctx.entropy_stats(False)
+
     kern = {}
-    for k in (pkg.K_HUFFMAN, pkg.K_RECON):
+    for k in (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON):
         launches, ms = ctx.prof_read(k)
         kern[ctx.kernel_name(k)] = {"launches": launches, "avg_ms": ms / max(launches, 1)}
     dom = max(kern, key=lambda name: kern[name]["avg_ms"])
@@ -159,7 +163,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernels": kern,
-                     "path_achieved": algo_bytes / (elapsed / args.steps) / 1e9},
+                     "path_achieved": algo_bytes / (elapsed / args.steps) / 1e9,
+                     "entropy_sync_rounds": {"mean": sync["rounds"] / max(sync["frames"], 1), "max": sync["max_rounds"]}},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

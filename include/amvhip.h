@@ -190,6 +190,20 @@ int amvhip_decode_batch(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_byte
                         uint32_t width, uint32_t height, uint32_t flags,
                         uint8_t *out, int32_t *status);
 
+/* Entropy-stage kernel choice.  AUTO: several lanes per frame (self-synchronising parallel Huffman
+ * decode); frames whose chunk does not fit its workspace window fall to the one-lane-per-frame kernel.
+ * SERIAL: always the one-lane-per-frame kernel.  Results are identical; the switch exists so the
+ * parity tests cover both kernels. */
+#define AMVHIP_ENTROPY_AUTO 0
+#define AMVHIP_ENTROPY_SERIAL 1
+int amvhip_set_entropy_mode(amvhip_ctx *ctx, int mode);
+/* Diagnostics of the synchronising entropy kernel: synchronises the device, returns the counters
+ * gathered since the last call in out[] = {frames, sum of synchronisation rounds, max rounds, 0,
+ * then shader clocks summed over waves for: coefficient zeroing, first walk, synchronisation
+ * rounds, writing pass, DC pass, and the number of waves}, clears them and switches gathering on
+ * or off (off by default; costs a few atomics per frame). */
+int amvhip_entropy_stats(amvhip_ctx *ctx, int enable, uint64_t out[10]);
+
 /* Stage access for parity tests: entropy stage only.  d_coef: n * nmcu*6*64 int16,
  * DC-predicted quantised coefficients in bitstream order (amvlib MCUBuffer,
  * AmvJpeg.c:1200-1223); d_nmcu_ok: MCUs decoded before the first error. */
@@ -277,7 +291,9 @@ int amvhip_synth_audio_dev(amvhip_ctx *ctx, uint32_t seed, uint64_t first_sample
 #define AMVHIP_K_ADPCM_DEC 4
 #define AMVHIP_K_ADPCM_ENC 5
 #define AMVHIP_K_SYNTH 6
-#define AMVHIP_K_COUNT 8
+#define AMVHIP_K_HUFFMAN_SERIAL 7
+#define AMVHIP_K_UNSTUFF 8
+#define AMVHIP_K_COUNT 10
 void amvhip_prof_enable(amvhip_ctx *ctx, int on);
 void amvhip_prof_reset(amvhip_ctx *ctx);
 int amvhip_prof_read(amvhip_ctx *ctx, int kernel, uint64_t *launches, double *total_ms);

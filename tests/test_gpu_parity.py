@@ -127,6 +127,38 @@ def test_decode_error_frames_match_oracle(ctx, orc):
     assert (wst != 0).sum() >= 8 and (wst & orc.ST_FORMAT).any() and (wst & orc.ST_TRUNCATED).any()
 
 
+def test_decode_both_entropy_kernels(ctx, pkg, orc, amv1):
+    """the one-lane-per-frame kernel (SERIAL) and the wave-per-frame kernel (AUTO) give the same
+    bytes and statuses; chunks too large for the LDS window and long FF runs take the hand-back path"""
+    w, h = 160, 120
+    rng = np.random.default_rng(17)
+    chunks = _synth_chunks(orc, 9, w, h, first=900)
+    chunks.append(b"\xff\xd8" + rng.integers(0, 255, 9000).astype(np.uint8).tobytes())      # > LDS window
+    chunks.append(b"\xff\xd8" + bytes(rng.integers(0, 256, 20000).astype(np.uint8)))       # > LDS window, with FFs
+    chunks.append(chunks[0][:1000] + b"\xff" * 9 + chunks[0][1000:])                         # long FF run
+    chunks.append(chunks[1][:-2])                                                           # EOI missing
+    chunks.append(chunks[2] + b"\x00" * 5000)                                               # trailing junk
+    big = orc.encode_frame(rng.integers(0, 256, (h, w, 3)).astype(np.uint8), w, h)          # noise: ~20 kB chunk
+    assert len(big) > 9000
+    chunks.append(big)
+    want, wst = _oracle_decode(orc, chunks, w, h)
+    try:
+        for mode in (pkg.ENTROPY_SERIAL, pkg.ENTROPY_AUTO):
+            ctx.set_entropy_mode(mode)
+            got, st = _gpu_decode(ctx, chunks, w, h, 0, pad_front=3)
+            assert (st == wst).all(), (mode, st, wst)
+            assert (got == want).all(), mode
+            out, st = _gpu_decode(ctx, amv1["video"][:70], 128, 96)
+            hsh = orc.FNV_BASIS
+            ref = orc.FNV_BASIS
+            for k in range(70):
+                hsh = orc.fnv1a64(hsh, out[k])
+                ref = orc.fnv1a64(ref, orc.decode_frame(amv1["video"][k], 128, 96)[0])
+            assert hsh == ref and (st == 0).all()
+    finally:
+        ctx.set_entropy_mode(pkg.ENTROPY_AUTO)
+
+
 def test_huffman_stage_matches_oracle(ctx, orc):
     import torch
     w, h, n = 160, 120, 67

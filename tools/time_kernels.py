@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Kernel-level timing of the decode path for experiments (not the bench): builds the synthetic
+160x120 stream on the device, then times the entropy stage and the reconstruction stage separately
+with HIP events through the library's own profiling hooks.  AMVHIP_LIB selects a library build."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=10000)
+ap.add_argument("--width", type=int, default=160)
+ap.add_argument("--height", type=int, default=120)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--serial", action="store_true")
+a = ap.parse_args()
+pkg = entry.load_package()
+ctx = pkg.Context(0)
+dev = "cuda:0"
+w, h, n = a.width, a.height, a.frames
+s = torch.cuda.current_stream().cuda_stream
+cap = max(1 << 20, n * w * h)
+blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
+offs = torch.zeros(n, dtype=torch.int64, device=dev)
+lens = torch.zeros(n, dtype=torch.int32, device=dev)
+pos = 0
+toffs = torch.zeros(2000, dtype=torch.int64, device=dev)
+rgb = torch.empty((2000, h, w, 3), dtype=torch.uint8, device=dev)
+for lo in range(0, n, 2000):
+    cnt = min(2000, n - lo)
+    ctx.synth_frames_dev(0xA11CE, lo, cnt, w, h, rgb, s)
+    ctx.encode_batch_dev(rgb, w * 3, 0, cnt, w, h, 0, blob[pos:], cap - pos, toffs, lens[lo:], s)
+    torch.cuda.synchronize()
+    offs[lo:lo + cnt] = toffs[:cnt] + pos
+    pos = (int(offs[lo + cnt - 1]) + int(lens[lo + cnt - 1]) + 3) & ~3
+nblk = ((w + 15) // 16) * ((h + 15) // 16) * 6
+coef = torch.empty((n, nblk, 64), dtype=torch.int16, device=dev)
+st = torch.empty(n, dtype=torch.int32, device=dev)
+ok = torch.empty(n, dtype=torch.int32, device=dev)
+out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
+if a.serial:
+    ctx.set_entropy_mode(pkg.ENTROPY_SERIAL)
+for it in range(a.steps + 2):
+    if it == 2:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+    ctx.huffman_decode_dev(blob, cap, offs, lens, n, w, h, coef, st, ok, s)
+    ctx.reconstruct_dev(coef, ok, n, w, h, 0, out, s)
+torch.cuda.synchronize()
+res = {"lib": os.path.basename(pkg.LIB_PATH), "frames": n, "size": [w, h], "bad": int((st != 0).sum())}
+for k in (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON):
+    cnt, ms = ctx.prof_read(k)
+    res[ctx.kernel_name(k)] = round(ms / max(cnt, 1), 4)
+ctx.entropy_stats(True)
+ctx.huffman_decode_dev(blob, cap, offs, lens, n, w, h, coef, st, ok, s)
+es = ctx.entropy_stats(False)
+res["sync"] = {"mean_rounds": round(es["rounds"] / max(es["frames"], 1), 2), "max_rounds": es["max_rounds"],
+               "kclk_per_wave": {k: round(v / 1e3, 1) for k, v in es["clocks_per_wave"].items()}}
+print(json.dumps(res))
