@@ -11,10 +11,9 @@
 //                           every block the wave writes the 64 slots out as 64 whole 128-byte
 //                           lines (8 dwordx4 stores per lane) and clears them, so HBM sees
 //                           only full-line coalesced writes and no separate memset.
-//   amv_reconstruct_kernel  everything after it is data parallel: one wave per MCU-row
-//                           segment (<= 10 MCUs = 60 blocks), coefficients staged in LDS,
-//                           row and column IDCT passes one 8-point transform per lane,
-//                           YCbCr->BGR and the bottom-up store (AmvJpeg.c:789-840).
+//   (amv_decode_sync.hip holds the faster entropy kernel with parallelism inside a frame, which
+//   hands oversize or pathological chunks back to this one; amv_reconstruct.hip holds the stage
+//   after it.)
 //
 // Compiled with -fwrapv: the integer pipeline relies on two's-complement wrap exactly as the
 // reference's compiler output does.
@@ -224,192 +223,6 @@ void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
     const uint32_t grid = (n + kWave - 1) / kWave;   // with a list: upper bound, surplus groups exit at once
     hipLaunchKernelGGL(amv_huffman_kernel, dim3(grid), dim3(kWave), 0, s, blob, blob_bytes, offs,
                        lens, n, g.blocks, d_img, coef, status, nmcu_ok, list, list_count);
-}
-
-// ============================================================================================
-// reconstruction stage
-// ============================================================================================
-
-namespace {
-
-constexpr int kSegMcus = 10;           // MCUs per workgroup: 160 pixels of one MCU row
-constexpr int kRowPitch = 72;          // int32 per block in the row-pass buffer (64 + 8: column
-                                       // reads of 4 neighbouring blocks hit 32 distinct banks)
-
-// 8-point inverse DCT of AmvJpeg.c: idctrow (:1082-1128) when kColumn == false, idctcol
-// (:1130-1175, without its final clamp) when true.  The reference's all-AC-zero shortcuts
-// (:1087-1092, :1134-1140) are exact special cases of this arithmetic and are not branched on.
-template <bool kColumn>
-__device__ __forceinline__ void idct8(int (&v)[8]) {
-    constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565;
-    constexpr int kUp = kColumn ? 256 : 2048;    // <<8 / <<11
-    constexpr int kBias = kColumn ? 8192 : 128;
-    constexpr int kRound = kColumn ? 4 : 0;
-    constexpr int kDown = kColumn ? 3 : 0;
-    constexpr int kOut = kColumn ? 14 : 8;
-    int a0 = v[0] * kUp + kBias, a1 = v[4] * kUp;
-    int a2 = v[6], a3 = v[2], a4 = v[1], a5 = v[7], a6 = v[5], a7 = v[3], t;
-    t = W7 * (a4 + a5) + kRound;
-    a4 = (t + (W1 - W7) * a4) >> kDown;
-    a5 = (t - (W1 + W7) * a5) >> kDown;
-    t = W3 * (a6 + a7) + kRound;
-    a6 = (t - (W3 - W5) * a6) >> kDown;
-    a7 = (t - (W3 + W5) * a7) >> kDown;
-    t = a0 + a1;
-    a0 -= a1;
-    a1 = W6 * (a3 + a2) + kRound;
-    a2 = (a1 - (W2 + W6) * a2) >> kDown;
-    a3 = (a1 + (W2 - W6) * a3) >> kDown;
-    a1 = a4 + a6;
-    a4 -= a6;
-    a6 = a5 + a7;
-    a5 -= a7;
-    a7 = t + a3;
-    t -= a3;
-    a3 = a0 + a2;
-    a0 -= a2;
-    a2 = (181 * (a4 + a5) + 128) >> 8;
-    a4 = (181 * (a4 - a5) + 128) >> 8;
-    v[0] = (a7 + a1) >> kOut;
-    v[1] = (a3 + a2) >> kOut;
-    v[2] = (a0 + a4) >> kOut;
-    v[3] = (t + a6) >> kOut;
-    v[4] = (t - a6) >> kOut;
-    v[5] = (a0 - a4) >> kOut;
-    v[6] = (a3 - a2) >> kOut;
-    v[7] = (a7 - a1) >> kOut;
-}
-
-// iclp[] of AmvJpeg.c:1073-1080 (table spans -512..511; beyond it the reference reads out of
-// bounds, defined here as saturation)
-__device__ __forceinline__ int clamp_iclp(int x) { return min(max(x, -256), 255); }
-
-__device__ __forceinline__ uint32_t clamp_u8(int x) { return (uint32_t)min(max(x, 0), 255); }
-
-}  // namespace
-
-__global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
-    const int16_t* __restrict__ coef, const uint32_t* __restrict__ nmcu_ok, uint32_t n,
-    FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
-    // coefficient stage and pixel planes share one region: the planes are written only after
-    // the row pass has consumed every coefficient
-    __shared__ __attribute__((aligned(16))) int16_t s_c[kSegMcus * 6 * 64];
-    __shared__ __attribute__((aligned(16))) int s_rows[kSegMcus * 6 * kRowPitch];
-    __shared__ uint16_t s_tab[2][64];
-
-    const uint32_t lane = threadIdx.x;
-    uint32_t bid = blockIdx.x;
-    const uint32_t seg = bid % nseg;
-    bid /= nseg;
-    const uint32_t my = bid % g.mcu_rows;
-    const uint32_t f = bid / g.mcu_rows;
-    const uint32_t m0 = seg * kSegMcus;
-    const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
-    const uint32_t nb = cnt * 6;
-
-    {   // IQtIZzBlock's gather (AmvJpeg.c:1035-1042): natural position -> (scan index, step)
-        uint32_t scan = kScanOfNatural[lane];
-        if (lane == (uint32_t)kAmvlibQuirkNatural && !(flags & kFlagZigzagFixed)) scan = kAmvlibQuirkScan;
-        s_tab[0][lane] = (uint16_t)(scan | ((uint32_t)kQuantLuma[scan] << 8));
-        s_tab[1][lane] = (uint16_t)(scan | ((uint32_t)kQuantChroma[scan] << 8));
-    }
-    {   // stage this segment's coefficients: nb consecutive 128-byte blocks
-        const uint4* src = reinterpret_cast<const uint4*>(
-            coef + ((uint64_t)f * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u);
-        uint4* dst = reinterpret_cast<uint4*>(s_c);
-        for (uint32_t i = lane; i < nb * 8; i += kWave) dst[i] = src[i];
-    }
-    __syncthreads();
-
-    // row pass: one (block, row) per lane
-    for (uint32_t t = lane; t < nb * 8; t += kWave) {
-        const uint32_t blk = t >> 3, r = t & 7u;
-        const uint16_t* tab = s_tab[(blk % 6u) >= 4u ? 1 : 0];
-        const int16_t* cb = s_c + blk * 64u;
-        int v[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t e = tab[r * 8u + c];
-            v[c] = (int)cb[e & 0xffu] * (int)(e >> 8);
-        }
-        idct8<false>(v);
-        int* dst = s_rows + blk * kRowPitch + r * 8u;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) dst[c] = v[c];
-    }
-    __syncthreads();
-
-    // column pass: one (block, column) per lane; results go to 16-row Y and 8-row U/V planes
-    int16_t* s_y = s_c;                         // [16][kSegMcus*16]
-    int16_t* s_u = s_c + 16 * kSegMcus * 16;    // [8][kSegMcus*8]
-    int16_t* s_v = s_u + 8 * kSegMcus * 8;
-    constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;
-    for (uint32_t t = lane; t < nb * 8; t += kWave) {
-        const uint32_t blk = t >> 3, c = t & 7u;
-        const uint32_t m = blk / 6u, k6 = blk % 6u;
-        const int* src = s_rows + blk * kRowPitch + c;
-        int v[8];
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) v[rr] = src[rr * 8];
-        idct8<true>(v);
-        if (k6 < 4) {  // GetYUV (AmvJpeg.c:754-787) + the +128 of IQtIZzBlock (:1023,1047)
-            int16_t* dst = s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u + c;
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) dst[rr * kPitchY] = (int16_t)(clamp_iclp(v[rr]) + 128);
-        } else {
-            int16_t* dst = (k6 == 4 ? s_u : s_v) + m * 8u + c;
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) dst[rr * kPitchC] = (int16_t)clamp_iclp(v[rr]);
-        }
-    }
-    __syncthreads();
-
-    // StoreBuffer (AmvJpeg.c:789-840): 4 pixels = 12 bytes = 3 dwords per lane step
-    const uint32_t ok = nmcu_ok[f];
-    const uint32_t groups = cnt * 4;
-    uint8_t* frame_out = out + (uint64_t)f * g.frame_bytes;
-    for (uint32_t t = lane; t < 16 * groups; t += kWave) {
-        const uint32_t i = t / groups, gi = t % groups;
-        const uint32_t row = my * 16u + i;
-        if (row >= g.height) break;                       // :798 (rows only grow with t)
-        const uint32_t lc = gi * 4u, gc = m0 * 16u + lc;
-        if (gc >= g.width) continue;                      // :803
-        const bool decoded = (my * g.mcu_cols + m0 + (gi >> 2)) < ok;
-        uint32_t bytes[12];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int y = s_y[i * kPitchY + lc + j];
-            const int u = s_u[(i >> 1) * kPitchC + ((lc + j) >> 1)];
-            const int w = s_v[(i >> 1) * kPitchC + ((lc + j) >> 1)];
-            const int rr = (y * 256 + 18 * u + 367 * w) >> 8;    // :808-810
-            const int gg = (y * 256 - 159 * u - 220 * w) >> 8;
-            const int bb = (y * 256 + 411 * u - 29 * w) >> 8;
-            bytes[3 * j + 0] = decoded ? clamp_u8(bb) : 0u;      // :829-831 B,G,R
-            bytes[3 * j + 1] = decoded ? clamp_u8(gg) : 0u;
-            bytes[3 * j + 2] = decoded ? clamp_u8(rr) : 0u;
-        }
-        uint8_t* dst = frame_out + (uint64_t)(g.height - 1u - row) * g.stride + gc * 3u;  // :800
-        if (gc + 4u <= g.width) {
-            uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                d32[q] = bytes[4 * q] | (bytes[4 * q + 1] << 8) | (bytes[4 * q + 2] << 16) | (bytes[4 * q + 3] << 24);
-        } else {
-            const uint32_t valid = (g.width - gc) * 3u;
-#pragma unroll
-            for (uint32_t q = 0; q < 12; ++q)
-                if (q < valid) dst[q] = (uint8_t)bytes[q];
-        }
-    }
-}
-
-void launch_reconstruct(const int16_t* coef, const uint32_t* nmcu_ok, uint32_t n,
-                        const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
-    if (n == 0) return;
-    const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
-    const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
-    hipLaunchKernelGGL(amv_reconstruct_kernel, dim3((uint32_t)grid), dim3(kWave), 0, s, coef,
-                       nmcu_ok, n, g, nseg, flags, out);
 }
 
 }  // namespace amv

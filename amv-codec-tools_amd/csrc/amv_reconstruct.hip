@@ -1,0 +1,230 @@
+// amv_reconstruct.hip -- everything after the entropy stage: dequantise, inverse DCT, YCbCr->BGR,
+// bottom-up store (IQtIZzBlock / Fast_IDCT / GetYUV / StoreBuffer, AmvJpeg.c:1010-1059, 754-840).
+//
+// One wave per MCU-row segment (<= 10 MCUs = 60 blocks = 160 pixels of 16 rows):
+//   A. lane b loads block b's 64 coefficients (one 128-byte line) straight into registers;
+//   B. the whole 8x8 block stays in that lane's registers: de-zig-zag is register renaming (plus
+//      one select for amvlib's [3][4] table entry), dequantisation one multiply per coefficient,
+//      then 8 row transforms and 8 column transforms with the reference's exact integer
+//      arithmetic -- no transposition, no LDS between the passes;
+//   C. results go to 16-row Y and 8-row U/V planes in LDS (one 16-byte store per block row);
+//   D. colour conversion, 4 pixels per lane step, into an LDS image of the destination rows in
+//      MEMORY order (the picture is stored bottom-up, so the segment's rows are one run of
+//      consecutive destination rows);
+//   E. that image goes out as 16-byte stores, 1 KiB per wave instruction, whole lines only.
+//
+// Pixels of MCUs at or after a frame's first decode error are zero (AMVDec.c:283 + the reference
+// stopping at the error).  Compiled with -fwrapv, as the reference's arithmetic wraps.
+#include "amv_kernels.h"
+
+namespace amv {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kSegMcus = 10;   // MCUs per wave: 60 of 64 lanes busy in the transform
+
+// 8-point inverse DCT of AmvJpeg.c: idctrow (:1082-1128) when kColumn == false, idctcol
+// (:1130-1175, without its final clamp) when true.  The reference's all-AC-zero shortcuts
+// (:1087-1092, :1134-1140) are exact special cases of this arithmetic and are not branched on.
+template <bool kColumn>
+__device__ __forceinline__ void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7) {
+    constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565;
+    constexpr int kUp = kColumn ? 256 : 2048;    // <<8 / <<11
+    constexpr int kBias = kColumn ? 8192 : 128;
+    constexpr int kRound = kColumn ? 4 : 0;
+    constexpr int kDown = kColumn ? 3 : 0;
+    constexpr int kOut = kColumn ? 14 : 8;
+    int a0 = v0 * kUp + kBias, a1 = v4 * kUp;
+    int a2 = v6, a3 = v2, a4 = v1, a5 = v7, a6 = v5, a7 = v3, t;
+    t = W7 * (a4 + a5) + kRound;
+    a4 = (t + (W1 - W7) * a4) >> kDown;
+    a5 = (t - (W1 + W7) * a5) >> kDown;
+    t = W3 * (a6 + a7) + kRound;
+    a6 = (t - (W3 - W5) * a6) >> kDown;
+    a7 = (t - (W3 + W5) * a7) >> kDown;
+    t = a0 + a1;
+    a0 -= a1;
+    a1 = W6 * (a3 + a2) + kRound;
+    a2 = (a1 - (W2 + W6) * a2) >> kDown;
+    a3 = (a1 + (W2 - W6) * a3) >> kDown;
+    a1 = a4 + a6;
+    a4 -= a6;
+    a6 = a5 + a7;
+    a5 -= a7;
+    a7 = t + a3;
+    t -= a3;
+    a3 = a0 + a2;
+    a0 -= a2;
+    a2 = (181 * (a4 + a5) + 128) >> 8;
+    a4 = (181 * (a4 - a5) + 128) >> 8;
+    v0 = (a7 + a1) >> kOut;
+    v1 = (a3 + a2) >> kOut;
+    v2 = (a0 + a4) >> kOut;
+    v3 = (t + a6) >> kOut;
+    v4 = (t - a6) >> kOut;
+    v5 = (a0 - a4) >> kOut;
+    v6 = (a3 - a2) >> kOut;
+    v7 = (a7 - a1) >> kOut;
+}
+
+// iclp[] of AmvJpeg.c:1073-1080 (table spans -512..511; beyond it the reference reads out of
+// bounds, defined here as saturation)
+__device__ __forceinline__ int clamp_iclp(int x) { return min(max(x, -256), 255); }
+__device__ __forceinline__ uint32_t clamp_u8(int x) { return (uint32_t)min(max(x, 0), 255); }
+
+// int16 number `i` of a block held as 32 dwords
+__device__ __forceinline__ int coef_at(const uint32_t (&c)[32], int i) {
+    return (i & 1) ? ((int)c[i >> 1] >> 16) : (int)(int16_t)(c[i >> 1] & 0xffffu);
+}
+
+}  // namespace
+
+template <bool kVec16>
+__global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
+    const int16_t* __restrict__ coef, const uint32_t* __restrict__ nmcu_ok, uint32_t n,
+    FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
+    constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;   // int16 units
+    constexpr uint32_t kPitchOut = kSegMcus * 48;                            // bytes per staged row
+    __shared__ __attribute__((aligned(16))) int16_t s_y[16 * kPitchY];
+    __shared__ __attribute__((aligned(16))) int16_t s_u[8 * kPitchC];
+    __shared__ __attribute__((aligned(16))) int16_t s_v[8 * kPitchC];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[16 * kPitchOut];
+
+    const uint32_t lane = threadIdx.x;
+    uint32_t bid = blockIdx.x;
+    const uint32_t seg = bid % nseg;
+    bid /= nseg;
+    const uint32_t my = bid % g.mcu_rows;
+    const uint32_t f = bid / g.mcu_rows;
+    const uint32_t m0 = seg * kSegMcus;
+    const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
+    const uint32_t nb = cnt * 6;
+
+    // ---- A + B + C: one block per lane
+    if (lane < nb) {
+        const uint32_t m = lane / 6u, k6 = lane % 6u;
+        const bool chroma = k6 >= 4u;
+        const uint4* src = reinterpret_cast<const uint4*>(
+            coef + (((uint64_t)f * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 6u + lane) * 64u);
+        uint32_t c[32];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 q = src[i];
+            c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+        }
+        // IQtIZzBlock's gather (AmvJpeg.c:1035-1042): out[nat] = coef[scan(nat)] * step[scan(nat)]
+        int v[64];
+#pragma unroll
+        for (int nat = 0; nat < 64; ++nat) {
+            const int scan = kScanOfNatural[nat];
+            const int step = chroma ? (int)kQuantChroma[scan] : (int)kQuantLuma[scan];
+            v[nat] = coef_at(c, scan) * step;
+        }
+        if (!(flags & kFlagZigzagFixed)) {   // amvlib's table reads scan position 37 at natural (3,4)
+            const int step = chroma ? (int)kQuantChroma[kAmvlibQuirkScan] : (int)kQuantLuma[kAmvlibQuirkScan];
+            v[kAmvlibQuirkNatural] = coef_at(c, kAmvlibQuirkScan) * step;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            idct8<false>(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
+#pragma unroll
+        for (int col = 0; col < 8; ++col)
+            idct8<true>(v[col], v[8 + col], v[16 + col], v[24 + col], v[32 + col], v[40 + col], v[48 + col], v[56 + col]);
+        // GetYUV (AmvJpeg.c:754-787) + the +128 of IQtIZzBlock (:1023,1047): one 16-byte row at a time
+        const int offset = chroma ? 0 : 128;
+        int16_t* dst = chroma ? (k6 == 4u ? s_u : s_v) + m * 8u
+                              : s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u;
+        const uint32_t pitch = chroma ? kPitchC : kPitchY;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t lo = (uint32_t)(clamp_iclp(v[8 * r + 2 * q]) + offset) & 0xffffu;
+                const uint32_t hi = (uint32_t)(clamp_iclp(v[8 * r + 2 * q + 1]) + offset) & 0xffffu;
+                w[q] = lo | (hi << 16);
+            }
+            *reinterpret_cast<uint4*>(dst + r * pitch) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    __syncthreads();
+
+    // ---- D: StoreBuffer (AmvJpeg.c:789-840) into the staged image.  Picture row my*16+i lands in
+    // destination row H-1-(my*16+i) (:800): staged slot vr-1-i, so that slots ascend in memory.
+    const uint32_t ok = nmcu_ok[f];
+    const uint32_t vr = min(16u, g.height - my * 16u);                 // rows of this MCU row inside the picture (:798)
+    const uint32_t px = min(cnt * 16u, g.width - m0 * 16u);            // pixels of this segment inside it (:803)
+    const uint32_t groups = cnt * 4u;
+    for (uint32_t t = lane; t < vr * groups; t += kWave) {
+        const uint32_t i = t / groups, gi = t % groups, lc = gi * 4u;
+        const bool decoded = (my * g.mcu_cols + m0 + (gi >> 2)) < ok;
+        const uint2 yy = *reinterpret_cast<const uint2*>(s_y + i * kPitchY + lc);
+        const uint32_t uu = *reinterpret_cast<const uint32_t*>(s_u + (i >> 1) * kPitchC + (lc >> 1));
+        const uint32_t vv = *reinterpret_cast<const uint32_t*>(s_v + (i >> 1) * kPitchC + (lc >> 1));
+        uint32_t b[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t yw = j < 2 ? yy.x : yy.y;
+            const int y = (j & 1) ? ((int)yw >> 16) : (int)(int16_t)(yw & 0xffffu);
+            const int u = j < 2 ? (int)(int16_t)(uu & 0xffffu) : ((int)uu >> 16);
+            const int w = j < 2 ? (int)(int16_t)(vv & 0xffffu) : ((int)vv >> 16);
+            const int rr = (y * 256 + 18 * u + 367 * w) >> 8;    // :808-810
+            const int gg = (y * 256 - 159 * u - 220 * w) >> 8;
+            const int bb = (y * 256 + 411 * u - 29 * w) >> 8;
+            b[3 * j + 0] = decoded ? clamp_u8(bb) : 0u;          // :829-831 B,G,R
+            b[3 * j + 1] = decoded ? clamp_u8(gg) : 0u;
+            b[3 * j + 2] = decoded ? clamp_u8(rr) : 0u;
+        }
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(s_out + (vr - 1u - i) * kPitchOut + lc * 3u);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            d32[q] = b[4 * q] | (b[4 * q + 1] << 8) | (b[4 * q + 2] << 16) | (b[4 * q + 3] << 24);
+    }
+    __syncthreads();
+
+    // ---- E: staged rows -> destination rows [H - my*16 - vr, H - my*16), bytes [m0*48, m0*48 + px*3)
+    uint8_t* dst0 = out + (uint64_t)f * g.frame_bytes + (uint64_t)(g.height - my * 16u - vr) * g.stride + m0 * 48u;
+    const uint32_t row_bytes = px * 3u;
+    if (kVec16) {   // stride, frame size and base are multiples of 16: whole 16-byte chunks, then the tail
+        const uint32_t chunks = row_bytes >> 4;
+        for (uint32_t t = lane; t < vr * chunks; t += kWave) {
+            const uint32_t s = t / chunks, ch = t % chunks;
+            *reinterpret_cast<uint4*>(dst0 + (uint64_t)s * g.stride + ch * 16u) =
+                *reinterpret_cast<const uint4*>(s_out + s * kPitchOut + ch * 16u);
+        }
+        const uint32_t tail = row_bytes & 15u;
+        for (uint32_t t = lane; t < vr * tail; t += kWave) {
+            const uint32_t s = t / tail, o = (row_bytes & ~15u) + t % tail;
+            dst0[(uint64_t)s * g.stride + o] = s_out[s * kPitchOut + o];
+        }
+    } else {        // rows are only 4-byte aligned (AmvJpeg.c:1524): dwords, then the tail
+        const uint32_t words = row_bytes >> 2;
+        for (uint32_t t = lane; t < vr * words; t += kWave) {
+            const uint32_t s = t / words, wd = t % words;
+            *reinterpret_cast<uint32_t*>(dst0 + (uint64_t)s * g.stride + wd * 4u) =
+                *reinterpret_cast<const uint32_t*>(s_out + s * kPitchOut + wd * 4u);
+        }
+        const uint32_t tail = row_bytes & 3u;
+        for (uint32_t t = lane; t < vr * tail; t += kWave) {
+            const uint32_t s = t / tail, o = (row_bytes & ~3u) + t % tail;
+            dst0[(uint64_t)s * g.stride + o] = s_out[s * kPitchOut + o];
+        }
+    }
+}
+
+void launch_reconstruct(const int16_t* coef, const uint32_t* nmcu_ok, uint32_t n,
+                        const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
+    const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
+    const bool vec16 = (g.stride % 16u) == 0 && (g.frame_bytes % 16u) == 0 && ((uintptr_t)out % 16u) == 0;
+    if (vec16)
+        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, dim3((uint32_t)grid), dim3(kWave), 0, s, coef, nmcu_ok, n, g,
+                           nseg, flags, out);
+    else
+        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, dim3((uint32_t)grid), dim3(kWave), 0, s, coef, nmcu_ok, n, g,
+                           nseg, flags, out);
+}
+
+}  // namespace amv
