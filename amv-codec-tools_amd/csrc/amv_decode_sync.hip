@@ -10,7 +10,10 @@
 //      copies the scan into a workspace as big-endian words with the byte after every FF removed
 //      (ReadByte, AmvJpeg.c:1061-1071), so that a decoder state is just a bit index.
 //
-//   amv_huffman_sync_kernel<L> (L lanes per frame, 64/L frames per wave)
+//   amv_huffman_sync_kernel<L> (4 independent waves per workgroup sharing the tables; L lanes per
+//   frame, 64/L frames per wave)
+//   0. the wave copies its frames' unstuffed words into LDS, packed back to back (whole-line
+//      loads), and zeroes their coefficient lines; from here on the bit stream is read from LDS;
 //   1. the bit stream is cut into L equal subsequences; lane i walks subsequence i from a GUESSED
 //      state (its first bit, "the DC symbol of block 0 comes next") up to the first symbol boundary
 //      past its end and remembers the state it arrives in: (bit, index in block, block in MCU).
@@ -20,19 +23,22 @@
 //      those branches, and a stream with a real error is caught in pass 4, which is strict;
 //   2. every lane takes its left neighbour's arrival state as its start state and walks again if
 //      that changed.  Lane 0's start is exact, so after round r lanes 0..r are exact; in practice
-//      wrong starts fall into step with the true decoder after a few MCUs (the slow part is the
-//      luma/chroma phase of the MCU) and the loop ends early (worst case L-1 rounds: still correct).
-//      These walks use "skip" tables (symbol length, index advance) and touch no coefficient;
+//      wrong starts fall into step with the true decoder after ~4 400 bits (the slow part is the
+//      luma/chroma phase of the MCU, a 1-in-6 guess) and the loop ends early (worst case L-1
+//      rounds: still correct).  These walks only look at symbol lengths and index advances, in a
+//      branch-free loop whose three LDS reads (two table levels, next stream word) go out together;
 //   3. a prefix sum of "blocks finished per lane" gives every lane its first block number;
 //   4. one strict pass decodes values and writes them (2-byte stores into the frame's zeroed
-//      coefficient lines), parking DC differences in LDS;
-//   5. the three DC predictors (ycoef/ucoef/vcoef, AmvJpeg.c:1200-1221) become a prefix sum over
-//      the parked differences.
+//      coefficient lines).  DC prediction (ycoef/ucoef/vcoef, AmvJpeg.c:1200-1221) is a running sum
+//      per component: each lane stores sums relative to its own start,
+//   5. a prefix sum over the lanes' totals gives every lane its three bases, which it adds to the DC
+//      values it stored itself.
 //
 // Statuses equal the serial kernel's bit for bit (tests): the first error on the true path stops
 // the frame, nmcu_ok counts whole MCUs before it, TRUNCATED compares consumed with stored bits.
-// Chunks larger than the per-frame workspace window, or with a run of FF bytes longer than the
-// 7-byte look-back of the unstuffer (never in a valid stream), are queued for amv_huffman_kernel.
+// Chunks larger than the per-frame window, or with a run of FF bytes longer than the 7-byte
+// look-back of the unstuffer (never in a valid stream), are queued for amv_huffman_kernel; frames
+// that find their wave's LDS pool full are queued for a second launch with one frame per wave.
 #include "amv_kernels.h"
 
 namespace amv {
@@ -40,8 +46,9 @@ namespace amv {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerGroup = 4;
+constexpr int kWaves = 4;                 // waves per workgroup (they share only the tables)
 constexpr uint32_t kNever = 0xffffffffu;
+constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + 4u * kLut2PagesPerTable * (1u << kLut2Bits) * 2u;
 
 struct State {
     uint32_t p;   // bit index in the unstuffed stream
@@ -67,22 +74,18 @@ __device__ __forceinline__ uint32_t seg_excl_sum(uint32_t v, uint32_t sub, uint3
     return x - v;
 }
 
-__device__ __forceinline__ uint32_t load_word(const uint32_t* __restrict__ words, uint32_t nwords, uint32_t i) {
-    return i < nwords ? words[i] : 0u;   // past the stored bits the stream reads as zeros
-}
-
 }  // namespace
 
 // =============================================================================================
 // unstuffing
 // =============================================================================================
 
-__global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_unstuff_kernel(
+__global__ __launch_bounds__(256) void amv_unstuff_kernel(
     const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offs,
     const uint32_t* __restrict__ lens, uint32_t n, uint32_t cap_words, uint32_t* __restrict__ ws,
     uint32_t* __restrict__ ws_bytes, uint32_t* __restrict__ retry_list, uint32_t* __restrict__ retry_count) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t frame = blockIdx.x * kWavesPerGroup + wave;
+    const uint32_t frame = blockIdx.x * 4u + wave;
     if (frame >= n) return;
     uint64_t off = offs[frame];
     uint32_t len = lens[frame];
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_unstuff_kernel(
                 if (keep & (1u << j)) { out[d ^ 3u] = (uint8_t)(w >> (8u * j)); ++d; }   // big-endian inside the word
             total += tile_total;
         }
-        // zero the tail of the last word
-        if (!retry && lane < ((4u - (total & 3u)) & 3u)) out[(total + lane) ^ 3u] = 0;
+        // zero the tail up to the next 16-byte boundary: the decoder copies whole 16-byte pieces
+        if (!retry && lane < ((16u - (total & 15u)) & 15u)) out[(total + lane) ^ 3u] = 0;
     }
     if (lane == 0) {
         ws_bytes[frame] = retry ? kNever : total;
@@ -144,90 +147,119 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_unstuff_kernel(
 }
 
 // =============================================================================================
-// walks
+// walks.  Table entries (HuffDecodeImage::m1/m2): bits 0-4 code length + magnitude bits (0 = no
+// such code), bits 5-10 how far the coefficient index moves (run + 1; 1 for a DC symbol; 63 for
+// end-of-block, which with k >= 1 always reaches 64), bits 11-14 magnitude bits; in m1 bit 15
+// means "the code is longer than 9 bits, see m2".
+//
+// Codes longer than 9 bits sit at the top of the 9-bit prefix space (canonical codes ascend with
+// length): in every table they are the prefixes [507, 512) or fewer.  m2 therefore gives each
+// table 5 pages of 128 entries, page = prefix - 507, and its address follows from the bits alone:
+// both levels are read together and the right one is selected afterwards -- no dependent second
+// LDS round trip, no branch.
 // =============================================================================================
 
 namespace {
 
+struct Window {          // a lane's view of its frame's bit stream in LDS
+    const uint32_t* words;
+    uint32_t last;       // index of a word that is always zero; reads past the data are clamped to it
+};
+
+__device__ __forceinline__ uint32_t word_at(const Window& w, uint32_t i) { return w.words[min(i, w.last)]; }
+
+// tab = table number << kLut1Bits
+__device__ __forceinline__ uint32_t lookup(const uint16_t* __restrict__ m1, const uint16_t* __restrict__ m2,
+                                           uint32_t tab, uint32_t v) {
+    constexpr uint32_t kFirst = (1u << kLut1Bits) - kLut2PagesPerTable;
+    const uint32_t prefix = v >> (32 - kLut1Bits);
+    const uint32_t page = max(prefix, kFirst) - kFirst;
+    const uint32_t e1 = m1[tab + prefix];
+    // table stride in m2 = 5 * 128 = 512 + 128 entries = tab + tab / 4
+    const uint32_t e2 = m2[tab + (tab >> 2) + (page << kLut2Bits) + ((v >> (32 - kLut1Bits - kLut2Bits)) & ((1u << kLut2Bits) - 1u))];
+    return (e1 & 0x8000u) ? e2 : e1;
+}
+
+__device__ __forceinline__ uint32_t table_of(uint32_t k, uint32_t k6) {
+    return ((k ? 2u : 0u) + (k6 >= 4u ? 1u : 0u)) << kLut1Bits;
+}
+
 // Speculative walk from `s` while s.p < limit: where symbols start and how the block position
-// moves, nothing else.  Returns the number of blocks finished.  The next stream word is always
-// one load ahead of its use.
-__device__ __forceinline__ uint32_t walk_skip(const uint32_t* __restrict__ words, uint32_t nwords,
-                                              const uint16_t* __restrict__ s1, const uint16_t* __restrict__ s2,
-                                              State& s, uint32_t limit) {
+// moves, nothing else.  Returns the number of blocks finished.
+__device__ __forceinline__ uint32_t walk_skip(const Window& w, const uint16_t* __restrict__ m1,
+                                              const uint16_t* __restrict__ m2, State& s, uint32_t limit) {
     uint32_t p = s.p, k = s.k, k6 = s.k6, nblk = 0;
     if (p >= limit) return 0u;
     uint32_t widx = p >> 5;
     const uint32_t bo = p & 31u;
-    uint64_t acc = (((uint64_t)load_word(words, nwords, widx) << 32) | load_word(words, nwords, widx + 1u)) << bo;
+    uint64_t acc = (((uint64_t)word_at(w, widx) << 32) | word_at(w, widx + 1u)) << bo;
     int nb = 64 - (int)bo;
     widx += 2u;
-    uint32_t nextw = load_word(words, nwords, widx);
-    uint32_t tab = ((k ? 2u : 0u) + (k6 >= 4u ? 1u : 0u)) << kLut1Bits;
+    uint32_t nextw = word_at(w, widx);                 // appended when the window runs low
+    ++widx;
+    uint32_t tab = table_of(k, k6);
     do {
-        const uint32_t v = (uint32_t)(acc >> 32);
-        uint32_t e = s1[tab + (v >> (32 - kLut1Bits))];
-        if (e & 0x8000u) e = s2[((e & 0xffu) << kLut2Bits) | ((v >> (32 - kLut1Bits - kLut2Bits)) & ((1u << kLut2Bits) - 1u))];
-        uint32_t used = e & 31u;
-        used = used ? used : 1u;                 // nonsense under a guessed start: slip one bit
-        const uint32_t kn = k + ((e >> 8) & 127u);
+        const uint32_t cand = word_at(w, widx);        // the word after nextw, in flight with the look-ups
+        const uint32_t e = lookup(m1, m2, tab, (uint32_t)(acc >> 32));
+        const uint32_t used = max(e & 31u, 1u);        // nonsense under a guessed start: slip one bit
+        const uint32_t kn = k + ((e >> 5) & 63u);
         acc <<= used;
         nb -= (int)used;
         p += used;
-        if (nb <= 32) {
-            acc |= (uint64_t)nextw << (32 - nb);
-            nb += 32;
-            ++widx;
-            nextw = load_word(words, nwords, widx);
-        }
-        const bool end = kn >= 64u;              // end of block, a full block, or an over-long run
+        const bool need = nb <= 32;
+        acc |= need ? (uint64_t)nextw << (need ? 32 - nb : 0) : 0ull;
+        nb += need ? 32 : 0;
+        nextw = need ? cand : nextw;
+        widx += need ? 1u : 0u;
+        const bool end = kn >= 64u;                    // end of block, a full block, or an over-long run
         k = end ? 0u : kn;
         k6 = end ? (k6 == 5u ? 0u : k6 + 1u) : k6;
         nblk += end ? 1u : 0u;
-        tab = ((k ? 2u : 0u) + (k6 >= 4u ? 1u : 0u)) << kLut1Bits;
+        tab = table_of(k, k6);
     } while (p < limit);
     s.p = p; s.k = k; s.k6 = k6;
     return nblk;
 }
 
 struct WriteResult {
-    uint32_t err;       // kStFormat / kStOverrun when the walk hit a real error
-    uint32_t err_blk;   // absolute block the error hit
-    uint32_t stop_p;    // bits consumed when the walk ended (FORMAT: incl. the reference's 17-bit give-up)
-    bool done;          // the frame's last block was finished here
+    uint32_t err;        // kStFormat / kStOverrun when the walk hit a real error
+    uint32_t err_blk;    // absolute block the error hit
+    uint32_t stop_p;     // bits consumed when the walk ended (FORMAT: incl. the reference's 17-bit give-up)
+    bool done;           // the frame's last block was finished here
+    uint32_t dc_first;   // first block whose DC symbol this lane decoded, and how many follow
+    uint32_t dc_count;
+    int sum[3];          // the lane's DC differences added up per component (Y, Cb, Cr)
 };
 
 // The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state.
-__device__ __forceinline__ WriteResult walk_write(const uint32_t* __restrict__ words, uint32_t nwords,
-                                                  const uint16_t* __restrict__ l1, const uint16_t* __restrict__ l2,
-                                                  State s, uint32_t limit, uint32_t blk, uint32_t blocks_per_frame,
-                                                  int16_t* __restrict__ coef, int16_t* __restrict__ dc) {
-    WriteResult r{0u, 0u, 0u, false};
+__device__ __forceinline__ WriteResult walk_write(const Window& w, const uint16_t* __restrict__ m1,
+                                                  const uint16_t* __restrict__ m2, State s, uint32_t limit,
+                                                  uint32_t blk, uint32_t blocks_per_frame,
+                                                  int16_t* __restrict__ coef) {
+    WriteResult r{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}};
     uint32_t p = s.p, k = s.k, k6 = s.k6;
     uint32_t widx = p >> 5;
     const uint32_t bo = p & 31u;
-    uint64_t acc = (((uint64_t)load_word(words, nwords, widx) << 32) | load_word(words, nwords, widx + 1u)) << bo;
+    uint64_t acc = (((uint64_t)word_at(w, widx) << 32) | word_at(w, widx + 1u)) << bo;
     int nb = 64 - (int)bo;
     widx += 2u;
-    uint32_t nextw = load_word(words, nwords, widx);
+    uint32_t nextw = word_at(w, widx);
+    r.dc_first = blk + (k ? 1u : 0u);
     while (p < limit) {
         const uint32_t v = (uint32_t)(acc >> 32);
-        const uint32_t tab = (k == 0u ? 0u : 2u) + (k6 >= 4u ? 1u : 0u);
-        uint32_t e = l1[(tab << kLut1Bits) + (v >> (32 - kLut1Bits))];
-        if (e & 0x8000u) e = l2[((e & 0xffu) << kLut2Bits) | ((v >> (32 - kLut1Bits - kLut2Bits)) & ((1u << kLut2Bits) - 1u))];
-        const uint32_t len = (e >> 8) & 31u;
-        if (len == 0u) {                         // no code matches: FUNC_FORMAT_ERROR, AmvJpeg.c:887
+        const uint32_t e = lookup(m1, m2, table_of(k, k6), v);
+        const uint32_t used = e & 31u;
+        if (used == 0u) {                        // no code matches: FUNC_FORMAT_ERROR, AmvJpeg.c:887
             r.err = kStFormat; r.err_blk = blk; r.stop_p = p + 17u;
             break;
         }
-        const uint32_t sym = e & 0xffu, size = sym & 15u;
+        const uint32_t size = (e >> 11) & 15u, adv = (e >> 5) & 63u;
         int val = 0;
         if (size) {
-            const uint32_t mag = (v << len) >> (32u - size);
+            const uint32_t mag = (v << (used - size)) >> (32u - size);
             val = (int)mag;
             if (mag < (1u << (size - 1u))) val -= (1 << size) - 1;   // :924-933
         }
-        const uint32_t used = len + size;
         acc <<= used;
         nb -= (int)used;
         p += used;
@@ -235,16 +267,20 @@ __device__ __forceinline__ WriteResult walk_write(const uint32_t* __restrict__ w
             acc |= (uint64_t)nextw << (32 - nb);
             nb += 32;
             ++widx;
-            nextw = load_word(words, nwords, widx);
+            nextw = word_at(w, widx);
         }
         bool block_end = false;
-        if (k == 0u) {                           // DC difference (:945-951)
-            dc[blk] = (int16_t)val;
+        if (k == 0u) {                           // DC difference (:945-951), summed per component (:1200-1221)
+            const int c = k6 < 4u ? 0 : (int)k6 - 3;
+            const int t = (c == 0 ? r.sum[0] : (c == 1 ? r.sum[1] : r.sum[2])) + val;
+            if (c == 0) r.sum[0] = t; else if (c == 1) r.sum[1] = t; else r.sum[2] = t;
+            coef[(uint64_t)blk * 64u] = (int16_t)t;   // relative to this lane's start; pass 5 adds the base
+            ++r.dc_count;
             k = 1u;
-        } else if (sym == 0u) {                  // end of block (:959-964)
+        } else if (adv == 63u) {                 // end of block (:959-964)
             block_end = true;
         } else {
-            k += sym >> 4;
+            k += adv - 1u;
             if (k > 63u) {                       // the reference writes out of bounds here (:967-969)
                 r.err = kStOverrun; r.err_blk = blk; r.stop_p = p;
                 break;
@@ -263,47 +299,75 @@ __device__ __forceinline__ WriteResult walk_write(const uint32_t* __restrict__ w
 
 }  // namespace
 
-// dynamic LDS: [ HuffDecodeImage 16 KB | per wave: dc[64/L][dc_cap] ]
+// dynamic LDS: [ m1 4 KB | m2 5 KB | per wave: pool of pool_bytes with the frames' stream words ]
+// With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).  Frames
+// whose words do not fit what is left of their wave's pool are appended to defer_list.
 template <int L>
-__global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel(
+__global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
-    uint32_t blocks_per_frame, uint32_t cap_words, uint32_t dc_cap, const HuffDecodeImage* __restrict__ img,
-    int16_t* __restrict__ coef, int32_t* __restrict__ status, uint32_t* __restrict__ nmcu_ok,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+    uint32_t blocks_per_frame, uint32_t cap_words, uint32_t pool_bytes,
+    const HuffDecodeImage* __restrict__ img, int16_t* __restrict__ coef, int32_t* __restrict__ status,
+    uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
     unsigned long long* __restrict__ stats) {
     constexpr int kFrames = kWave / L;   // frames per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
-    const uint16_t* s_l1 = reinterpret_cast<const uint16_t*>(s_mem);
-    const uint16_t* s_l2 = s_l1 + (4 << kLut1Bits);
-    const uint16_t* s_s1 = s_l2 + (kLut2Pages << kLut2Bits);
-    const uint16_t* s_s2 = s_s1 + (4 << kLut1Bits);
+    const uint16_t* m1 = reinterpret_cast<const uint16_t*>(s_mem);
+    const uint16_t* m2 = m1 + (4 << kLut1Bits);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slot = lane / L, sub = lane % L;
 
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(img);
+    {   // tables, shared by the four waves
+        const uint4* src = reinterpret_cast<const uint4*>(&img->m1[0][0]);
         uint4* dst = reinterpret_cast<uint4*>(s_mem);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)sizeof(HuffDecodeImage) / 16u; i += kWave * kWavesPerGroup) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < kTableBytes / 16u; i += kWave * kWaves) dst[i] = src[i];
     }
-    __syncthreads();   // the only workgroup-wide barrier
-
-    const uint32_t frame = (blockIdx.x * kWavesPerGroup + wave) * kFrames + slot;
-    const uint32_t total = frame < n ? ws_bytes[frame] : kNever;
-    const bool live = total != kNever;            // not: past the batch, or handed to the serial kernel
-    const uint32_t* words = ws + (uint64_t)(live ? frame : 0) * cap_words;
-    int16_t* fcoef = coef + (uint64_t)(live ? frame : 0) * blocks_per_frame * 64u;
-    int16_t* dc = reinterpret_cast<int16_t*>(s_mem + sizeof(HuffDecodeImage)) + (wave * kFrames + slot) * dc_cap;
-    const uint32_t valid_bits = live ? total * 8u : 0u;
-    const uint32_t nwords = live ? (total + 3u) >> 2 : 0u;
+    __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
+    if (list) n = *list_count;
+    const uint32_t task = blockIdx.x * kWaves + wave;
+    if (task * kFrames >= n) return;
 
     const bool timing = stats != nullptr && lane == 0;   // optional phase clock (amvhip_entropy_stats)
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
     if (timing) tc[0] = clock64();
 
-    // ---- 0. zero this frame's coefficient lines
+    const uint32_t idx = task * kFrames + slot;
+    const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
+    uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+    uint8_t* pool = s_mem + kTableBytes + wave * pool_bytes;
+
+    // ---- 0. stream words -> LDS, frames packed back to back (16-byte pieces, every lane helps with
+    // every frame), one zero piece behind each for clamped reads; coefficient lines zeroed
+    uint32_t my_off = 0, used_pool = 0;
+#pragma unroll
+    for (int f = 0; f < kFrames; ++f) {
+        const uint32_t t = __shfl(total, f * L);
+        const uint32_t fr = __shfl(frame, f * L);
+        if (t == kNever) continue;                // wave-uniform
+        const uint32_t pieces = (t + 15u) >> 4;
+        const uint32_t need = (pieces + 1u) * 16u;
+        if (used_pool + need > pool_bytes) {      // no room left in this wave's pool
+            if (lane == 0) defer_list[atomicAdd(defer_count, 1u)] = fr;
+            if (slot == (uint32_t)f) total = kNever;
+            continue;
+        }
+        const uint4* src = reinterpret_cast<const uint4*>(ws + (uint64_t)fr * cap_words);
+        uint4* dst = reinterpret_cast<uint4*>(pool + used_pool);
+        for (uint32_t i = lane; i < pieces; i += kWave) dst[i] = src[i];
+        if (lane == 0) dst[pieces] = make_uint4(0, 0, 0, 0);
+        if (slot == (uint32_t)f) my_off = used_pool;
+        used_pool += need;
+    }
+    const bool live = total != kNever;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(pool + my_off);
+    int16_t* fcoef = coef + (uint64_t)(live ? frame : 0) * blocks_per_frame * 64u;
+    const uint32_t valid_bits = live ? total * 8u : 0u;
     if (live) {
         uint4* z = reinterpret_cast<uint4*>(fcoef);
         for (uint32_t i = sub; i < blocks_per_frame * 8u; i += L) z[i] = make_uint4(0, 0, 0, 0);
     }
+    wave_sync();   // LDS fills are ordered before the walks; the zeroing stores stay in flight
+    Window win{words, live ? ((total + 15u) >> 4) * 4u : 0u};
 
     // ---- 1/2. speculative walks until every lane's start state equals its neighbour's arrival
     uint32_t S = ((valid_bits + L - 1) / L + 31u) & ~31u;   // bits per lane, a whole number of words
@@ -312,7 +376,7 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel
     const uint32_t limit = (!live || sub == L - 1) ? 0u : (sub + 1u) * S;
     State entry{sub * S, 0u, 0u}, arrive = entry;
     if (timing) tc[1] = clock64();
-    uint32_t my_blocks = walk_skip(words, nwords, s_s1, s_s2, arrive, limit);
+    uint32_t my_blocks = walk_skip(win, m1, m2, arrive, limit);
     if (timing) tc[2] = clock64();
     uint32_t rounds = 0;
     const uint64_t seg = L == 64 ? ~0ull : (((1ull << (L & 63)) - 1ull) << (slot * L));
@@ -328,11 +392,11 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel
         if (changed) {
             entry = left;
             arrive = left;
-            my_blocks = walk_skip(words, nwords, s_s1, s_s2, arrive, limit);
+            my_blocks = walk_skip(win, m1, m2, arrive, limit);
         }
     }
-
     if (timing) tc[3] = clock64();
+
     // ---- 3. first block of every lane
     uint32_t all_blocks;
     const uint32_t blk0 = seg_excl_sum<L>(my_blocks, sub, all_blocks);
@@ -340,9 +404,9 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel
     // ---- 4. the strict, writing pass.  Lanes left of the frame's end (or first error) are exact;
     // whatever a lane to the right of it does is ignored below.
     __builtin_amdgcn_s_waitcnt(0);   // the zeroing stores have landed before the sparse ones go out
-    WriteResult wr{0u, 0u, 0u, false};
+    WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}};
     if (live && blk0 < blocks_per_frame)
-        wr = walk_write(words, nwords, s_l1, s_l2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, fcoef, dc);
+        wr = walk_write(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, fcoef);
     if (timing) tc[4] = clock64();
     const uint64_t stop_mask = __ballot(wr.done || wr.err != 0u) & seg;
     uint32_t st = 0, good_blocks = blocks_per_frame;
@@ -357,28 +421,19 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel
     } else {
         st = kStFormat; good_blocks = 0;   // unreachable: the last lane runs until the frame ends or fails
     }
-    const uint32_t mcus = good_blocks / 6u;
 
-    // ---- 5. DC prediction over whole MCUs: value = running sum of the component's differences
-    wave_sync();
-    const uint32_t per = (mcus + L - 1) / L;
-    const uint32_t m_lo = live ? min(mcus, sub * per) : 0u, m_hi = live ? min(mcus, m_lo + per) : 0u;
-    uint32_t sy = 0, su = 0, sv = 0;
-    for (uint32_t m = m_lo; m < m_hi; ++m) {
-        const int16_t* d = dc + m * 6u;
-        sy += (uint32_t)(d[0] + d[1] + d[2] + d[3]);
-        su += (uint32_t)d[4];
-        sv += (uint32_t)d[5];
-    }
+    // ---- 5. DC prediction: every lane adds the sums of the lanes to its left to the DCs it stored.
+    // A lane reads back only its own stores (same thread, ordered by the wait), so no cache is in play.
     uint32_t tot;
-    uint32_t py = seg_excl_sum<L>(sy, sub, tot), pu = seg_excl_sum<L>(su, sub, tot), pv = seg_excl_sum<L>(sv, sub, tot);
-    for (uint32_t m = m_lo; m < m_hi; ++m) {
-        const int16_t* d = dc + m * 6u;
-        int16_t* o = fcoef + (uint64_t)m * 384u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { py += (uint32_t)d[q]; o[q * 64] = (int16_t)py; }
-        pu += (uint32_t)d[4]; o[256] = (int16_t)pu;
-        pv += (uint32_t)d[5]; o[320] = (int16_t)pv;
+    const int by = (int)seg_excl_sum<L>((uint32_t)wr.sum[0], sub, tot);
+    const int bu = (int)seg_excl_sum<L>((uint32_t)wr.sum[1], sub, tot);
+    const int bv = (int)seg_excl_sum<L>((uint32_t)wr.sum[2], sub, tot);
+    __builtin_amdgcn_s_waitcnt(0);
+    for (uint32_t j = 0; j < wr.dc_count; ++j) {
+        const uint32_t b = wr.dc_first + j, c6 = b % 6u;
+        const int base = c6 < 4u ? by : (c6 == 4u ? bu : bv);
+        int16_t* q = fcoef + (uint64_t)b * 64u;
+        *q = (int16_t)(*q + base);
     }
     if (timing) {
         tc[5] = clock64();
@@ -392,55 +447,81 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel
             atomicMax(&stats[2], (unsigned long long)rounds);
         }
         status[frame] = (int32_t)st;
-        nmcu_ok[frame] = mcus;
+        nmcu_ok[frame] = good_blocks / 6u;
     }
 }
 
 namespace {
 
 template <int L>
-void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const FrameGeom& g, uint32_t cap_words,
+void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
+                 const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, uint32_t pool_bytes,
                  const HuffDecodeImage* d_img, int16_t* coef, int32_t* status, uint32_t* nmcu_ok,
-                 unsigned long long* stats, hipStream_t s) {
-    constexpr int kFrames = kWave / L;
-    const uint32_t dc_cap = (g.blocks + 7u) & ~7u;
-    const uint32_t lds = (uint32_t)sizeof(HuffDecodeImage) + kWavesPerGroup * kFrames * dc_cap * 2u;
+                 uint32_t* defer_list, uint32_t* defer_count, unsigned long long* stats, hipStream_t s) {
+    constexpr uint32_t kPerGroup = (uint32_t)(kWave / L) * kWaves;
     static bool raised = false;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
-    const uint32_t per_group = kWavesPerGroup * kFrames;
-    hipLaunchKernelGGL(amv_huffman_sync_kernel<L>, dim3((n + per_group - 1) / per_group), dim3(kWave * kWavesPerGroup),
-                       lds, s, ws, ws_bytes, n, g.blocks, cap_words, dc_cap, d_img, coef, status, nmcu_ok, stats);
+    hipLaunchKernelGGL(amv_huffman_sync_kernel<L>, dim3((n + kPerGroup - 1) / kPerGroup), dim3(kWave * kWaves),
+                       kTableBytes + kWaves * pool_bytes, s, ws, ws_bytes, n, list, list_count, g.blocks, cap_words,
+                       pool_bytes, d_img, coef, status, nmcu_ok, defer_list, defer_count, stats);
 }
 
 }  // namespace
 
-bool huffman_sync_fits(const FrameGeom& g, int lanes_per_frame) {
-    const uint32_t dc_cap = (g.blocks + 7u) & ~7u;
-    return sizeof(HuffDecodeImage) + (size_t)kWavesPerGroup * (kWave / lanes_per_frame) * dc_cap * 2u <= 150u * 1024u;
+// The launch plan for a geometry.  First pass: as few lanes per frame as `wanted` allows while two
+// workgroups (8 waves) fit a CU's LDS, with a pool that holds its frames at ~70 % of the window each.
+// lanes == 0: frames too large for any configuration, use the serial kernel.
+SyncPlan huffman_sync_plan(const FrameGeom& g, uint32_t cap_words, int wanted) {
+    (void)g;
+    SyncPlan plan{0, 0u, 0u};
+    const uint32_t one = cap_words * 4u + 16u;          // the largest frame plus its zero piece
+    plan.pool_single = one;
+    if (kTableBytes + kWaves * one > 150u * 1024u) return plan;
+    const uint32_t budget = (78u * 1024u - kTableBytes) / kWaves;   // per wave, two workgroups per CU
+    const int tries[4] = {8, 16, 32, 64};
+    for (int i = 0; i < 4; ++i) {
+        const int lanes = tries[i];
+        if (lanes < wanted) continue;
+        const uint32_t frames = (uint32_t)(kWave / lanes);
+        if (lanes != 64 && (frames * one * 7u) / 10u > budget) continue;   // frames would not fit their pool
+        uint32_t pool = lanes == 64 ? one : budget;
+        if (pool > frames * one) pool = frames * one;
+        if (pool < one) pool = one;
+        plan.lanes = lanes;
+        plan.pool = pool & ~15u;
+        return plan;
+    }
+    plan.lanes = 64;
+    plan.pool = one;
+    return plan;
 }
 
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
                     uint32_t cap_words, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
                     hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(amv_unstuff_kernel, dim3((n + kWavesPerGroup - 1) / kWavesPerGroup), dim3(kWave * kWavesPerGroup), 0,
-                       s, blob, blob_bytes, offs, lens, n, cap_words, ws, ws_bytes, retry_list, retry_count);
+    hipLaunchKernelGGL(amv_unstuff_kernel, dim3((n + 3u) / 4u), dim3(256), 0, s, blob, blob_bytes, offs, lens, n,
+                       cap_words, ws, ws_bytes, retry_list, retry_count);
 }
 
-void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const FrameGeom& g, uint32_t cap_words,
-                         int lanes_per_frame, const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
-                         uint32_t* nmcu_ok, unsigned long long* stats, hipStream_t s) {
+void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
+                         const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
+                         uint32_t pool_bytes, const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
+                         uint32_t* nmcu_ok, uint32_t* defer_list, uint32_t* defer_count, unsigned long long* stats,
+                         hipStream_t s) {
     if (n == 0) return;
+#define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, pool_bytes, d_img, coef, status, nmcu_ok, defer_list, defer_count, stats, s
     switch (lanes_per_frame) {
-        case 64: launch_sync<64>(ws, ws_bytes, n, g, cap_words, d_img, coef, status, nmcu_ok, stats, s); break;
-        case 32: launch_sync<32>(ws, ws_bytes, n, g, cap_words, d_img, coef, status, nmcu_ok, stats, s); break;
-        case 8: launch_sync<8>(ws, ws_bytes, n, g, cap_words, d_img, coef, status, nmcu_ok, stats, s); break;
-        default: launch_sync<16>(ws, ws_bytes, n, g, cap_words, d_img, coef, status, nmcu_ok, stats, s); break;
+        case 64: launch_sync<64>(AMV_SYNC_ARGS); break;
+        case 32: launch_sync<32>(AMV_SYNC_ARGS); break;
+        case 8: launch_sync<8>(AMV_SYNC_ARGS); break;
+        default: launch_sync<16>(AMV_SYNC_ARGS); break;
     }
+#undef AMV_SYNC_ARGS
 }
 
 }  // namespace amv

@@ -23,10 +23,18 @@ void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
                     uint32_t cap_words, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
                     hipStream_t s);
-void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const FrameGeom& g, uint32_t cap_words,
-                         int lanes_per_frame, const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
-                         uint32_t* nmcu_ok, unsigned long long* stats, hipStream_t s);
-bool huffman_sync_fits(const FrameGeom& g, int lanes_per_frame);
+struct SyncPlan {
+    int lanes;             // lanes per frame of the first pass, 0 = serial kernel only
+    uint32_t pool;         // LDS stream pool of the first pass (bytes)
+    uint32_t pool_single;  // pool that holds any one frame (second pass, one frame per wave)
+};
+SyncPlan huffman_sync_plan(const FrameGeom& g, uint32_t cap_words, int wanted);
+// list/list_count: optional frame list (second pass); defer_list/defer_count: frames that did not fit the pool
+void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
+                         const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
+                         uint32_t pool_bytes, const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
+                         uint32_t* nmcu_ok, uint32_t* defer_list, uint32_t* defer_count, unsigned long long* stats,
+                         hipStream_t s);
 // dequantise + IDCT + YCbCr->BGR + flipped store: one wave per MCU-row segment
 void launch_reconstruct(const int16_t* coef, const uint32_t* nmcu_ok, uint32_t n,
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s);

@@ -89,14 +89,17 @@ static constexpr int16_t kSinQ14[65] = {
 static constexpr int kLut1Bits = 9;
 static constexpr int kLut2Bits = 7;
 static constexpr int kLut2Pages = 16;
-// The "skip" copies serve walks that only need to know where the next symbol starts: bits 0-4
-// code length + magnitude bits, bits 8-14 how far the coefficient index moves (run + 1; 64 for
-// end-of-block; 1 for a DC symbol), bit 15 "go to level 2" with the page in bits 0-7.
+// m1/m2 are the same codes in the form the synchronising kernel wants (amv_decode_sync.hip):
+// bits 0-4 code length + magnitude bits (0 = no such code), bits 5-10 how far the coefficient index
+// moves (run + 1; 1 for a DC symbol; 63 for end-of-block), bits 11-14 magnitude bits, m1 bit 15 "the
+// code is longer than 9 bits".  Long codes occupy the top prefixes of every table (at most the
+// last 5), so m2 gives each table 5 pages: page = prefix - 507.
+static constexpr int kLut2PagesPerTable = 5;
 struct HuffDecodeImage {
     uint16_t l1[4][1 << kLut1Bits];
     uint16_t l2[kLut2Pages][1 << kLut2Bits];
-    uint16_t s1[4][1 << kLut1Bits];
-    uint16_t s2[kLut2Pages][1 << kLut2Bits];
+    uint16_t m1[4][1 << kLut1Bits];
+    uint16_t m2[4][kLut2PagesPerTable][1 << kLut2Bits];
 };
 
 // Encoder code book: for symbol s of table t, code | (length << 16)

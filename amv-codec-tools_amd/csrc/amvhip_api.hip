@@ -40,7 +40,7 @@ struct amvhip_ctx {
     HuffEncodeImage* d_enc = nullptr;
     // workspace
     DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes;
-    int sync_lanes = 16;
+    int sync_lanes = 8;   // minimum lanes per frame; the launch picks the smallest count whose LDS fits
     bool want_stats = false;
     int entropy_mode = AMVHIP_ENTROPY_AUTO;
     // host-pointer staging
@@ -123,22 +123,22 @@ void build_images(HuffDecodeImage& dec, HuffEncodeImage& enc) {
         }
     }
     if (pages > kLut2Pages) abort();  // static property of the K.3 tables (11 pages)
-    // skip copies
-    int page_table[kLut2Pages];
-    for (int t = 0; t < 4; ++t)
-        for (int i = 0; i < (1 << kLut1Bits); ++i)
-            if (dec.l1[t][i] & 0x8000u) page_table[dec.l1[t][i] & 0xffu] = t;
-    auto skip = [](uint16_t e, int t) -> uint16_t {
-        const uint32_t len = (e >> 8) & 31u, sym = e & 0xffu;
+    // the synchronising kernel's form of the same tables
+    auto merged = [](uint16_t e, int t) -> uint16_t {
+        const uint32_t len = (e >> 8) & 31u, sym = e & 0xffu, size = sym & 15u;
         if (len == 0) return 0;
-        const uint32_t adv = t < 2 ? 1u : (sym == 0 ? 64u : (sym >> 4) + 1u);
-        return (uint16_t)((len + (sym & 15u)) | (adv << 8));
+        const uint32_t adv = t < 2 ? 1u : (sym == 0 ? 63u : (sym >> 4) + 1u);
+        return (uint16_t)((len + size) | (adv << 5) | (size << 11));
     };
+    const int first = (1 << kLut1Bits) - kLut2PagesPerTable;
     for (int t = 0; t < 4; ++t)
-        for (int i = 0; i < (1 << kLut1Bits); ++i)
-            dec.s1[t][i] = (dec.l1[t][i] & 0x8000u) ? dec.l1[t][i] : skip(dec.l1[t][i], t);
-    for (int pg = 0; pg < pages; ++pg)
-        for (int i = 0; i < (1 << kLut2Bits); ++i) dec.s2[pg][i] = skip(dec.l2[pg][i], page_table[pg]);
+        for (int i = 0; i < (1 << kLut1Bits); ++i) {
+            const uint16_t e = dec.l1[t][i];
+            if (!(e & 0x8000u)) { dec.m1[t][i] = merged(e, t); continue; }
+            if (i < first) abort();   // static property of the K.3 tables: long codes live in the last 5 prefixes
+            dec.m1[t][i] = 0x8000u;
+            for (int j = 0; j < (1 << kLut2Bits); ++j) dec.m2[t][i - first][j] = merged(dec.l2[e & 0xffu][j], t);
+        }
 }
 
 // ---- timing ---------------------------------------------------------------------------------
@@ -261,22 +261,27 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     if (n == 0) return AMVHIP_OK;
     const FrameGeom g = make_geom(w, h);
     hipStream_t st = (hipStream_t)stream;
-    // workspace window per frame for the unstuffed scan: ~4x the 0.2 B/pixel AMV streams run at
-    uint32_t cap_bytes = ((w * h * 3u / 4u) + 255u) & ~255u;
-    if (cap_bytes < 4096u) cap_bytes = 4096u;
+    // window per frame for the unstuffed scan (global workspace and LDS): ~1.6x the 0.2 B/pixel AMV
+    // streams run at; larger chunks take the serial kernel
+    uint32_t cap_bytes = ((w * h * 5u / 16u) + 1023u) & ~1023u;
+    if (cap_bytes < 2048u) cap_bytes = 2048u;
     const uint32_t cap_words = cap_bytes / 4u;
-    const bool sync_ok = c->entropy_mode != AMVHIP_ENTROPY_SERIAL && huffman_sync_fits(g, c->sync_lanes);
+    SyncPlan plan{0, 0u, 0u};
+    if (c->entropy_mode != AMVHIP_ENTROPY_SERIAL) plan = huffman_sync_plan(g, cap_words, c->sync_lanes);
+    const bool sync_ok = plan.lanes != 0;
     if (!sync_ok) {
         Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
         launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, nullptr, nullptr, st);
         return check_launch(c, "huffman");
     }
-    if (int r = ensure(c, c->retry, ((size_t)n + 4) * 4)) return r;
+    if (int r = ensure(c, c->retry, ((size_t)n + 4) * 8)) return r;   // [retry count x4 | defer count x4 | retry list n | defer list n]
     if (int r = ensure(c, c->ws, (size_t)n * cap_bytes)) return r;
     if (int r = ensure(c, c->ws_bytes, (size_t)n * 4)) return r;
     uint32_t* retry_count = (uint32_t*)c->retry.p;
-    uint32_t* retry_list = retry_count + 4;
-    HIP_TRY(c, hipMemsetAsync(retry_count, 0, 16, st));
+    uint32_t* defer_count = retry_count + 4;
+    uint32_t* retry_list = retry_count + 8;
+    uint32_t* defer_list = retry_list + n;
+    HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, st));
     {
         Timed t(c, AMVHIP_K_UNSTUFF, st);
         launch_unstuff(d_blob, blob_bytes, d_offs, d_lens, n, cap_words, (uint32_t*)c->ws.p, (uint32_t*)c->ws_bytes.p,
@@ -285,9 +290,14 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     if (int r = check_launch(c, "unstuff")) return r;
     {
         Timed t(c, AMVHIP_K_HUFFMAN, st);
-        launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, g, cap_words, c->sync_lanes,
-                            c->d_dec, d_coef, d_status, d_nmcu_ok,
-                            c->want_stats ? (unsigned long long*)c->stats.p : nullptr, st);
+        unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
+        launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, cap_words,
+                            plan.lanes, plan.pool, c->d_dec, d_coef, d_status, d_nmcu_ok, defer_list, defer_count,
+                            stats, st);
+        if (plan.lanes != 64)   // frames that found their wave's pool full: one frame per wave (usually none)
+            launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, defer_list, defer_count, g,
+                                cap_words, 64, plan.pool_single, c->d_dec, d_coef, d_status, d_nmcu_ok, defer_list,
+                                defer_count, stats, st);
     }
     if (int r = check_launch(c, "huffman_sync")) return r;
     {   // frames handed back (oversize chunks, long FF runs): usually none, the kernel exits at once
