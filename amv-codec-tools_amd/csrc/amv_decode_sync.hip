@@ -187,8 +187,10 @@ __device__ __forceinline__ uint32_t table_of(uint32_t k, uint32_t k6) {
 // Speculative walk from `s` while s.p < limit: where symbols start and how the block position
 // moves, nothing else.  Returns the number of blocks finished.
 __device__ __forceinline__ uint32_t walk_skip(const Window& w, const uint16_t* __restrict__ m1,
-                                              const uint16_t* __restrict__ m2, State& s, uint32_t limit) {
-    uint32_t p = s.p, k = s.k, k6 = s.k6, nblk = 0;
+                                              const uint16_t* __restrict__ m2, State& s, uint32_t limit,
+                                              uint32_t& nrec_out) {
+    uint32_t p = s.p, k = s.k, k6 = s.k6, nblk = 0, nrec = 0;
+    nrec_out = 0u;
     if (p >= limit) return 0u;
     uint32_t widx = p >> 5;
     const uint32_t bo = p & 31u;
@@ -203,6 +205,7 @@ __device__ __forceinline__ uint32_t walk_skip(const Window& w, const uint16_t* _
         const uint32_t e = lookup(m1, m2, tab, (uint32_t)(acc >> 32));
         const uint32_t used = max(e & 31u, 1u);        // nonsense under a guessed start: slip one bit
         const uint32_t kn = k + ((e >> 5) & 63u);
+        nrec += (k != 0u && (e & 0x7800u) != 0u) ? 1u : 0u;   // an AC symbol that carries a value
         acc <<= used;
         nb -= (int)used;
         p += used;
@@ -218,6 +221,7 @@ __device__ __forceinline__ uint32_t walk_skip(const Window& w, const uint16_t* _
         tab = table_of(k, k6);
     } while (p < limit);
     s.p = p; s.k = k; s.k6 = k6;
+    nrec_out = nrec;
     return nblk;
 }
 
@@ -229,14 +233,28 @@ struct WriteResult {
     uint32_t dc_first;   // first block whose DC symbol this lane decoded, and how many follow
     uint32_t dc_count;
     int sum[3];          // the lane's DC differences added up per component (Y, Cb, Cr)
+    uint32_t recpos;     // records mode: next free record when the walk ended
+    int last_dc;         // last block whose DC symbol is decoded (by this lane or one to its left)
+};
+
+// Where the strict pass puts its output.  Dense: the frame's coefficient lines (zeroed before).
+// Records: one 32-bit word per non-zero AC coefficient, in stream order -- bits 0-5 index in block,
+// bits 6-19 block, bits 20-31 value -- plus a DC array and the record index at which every MCU starts.
+struct Sink {
+    int16_t* coef;        // dense
+    uint32_t* rec;        // records
+    int16_t* dcv;
+    uint32_t* mcu_start;
 };
 
 // The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state.
+template <bool kRec>
 __device__ __forceinline__ WriteResult walk_write(const Window& w, const uint16_t* __restrict__ m1,
                                                   const uint16_t* __restrict__ m2, State s, uint32_t limit,
-                                                  uint32_t blk, uint32_t blocks_per_frame,
-                                                  int16_t* __restrict__ coef) {
-    WriteResult r{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}};
+                                                  uint32_t blk, uint32_t blocks_per_frame, const Sink& out,
+                                                  uint32_t recpos, uint32_t rec_cap) {
+    WriteResult r{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, recpos, (int)blk - (s.k ? 0 : 1)};
+    int16_t* __restrict__ coef = out.coef;
     uint32_t p = s.p, k = s.k, k6 = s.k6;
     uint32_t widx = p >> 5;
     const uint32_t bo = p & 31u;
@@ -244,72 +262,108 @@ __device__ __forceinline__ WriteResult walk_write(const Window& w, const uint16_
     int nb = 64 - (int)bo;
     widx += 2u;
     uint32_t nextw = word_at(w, widx);
+    ++widx;
     r.dc_first = blk + (k ? 1u : 0u);
-    while (p < limit) {
+    int s0 = 0, s1 = 0, s2 = 0;
+    bool alive = true;
+    // one symbol per step; everything but the two stores is straight-line selects, so that lanes in
+    // different states (DC / AC / end of block) share every instruction
+    while (alive && p < limit) {
+        const uint32_t cand = word_at(w, widx);
         const uint32_t v = (uint32_t)(acc >> 32);
         const uint32_t e = lookup(m1, m2, table_of(k, k6), v);
-        const uint32_t used = e & 31u;
-        if (used == 0u) {                        // no code matches: FUNC_FORMAT_ERROR, AmvJpeg.c:887
-            r.err = kStFormat; r.err_blk = blk; r.stop_p = p + 17u;
-            break;
-        }
-        const uint32_t size = (e >> 11) & 15u, adv = (e >> 5) & 63u;
-        int val = 0;
-        if (size) {
-            const uint32_t mag = (v << (used - size)) >> (32u - size);
-            val = (int)mag;
-            if (mag < (1u << (size - 1u))) val -= (1 << size) - 1;   // :924-933
-        }
-        acc <<= used;
-        nb -= (int)used;
-        p += used;
-        if (nb <= 32) {
-            acc |= (uint64_t)nextw << (32 - nb);
-            nb += 32;
-            ++widx;
-            nextw = word_at(w, widx);
-        }
-        bool block_end = false;
-        if (k == 0u) {                           // DC difference (:945-951), summed per component (:1200-1221)
-            const int c = k6 < 4u ? 0 : (int)k6 - 3;
-            const int t = (c == 0 ? r.sum[0] : (c == 1 ? r.sum[1] : r.sum[2])) + val;
-            if (c == 0) r.sum[0] = t; else if (c == 1) r.sum[1] = t; else r.sum[2] = t;
-            coef[(uint64_t)blk * 64u] = (int16_t)t;   // relative to this lane's start; pass 5 adds the base
-            ++r.dc_count;
-            k = 1u;
-        } else if (adv == 63u) {                 // end of block (:959-964)
-            block_end = true;
-        } else {
-            k += adv - 1u;
-            if (k > 63u) {                       // the reference writes out of bounds here (:967-969)
-                r.err = kStOverrun; r.err_blk = blk; r.stop_p = p;
-                break;
+        const uint32_t used = e & 31u, size = (e >> 11) & 15u, adv = (e >> 5) & 63u;
+        const bool bad = used == 0u;                         // no code matches: FUNC_FORMAT_ERROR, AmvJpeg.c:887
+        const bool isdc = k == 0u;
+        const bool iseob = !isdc && adv == 63u;              // end of block (:959-964)
+        const uint32_t idx = k + adv - 1u;                   // AC: where the coefficient goes
+        const bool over = !bad && !isdc && !iseob && idx > 63u;   // the reference writes out of bounds here (:967-969)
+        // magnitude bits -> value (:924-933); size 0 gives 0
+        const uint32_t mag = ((v << (used - size)) >> 1) >> (31u - size);
+        const uint32_t half = (1u << size) >> 1;
+        const int val = (int)mag - (mag < half ? (int)((1u << size) - 1u) : 0);
+        // consume (a code that matches nothing consumes nothing; the reference has read 17 bits by then)
+        const uint32_t eat = bad ? 0u : used;
+        acc <<= eat;
+        nb -= (int)eat;
+        p += eat;
+        const bool need = nb <= 32;
+        acc |= need ? (uint64_t)nextw << (need ? 32 - nb : 0) : 0ull;
+        nb += need ? 32 : 0;
+        nextw = need ? cand : nextw;
+        widx += need ? 1u : 0u;
+        const bool good = !bad && !over;
+        if (isdc && good) {                                  // DC difference (:945-951), summed per component (:1200-1221)
+            const int t = (k6 < 4u ? s0 : (k6 == 4u ? s1 : s2)) + val;
+            s0 = k6 < 4u ? t : s0;
+            s1 = k6 == 4u ? t : s1;
+            s2 = k6 == 5u ? t : s2;
+            // relative to this lane's start; pass 5 adds the base
+            if (kRec) {
+                out.dcv[blk] = (int16_t)t;
+                if (k6 == 0u) out.mcu_start[blk / 6u] = r.recpos;
+            } else {
+                coef[(uint64_t)blk * 64u] = (int16_t)t;
             }
-            if (size) coef[(uint64_t)blk * 64u + k] = (int16_t)val;
-            block_end = ++k == 64u;
+            ++r.dc_count;
+            r.last_dc = (int)blk;
         }
-        if (block_end) {
-            k = 0u;
-            k6 = k6 == 5u ? 0u : k6 + 1u;
-            if (++blk == blocks_per_frame) { r.done = true; r.stop_p = p; break; }
+        const bool emit = good && !isdc && !iseob && size != 0u;
+        if (emit) {
+            if (kRec) {   // never past the frame's record space; an overfull frame is redone densely
+                if (r.recpos < rec_cap) out.rec[r.recpos] = idx | (blk << 6) | ((uint32_t)val << 20);
+            } else {
+                coef[(uint64_t)blk * 64u + idx] = (int16_t)val;
+            }
+        }
+        r.recpos += (kRec && emit) ? 1u : 0u;
+        const uint32_t newk = isdc ? 1u : idx + 1u;
+        const bool block_end = good && (iseob || (!isdc && newk == 64u));
+        k = good ? (block_end ? 0u : newk) : k;
+        k6 = block_end ? (k6 == 5u ? 0u : k6 + 1u) : k6;
+        blk += block_end ? 1u : 0u;
+        const bool finished = block_end && blk == blocks_per_frame;
+        if (bad || over || finished) {
+            r.err = bad ? kStFormat : (over ? kStOverrun : 0u);
+            r.err_blk = blk;
+            r.stop_p = bad ? p + 17u : p;
+            r.done = finished;
+            alive = false;
         }
     }
+    r.sum[0] = s0; r.sum[1] = s1; r.sum[2] = s2;
     return r;
 }
 
 }  // namespace
 
+// Outputs of the records form (SyncOut::rec != nullptr), all per frame: rec[cap_rec] records,
+// dcv[blocks] predicted DC values, mcu_start[mcus + 1] record index at which each MCU starts (entries
+// of MCUs the decoder never reached hold the total), rec_count = total, or ~0 when the frame was
+// handed to the serial kernel, whose output is dense coefficient lines.
+struct SyncOut {
+    int16_t* coef;
+    uint32_t* rec;
+    uint32_t cap_rec;
+    int16_t* dcv;
+    uint32_t* mcu_start;
+    uint32_t mcus;
+    uint32_t* rec_count;
+    uint32_t* retry_list;    // frames for amv_huffman_kernel
+    uint32_t* retry_count;
+};
+
 // dynamic LDS: [ m1 4 KB | m2 5 KB | per wave: pool of pool_bytes with the frames' stream words ]
 // With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).  Frames
 // whose words do not fit what is left of their wave's pool are appended to defer_list.
-template <int L>
+template <int L, bool kRec>
 __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
     uint32_t blocks_per_frame, uint32_t cap_words, uint32_t pool_bytes,
-    const HuffDecodeImage* __restrict__ img, int16_t* __restrict__ coef, int32_t* __restrict__ status,
+    const HuffDecodeImage* __restrict__ img, SyncOut out, int32_t* __restrict__ status,
     uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
-    unsigned long long* __restrict__ stats) {
+    uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
     constexpr int kFrames = kWave / L;   // frames per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const uint16_t* m1 = reinterpret_cast<const uint16_t*>(s_mem);
@@ -324,8 +378,16 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
     }
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
     if (list) n = *list_count;
-    const uint32_t task = blockIdx.x * kWaves + wave;
-    if (task * kFrames >= n) return;
+    const uint32_t ntasks = (n + kFrames - 1) / kFrames;
+    // Tasks (kFrames frames each) are handed out through a counter: a wave that finishes early -- the
+    // number of synchronisation rounds varies a lot between frames -- takes the next one instead of
+    // idling until the slowest wave of the grid is done.  Every wave leaves once the counter passes ntasks.
+    for (;;) {
+    uint32_t task = 0;
+    if (lane == 0) task = atomicAdd(queue, 1u);
+    task = __shfl(task, 0);
+    if (task >= ntasks) return;
+    wave_sync();   // the previous task's LDS reads are done before its pool is refilled
 
     const bool timing = stats != nullptr && lane == 0;   // optional phase clock (amvhip_entropy_stats)
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
@@ -334,10 +396,11 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
     const uint32_t idx = task * kFrames + slot;
     const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
     uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+    if (kRec && frame != kNever && total == kNever && sub == 0) out.rec_count[frame] = kNever;
     uint8_t* pool = s_mem + kTableBytes + wave * pool_bytes;
 
     // ---- 0. stream words -> LDS, frames packed back to back (16-byte pieces, every lane helps with
-    // every frame), one zero piece behind each for clamped reads; coefficient lines zeroed
+    // every frame), one zero piece behind each for clamped reads; dense form: coefficient lines zeroed
     uint32_t my_off = 0, used_pool = 0;
 #pragma unroll
     for (int f = 0; f < kFrames; ++f) {
@@ -358,12 +421,17 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
         if (slot == (uint32_t)f) my_off = used_pool;
         used_pool += need;
     }
-    const bool live = total != kNever;
+    bool live = total != kNever;
+    const uint32_t fsafe = live ? frame : 0u;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(pool + my_off);
-    int16_t* fcoef = coef + (uint64_t)(live ? frame : 0) * blocks_per_frame * 64u;
+    Sink sink;
+    sink.coef = kRec ? nullptr : out.coef + (uint64_t)fsafe * blocks_per_frame * 64u;
+    sink.rec = kRec ? out.rec + (uint64_t)fsafe * out.cap_rec : nullptr;
+    sink.dcv = kRec ? out.dcv + (uint64_t)fsafe * blocks_per_frame : nullptr;
+    sink.mcu_start = kRec ? out.mcu_start + (uint64_t)fsafe * (out.mcus + 1u) : nullptr;
     const uint32_t valid_bits = live ? total * 8u : 0u;
-    if (live) {
-        uint4* z = reinterpret_cast<uint4*>(fcoef);
+    if (!kRec && live) {
+        uint4* z = reinterpret_cast<uint4*>(sink.coef);
         for (uint32_t i = sub; i < blocks_per_frame * 8u; i += L) z[i] = make_uint4(0, 0, 0, 0);
     }
     wave_sync();   // LDS fills are ordered before the walks; the zeroing stores stay in flight
@@ -376,7 +444,8 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
     const uint32_t limit = (!live || sub == L - 1) ? 0u : (sub + 1u) * S;
     State entry{sub * S, 0u, 0u}, arrive = entry;
     if (timing) tc[1] = clock64();
-    uint32_t my_blocks = walk_skip(win, m1, m2, arrive, limit);
+    uint32_t my_recs;
+    uint32_t my_blocks = walk_skip(win, m1, m2, arrive, limit, my_recs);
     if (timing) tc[2] = clock64();
     uint32_t rounds = 0;
     const uint64_t seg = L == 64 ? ~0ull : (((1ull << (L & 63)) - 1ull) << (slot * L));
@@ -392,29 +461,34 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
         if (changed) {
             entry = left;
             arrive = left;
-            my_blocks = walk_skip(win, m1, m2, arrive, limit);
+            my_blocks = walk_skip(win, m1, m2, arrive, limit, my_recs);
         }
     }
     if (timing) tc[3] = clock64();
 
-    // ---- 3. first block of every lane
-    uint32_t all_blocks;
+    // ---- 3. first block (and first record) of every lane
+    uint32_t all_blocks, all_recs = 0;
     const uint32_t blk0 = seg_excl_sum<L>(my_blocks, sub, all_blocks);
+    uint32_t rec0 = 0;
+    if (kRec) rec0 = seg_excl_sum<L>(my_recs, sub, all_recs);   // (the last lane has not walked: its count is 0, it is last)
 
     // ---- 4. the strict, writing pass.  Lanes left of the frame's end (or first error) are exact;
     // whatever a lane to the right of it does is ignored below.
-    __builtin_amdgcn_s_waitcnt(0);   // the zeroing stores have landed before the sparse ones go out
-    WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}};
+    __builtin_amdgcn_s_waitcnt(0);   // dense form: the zeroing stores have landed before the sparse ones go out
+    WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, 0u, -1};
     if (live && blk0 < blocks_per_frame)
-        wr = walk_write(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, fcoef);
+        wr = walk_write<kRec>(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, sink, rec0, out.cap_rec);
     if (timing) tc[4] = clock64();
     const uint64_t stop_mask = __ballot(wr.done || wr.err != 0u) & seg;
-    uint32_t st = 0, good_blocks = blocks_per_frame;
+    uint32_t st = 0, good_blocks = blocks_per_frame, rec_total = 0;
+    int last_dc = -1;
     if (stop_mask) {
         const int stop_lane = __builtin_ctzll(stop_mask);   // leftmost = the true path
         const uint32_t e = __shfl(wr.err, stop_lane);
         const uint32_t eb = __shfl(wr.err_blk, stop_lane);
         const uint32_t sp = __shfl(wr.stop_p, stop_lane);
+        rec_total = __shfl(wr.recpos, stop_lane);
+        last_dc = __shfl(wr.last_dc, stop_lane);
         st = e;
         if (e) good_blocks = eb;
         if (sp > valid_bits) st |= kStTruncated;
@@ -432,8 +506,12 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
     for (uint32_t j = 0; j < wr.dc_count; ++j) {
         const uint32_t b = wr.dc_first + j, c6 = b % 6u;
         const int base = c6 < 4u ? by : (c6 == 4u ? bu : bv);
-        int16_t* q = fcoef + (uint64_t)b * 64u;
+        int16_t* q = kRec ? sink.dcv + b : sink.coef + (uint64_t)b * 64u;
         *q = (int16_t)(*q + base);
+    }
+    if (kRec && live) {   // MCUs the decoder never started begin (and end) at the total
+        const uint32_t started = last_dc < 0 ? 0u : (uint32_t)last_dc / 6u + 1u;
+        for (uint32_t m = started + sub; m <= out.mcus; m += L) sink.mcu_start[m] = rec_total;
     }
     if (timing) {
         tc[5] = clock64();
@@ -446,28 +524,40 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
             atomicAdd(&stats[1], (unsigned long long)rounds);
             atomicMax(&stats[2], (unsigned long long)rounds);
         }
-        status[frame] = (int32_t)st;
-        nmcu_ok[frame] = good_blocks / 6u;
+        if (kRec && rec_total > out.cap_rec) {   // more non-zero coefficients than the record space holds
+            out.rec_count[frame] = kNever;
+            out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
+        } else {
+            status[frame] = (int32_t)st;
+            nmcu_ok[frame] = good_blocks / 6u;
+            if (kRec) out.rec_count[frame] = rec_total;
+        }
     }
+    }   // next task
 }
 
 namespace {
 
-template <int L>
+template <int L, bool kRec>
 void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
                  const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, uint32_t pool_bytes,
-                 const HuffDecodeImage* d_img, int16_t* coef, int32_t* status, uint32_t* nmcu_ok,
-                 uint32_t* defer_list, uint32_t* defer_count, unsigned long long* stats, hipStream_t s) {
+                 const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
+                 uint32_t* defer_list, uint32_t* defer_count, uint32_t* queue, unsigned long long* stats, hipStream_t s) {
     constexpr uint32_t kPerGroup = (uint32_t)(kWave / L) * kWaves;
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L, kRec>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
-    hipLaunchKernelGGL(amv_huffman_sync_kernel<L>, dim3((n + kPerGroup - 1) / kPerGroup), dim3(kWave * kWaves),
-                       kTableBytes + kWaves * pool_bytes, s, ws, ws_bytes, n, list, list_count, g.blocks, cap_words,
-                       pool_bytes, d_img, coef, status, nmcu_ok, defer_list, defer_count, stats);
+    // enough workgroups to fill the chip (LDS allows a few per CU), never more than there are tasks
+    const uint32_t lds = kTableBytes + kWaves * pool_bytes;
+    uint32_t grid = (n + kPerGroup - 1) / kPerGroup;
+    const uint32_t resident = 256u * (160u * 1024u / lds > 0 ? 160u * 1024u / lds : 1u);
+    if (grid > resident) grid = resident;
+    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * kWaves), lds, s, ws, ws_bytes, n, list,
+                       list_count, g.blocks, cap_words, pool_bytes, d_img, out, status, nmcu_ok, defer_list, defer_count,
+                       queue, stats);
 }
 
 }  // namespace
@@ -510,16 +600,26 @@ void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
 
 void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
                          const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
-                         uint32_t pool_bytes, const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
-                         uint32_t* nmcu_ok, uint32_t* defer_list, uint32_t* defer_count, unsigned long long* stats,
-                         hipStream_t s) {
+                         uint32_t pool_bytes, const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status,
+                         uint32_t* nmcu_ok, uint32_t* defer_list, uint32_t* defer_count, uint32_t* queue,
+                         unsigned long long* stats, hipStream_t s) {
     if (n == 0) return;
-#define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, pool_bytes, d_img, coef, status, nmcu_ok, defer_list, defer_count, stats, s
-    switch (lanes_per_frame) {
-        case 64: launch_sync<64>(AMV_SYNC_ARGS); break;
-        case 32: launch_sync<32>(AMV_SYNC_ARGS); break;
-        case 8: launch_sync<8>(AMV_SYNC_ARGS); break;
-        default: launch_sync<16>(AMV_SYNC_ARGS); break;
+    SyncOut out{sinks.coef, sinks.rec, sinks.cap_rec, sinks.dcv, sinks.mcu_start, g.mcus, sinks.rec_count, sinks.retry_list, sinks.retry_count};
+#define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, pool_bytes, d_img, out, status, nmcu_ok, defer_list, defer_count, queue, stats, s
+    if (sinks.rec) {
+        switch (lanes_per_frame) {
+            case 64: launch_sync<64, true>(AMV_SYNC_ARGS); break;
+            case 32: launch_sync<32, true>(AMV_SYNC_ARGS); break;
+            case 8: launch_sync<8, true>(AMV_SYNC_ARGS); break;
+            default: launch_sync<16, true>(AMV_SYNC_ARGS); break;
+        }
+    } else {
+        switch (lanes_per_frame) {
+            case 64: launch_sync<64, false>(AMV_SYNC_ARGS); break;
+            case 32: launch_sync<32, false>(AMV_SYNC_ARGS); break;
+            case 8: launch_sync<8, false>(AMV_SYNC_ARGS); break;
+            default: launch_sync<16, false>(AMV_SYNC_ARGS); break;
+        }
     }
 #undef AMV_SYNC_ARGS
 }

@@ -29,14 +29,30 @@ struct SyncPlan {
     uint32_t pool_single;  // pool that holds any one frame (second pass, one frame per wave)
 };
 SyncPlan huffman_sync_plan(const FrameGeom& g, uint32_t cap_words, int wanted);
+// Where the entropy stage puts its result.  rec == nullptr: dense coefficient lines in coef
+// ([n][blocks][64] int16).  Otherwise the records form, per frame: rec[cap_rec] (one word per
+// non-zero AC coefficient: bits 0-5 index in block, 6-19 block, 20-31 value), dcv[blocks] predicted
+// DC values, mcu_start[mcus + 1] first record of each MCU, rec_count (total, or ~0 = this frame is in
+// dense form in coef because it went through amv_huffman_kernel).
+struct SyncSinks {
+    int16_t* coef;
+    uint32_t* rec;
+    uint32_t cap_rec;
+    int16_t* dcv;
+    uint32_t* mcu_start;
+    uint32_t* rec_count;
+    uint32_t* retry_list;
+    uint32_t* retry_count;
+};
 // list/list_count: optional frame list (second pass); defer_list/defer_count: frames that did not fit the pool
 void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
                          const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
-                         uint32_t pool_bytes, const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
-                         uint32_t* nmcu_ok, uint32_t* defer_list, uint32_t* defer_count, unsigned long long* stats,
-                         hipStream_t s);
+                         uint32_t pool_bytes, const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status,
+                         uint32_t* nmcu_ok, uint32_t* defer_list, uint32_t* defer_count, uint32_t* queue,
+                         unsigned long long* stats, hipStream_t s);   // *queue: a zeroed task counter per launch
 // dequantise + IDCT + YCbCr->BGR + flipped store: one wave per MCU-row segment
-void launch_reconstruct(const int16_t* coef, const uint32_t* nmcu_ok, uint32_t n,
+// sinks.rec == nullptr: every frame is dense in sinks.coef; otherwise per frame as rec_count says
+void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n,
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s);
 
 // ---- encode -------------------------------------------------------------------------------

@@ -2,7 +2,10 @@
 // bottom-up store (IQtIZzBlock / Fast_IDCT / GetYUV / StoreBuffer, AmvJpeg.c:1010-1059, 754-840).
 //
 // One wave per MCU-row segment (<= 10 MCUs = 60 blocks = 160 pixels of 16 rows):
-//   A. lane b loads block b's 64 coefficients (one 128-byte line) straight into registers;
+//   A. lane b loads block b's 64 coefficients into registers: from its dense 128-byte line, or --
+//      records form -- after the wave has scattered the segment's (block, index, value) records and
+//      DC values into a zeroed LDS image of the 60 blocks (16-byte granules XOR-swizzled by block so
+//      that the per-lane 128-byte reads do not collide on banks);
 //   B. the whole 8x8 block stays in that lane's registers: de-zig-zag is register renaming (plus
 //      one select for amvlib's [3][4] table entry), dequantisation one multiply per coefficient,
 //      then 8 row transforms and 8 column transforms with the reference's exact integer
@@ -82,8 +85,9 @@ __device__ __forceinline__ int coef_at(const uint32_t (&c)[32], int i) {
 
 template <bool kVec16>
 __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
-    const int16_t* __restrict__ coef, const uint32_t* __restrict__ nmcu_ok, uint32_t n,
+    SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n,
     FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
+    const int16_t* __restrict__ coef = in.coef;
     constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;   // int16 units
     constexpr uint32_t kPitchOut = kSegMcus * 48;                            // bytes per staged row
     __shared__ __attribute__((aligned(16))) int16_t s_y[16 * kPitchY];
@@ -101,17 +105,48 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
     const uint32_t nb = cnt * 6;
 
+    const uint32_t ok = nmcu_ok[f];
+    const uint32_t mcu0 = my * g.mcu_cols + m0;                       // first MCU of this segment
+    const bool records = in.rec != nullptr && in.rec_count[f] != 0xffffffffu;
+    if (records) {   // records -> dense image of the segment's blocks in LDS (s_out is free until phase D)
+        uint4* img16 = reinterpret_cast<uint4*>(s_out);
+        for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
+        const uint32_t* ms = in.mcu_start + (uint64_t)f * (g.mcus + 1u);
+        const uint32_t r0 = ms[mcu0], r1 = ms[mcu0 + cnt_ok];
+        const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec;
+        int16_t* img = reinterpret_cast<int16_t*>(s_out);
+        for (uint32_t r = r0 + lane; r < r1; r += kWave) {
+            const uint32_t w = rec[r];
+            const uint32_t b = ((w >> 6) & 0x3fffu) - mcu0 * 6u, k = w & 63u;
+            if (b < cnt_ok * 6u) img[b * 64u + ((((k >> 3) ^ b) & 7u) << 3) + (k & 7u)] = (int16_t)((int)w >> 20);
+        }
+        if (lane < cnt_ok * 6u)
+            img[lane * 64u + ((lane & 7u) << 3)] = in.dcv[(uint64_t)f * g.blocks + mcu0 * 6u + lane];   // k = 0: granule 0 ^ b
+        __syncthreads();
+    }
+
     // ---- A + B + C: one block per lane
     if (lane < nb) {
         const uint32_t m = lane / 6u, k6 = lane % 6u;
         const bool chroma = k6 >= 4u;
-        const uint4* src = reinterpret_cast<const uint4*>(
-            coef + (((uint64_t)f * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 6u + lane) * 64u);
         uint32_t c[32];
+        if (records) {
+            const uint4* src = reinterpret_cast<const uint4*>(s_out) + lane * 8u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint4 q = src[i];
-            c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+            for (int i = 0; i < 8; ++i) {
+                const uint4 q = src[(uint32_t)i ^ (lane & 7u)];
+                c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+            }
+        } else {
+            const uint4* src = reinterpret_cast<const uint4*>(
+                coef + (((uint64_t)f * g.mcus + mcu0) * 6u + lane) * 64u);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 q = src[i];
+                c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+            }
         }
         // IQtIZzBlock's gather (AmvJpeg.c:1035-1042): out[nat] = coef[scan(nat)] * step[scan(nat)]
         int v[64];
@@ -152,7 +187,6 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
 
     // ---- D: StoreBuffer (AmvJpeg.c:789-840) into the staged image.  Picture row my*16+i lands in
     // destination row H-1-(my*16+i) (:800): staged slot vr-1-i, so that slots ascend in memory.
-    const uint32_t ok = nmcu_ok[f];
     const uint32_t vr = min(16u, g.height - my * 16u);                 // rows of this MCU row inside the picture (:798)
     const uint32_t px = min(cnt * 16u, g.width - m0 * 16u);            // pixels of this segment inside it (:803)
     const uint32_t groups = cnt * 4u;
@@ -213,17 +247,17 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     }
 }
 
-void launch_reconstruct(const int16_t* coef, const uint32_t* nmcu_ok, uint32_t n,
+void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n,
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
     if (n == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
     const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
     const bool vec16 = (g.stride % 16u) == 0 && (g.frame_bytes % 16u) == 0 && ((uintptr_t)out % 16u) == 0;
     if (vec16)
-        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, dim3((uint32_t)grid), dim3(kWave), 0, s, coef, nmcu_ok, n, g,
+        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, dim3((uint32_t)grid), dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
                            nseg, flags, out);
     else
-        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, dim3((uint32_t)grid), dim3(kWave), 0, s, coef, nmcu_ok, n, g,
+        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, dim3((uint32_t)grid), dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
                            nseg, flags, out);
 }
 

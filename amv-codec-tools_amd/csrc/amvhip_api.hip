@@ -39,7 +39,8 @@ struct amvhip_ctx {
     HuffDecodeImage* d_dec = nullptr;
     HuffEncodeImage* d_enc = nullptr;
     // workspace
-    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes;
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, dcv, mcu_start, rec_count;
+    bool dense_intermediate = false;   // AMVHIP_DENSE=1: dense coefficient lines between the decode stages (experiments)
     int sync_lanes = 8;   // minimum lanes per frame; the launch picks the smallest count whose LDS fits
     bool want_stats = false;
     int entropy_mode = AMVHIP_ENTROPY_AUTO;
@@ -208,6 +209,7 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
     std::call_once(once, [] { build_images(dec, enc); });
     auto die = [&](int code) { amvhip_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
+    if (const char* e = getenv("AMVHIP_DENSE")) c->dense_intermediate = atoi(e) != 0;
     if (const char* e = getenv("AMVHIP_SYNC_LANES")) {   // tuning knob: lanes per frame of the entropy kernel
         const int v = atoi(e);
         if (v == 8 || v == 16 || v == 32 || v == 64) c->sync_lanes = v;
@@ -226,7 +228,7 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     drain(c);
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux})
+                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->dcv, &c->mcu_start, &c->rec_count, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -249,29 +251,21 @@ extern "C" uint32_t amvhip_encode_bound(uint32_t w, uint32_t h) {
 
 static int size_ok(uint32_t w, uint32_t h) { return w > 0 && h > 0 && w <= 16384 && h <= 16384; }
 
-extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
-                                         const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
-                                         uint32_t w, uint32_t h, int16_t* d_coef, int32_t* d_status,
-                                         uint32_t* d_nmcu_ok, void* stream) {
-    if (!c) return AMVHIP_ERR_ARG;
-    if (!size_ok(w, h) || (n && (!d_blob || !d_offs || !d_lens || !d_coef || !d_status || !d_nmcu_ok)))
-        return fail(c, AMVHIP_ERR_ARG, "huffman_decode: bad argument");
-    if (((uintptr_t)d_blob & 3u) || ((uintptr_t)d_coef & 15u)) return fail(c, AMVHIP_ERR_ARG, "huffman_decode: blob must be 4-byte, coef 16-byte aligned");
-    if (int r = use_device(c)) return r;
-    if (n == 0) return AMVHIP_OK;
-    const FrameGeom g = make_geom(w, h);
-    hipStream_t st = (hipStream_t)stream;
+// The entropy stage into `sinks` (dense when sinks.rec == nullptr, records otherwise).
+static int entropy_stage(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offs,
+                         const uint32_t* d_lens, uint32_t n, const FrameGeom& g, SyncSinks sinks, int32_t* d_status,
+                         uint32_t* d_nmcu_ok, hipStream_t st) {
     // window per frame for the unstuffed scan (global workspace and LDS): ~1.6x the 0.2 B/pixel AMV
     // streams run at; larger chunks take the serial kernel
-    uint32_t cap_bytes = ((w * h * 5u / 16u) + 1023u) & ~1023u;
+    uint32_t cap_bytes = ((g.width * g.height * 5u / 16u) + 1023u) & ~1023u;
     if (cap_bytes < 2048u) cap_bytes = 2048u;
     const uint32_t cap_words = cap_bytes / 4u;
     SyncPlan plan{0, 0u, 0u};
-    if (c->entropy_mode != AMVHIP_ENTROPY_SERIAL) plan = huffman_sync_plan(g, cap_words, c->sync_lanes);
-    const bool sync_ok = plan.lanes != 0;
-    if (!sync_ok) {
+    if (c->entropy_mode != AMVHIP_ENTROPY_SERIAL && g.blocks < 16384u) plan = huffman_sync_plan(g, cap_words, c->sync_lanes);
+    if (plan.lanes == 0) {
+        if (sinks.rec) HIP_TRY(c, hipMemsetAsync(sinks.rec_count, 0xff, (size_t)n * 4, st));   // every frame dense
         Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
-        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, nullptr, nullptr, st);
+        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, sinks.coef, d_status, d_nmcu_ok, nullptr, nullptr, st);
         return check_launch(c, "huffman");
     }
     if (int r = ensure(c, c->retry, ((size_t)n + 4) * 8)) return r;   // [retry count x4 | defer count x4 | retry list n | defer list n]
@@ -281,6 +275,8 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     uint32_t* defer_count = retry_count + 4;
     uint32_t* retry_list = retry_count + 8;
     uint32_t* defer_list = retry_list + n;
+    sinks.retry_list = retry_list;
+    sinks.retry_count = retry_count;
     HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, st));
     {
         Timed t(c, AMVHIP_K_UNSTUFF, st);
@@ -292,20 +288,46 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
         Timed t(c, AMVHIP_K_HUFFMAN, st);
         unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
         launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, cap_words,
-                            plan.lanes, plan.pool, c->d_dec, d_coef, d_status, d_nmcu_ok, defer_list, defer_count,
+                            plan.lanes, plan.pool, c->d_dec, sinks, d_status, d_nmcu_ok, defer_list, defer_count, retry_count + 1,
                             stats, st);
         if (plan.lanes != 64)   // frames that found their wave's pool full: one frame per wave (usually none)
             launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, defer_list, defer_count, g,
-                                cap_words, 64, plan.pool_single, c->d_dec, d_coef, d_status, d_nmcu_ok, defer_list,
-                                defer_count, stats, st);
+                                cap_words, 64, plan.pool_single, c->d_dec, sinks, d_status, d_nmcu_ok, defer_list,
+                                defer_count, retry_count + 2, stats, st);
     }
     if (int r = check_launch(c, "huffman_sync")) return r;
-    {   // frames handed back (oversize chunks, long FF runs): usually none, the kernel exits at once
+    {   // frames handed back (oversize chunks, long FF runs, too many coefficients): usually none, exits at once
         Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
-        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, retry_list,
+        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, sinks.coef, d_status, d_nmcu_ok, retry_list,
                        retry_count, st);
     }
     return check_launch(c, "huffman");
+}
+
+extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
+                                         const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
+                                         uint32_t w, uint32_t h, int16_t* d_coef, int32_t* d_status,
+                                         uint32_t* d_nmcu_ok, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (n && (!d_blob || !d_offs || !d_lens || !d_coef || !d_status || !d_nmcu_ok)))
+        return fail(c, AMVHIP_ERR_ARG, "huffman_decode: bad argument");
+    if (((uintptr_t)d_blob & 3u) || ((uintptr_t)d_coef & 15u)) return fail(c, AMVHIP_ERR_ARG, "huffman_decode: blob must be 4-byte, coef 16-byte aligned");
+    if (int r = use_device(c)) return r;
+    if (n == 0) return AMVHIP_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    SyncSinks sinks{d_coef, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return entropy_stage(c, d_blob, blob_bytes, d_offs, d_lens, n, make_geom(w, h), sinks, d_status, d_nmcu_ok, (hipStream_t)stream);
+}
+
+static int reconstruct_stage(amvhip_ctx* c, const SyncSinks& sinks, const uint32_t* d_nmcu_ok, uint32_t n,
+                             const FrameGeom& g, uint32_t flags, uint8_t* d_out, hipStream_t st) {
+    if (g.stride != g.width * 3)  // row padding bytes stay zero as in AMVDec.c:283
+        HIP_TRY(c, hipMemsetAsync(d_out, 0, g.frame_bytes * n, st));
+    {
+        Timed t(c, AMVHIP_K_RECON, st);
+        launch_reconstruct(sinks, d_nmcu_ok, n, g, flags, d_out, st);
+    }
+    return check_launch(c, "reconstruct");
 }
 
 extern "C" int amvhip_reconstruct_dev(amvhip_ctx* c, const int16_t* d_coef, const uint32_t* d_nmcu_ok,
@@ -315,14 +337,9 @@ extern "C" int amvhip_reconstruct_dev(amvhip_ctx* c, const int16_t* d_coef, cons
     if (!size_ok(w, h) || (n && (!d_coef || !d_nmcu_ok || !d_out))) return fail(c, AMVHIP_ERR_ARG, "reconstruct: bad argument");
     if (((uintptr_t)d_out & 3u) || ((uintptr_t)d_coef & 15u)) return fail(c, AMVHIP_ERR_ARG, "reconstruct: out must be 4-byte, coef 16-byte aligned");
     if (int r = use_device(c)) return r;
-    const FrameGeom g = make_geom(w, h);
-    if (g.stride != w * 3)  // row padding bytes stay zero as in AMVDec.c:283
-        HIP_TRY(c, hipMemsetAsync(d_out, 0, g.frame_bytes * n, (hipStream_t)stream));
-    {
-        Timed t(c, AMVHIP_K_RECON, (hipStream_t)stream);
-        launch_reconstruct(d_coef, d_nmcu_ok, n, g, flags, d_out, (hipStream_t)stream);
-    }
-    return check_launch(c, "reconstruct");
+    if (n == 0) return AMVHIP_OK;
+    SyncSinks sinks{const_cast<int16_t*>(d_coef), nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return reconstruct_stage(c, sinks, d_nmcu_ok, n, make_geom(w, h), flags, d_out, (hipStream_t)stream);
 }
 
 extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
@@ -332,16 +349,26 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     if (!c) return AMVHIP_ERR_ARG;
     if (!size_ok(w, h)) return fail(c, AMVHIP_ERR_ARG, "decode: bad size %ux%u", w, h);
     if (n == 0) return AMVHIP_OK;
+    if (!d_blob || !d_offs || !d_lens || !d_out || !d_status) return fail(c, AMVHIP_ERR_ARG, "decode: null argument");
+    if (((uintptr_t)d_blob & 3u) || ((uintptr_t)d_out & 3u)) return fail(c, AMVHIP_ERR_ARG, "decode: blob and out must be 4-byte aligned");
     if (int r = use_device(c)) return r;
     const FrameGeom g = make_geom(w, h);
     std::lock_guard<std::mutex> lk(c->mu);
+    // between the two stages coefficients travel as records (one word per non-zero AC coefficient) +
+    // DC values; the dense lines are only touched by frames that go through the serial kernel
+    const uint32_t cap_rec = g.blocks * 20u;
     if (int r = ensure(c, c->coef, (size_t)n * g.blocks * 128)) return r;
     if (int r = ensure(c, c->nmcu, (size_t)n * 4)) return r;
-    if (int r = amvhip_huffman_decode_dev(c, d_blob, blob_bytes, d_offs, d_lens, n, w, h, (int16_t*)c->coef.p,
-                                          d_status, (uint32_t*)c->nmcu.p, stream))
+    if (int r = ensure(c, c->rec, (size_t)n * cap_rec * 4)) return r;
+    if (int r = ensure(c, c->dcv, (size_t)n * g.blocks * 2 + 16)) return r;
+    if (int r = ensure(c, c->mcu_start, (size_t)n * (g.mcus + 1) * 4)) return r;
+    if (int r = ensure(c, c->rec_count, (size_t)n * 4)) return r;
+    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)c->rec.p, cap_rec, (int16_t*)c->dcv.p, (uint32_t*)c->mcu_start.p,
+                    (uint32_t*)c->rec_count.p, nullptr, nullptr};
+    if (c->dense_intermediate) sinks.rec = nullptr;
+    if (int r = entropy_stage(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, (uint32_t*)c->nmcu.p, (hipStream_t)stream))
         return r;
-    return amvhip_reconstruct_dev(c, (const int16_t*)c->coef.p, (const uint32_t*)c->nmcu.p, n, w, h, flags,
-                                  d_out, stream);
+    return reconstruct_stage(c, sinks, (const uint32_t*)c->nmcu.p, n, g, flags, d_out, (hipStream_t)stream);
 }
 
 extern "C" int amvhip_decode_batch(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,

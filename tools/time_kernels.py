@@ -50,15 +50,14 @@ for it in range(a.steps + 2):
     if it == 2:
         ctx.prof_enable(True)
         ctx.prof_reset()
-    ctx.huffman_decode_dev(blob, cap, offs, lens, n, w, h, coef, st, ok, s)
-    ctx.reconstruct_dev(coef, ok, n, w, h, 0, out, s)
+    ctx.decode_batch_dev(blob, cap, offs, lens, n, w, h, 0, out, st, s)
 torch.cuda.synchronize()
 res = {"lib": os.path.basename(pkg.LIB_PATH), "frames": n, "size": [w, h], "bad": int((st != 0).sum())}
 for k in (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON):
     cnt, ms = ctx.prof_read(k)
     res[ctx.kernel_name(k)] = round(ms / max(cnt, 1), 4)
 ctx.entropy_stats(True)
-ctx.huffman_decode_dev(blob, cap, offs, lens, n, w, h, coef, st, ok, s)
+ctx.decode_batch_dev(blob, cap, offs, lens, n, w, h, 0, out, st, s)
 es = ctx.entropy_stats(False)
 res["sync"] = {"mean_rounds": round(es["rounds"] / max(es["frames"], 1), 2), "max_rounds": es["max_rounds"],
                "kclk_per_wave": {k: round(v / 1e3, 1) for k, v in es["clocks_per_wave"].items()}}
