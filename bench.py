@@ -144,6 +144,18 @@ def main():
     algo_bytes = stream_bytes + n * 3 * w * h                 # per launch (= per step, per GPU)
     achieved = algo_bytes / (kern[dom]["avg_ms"] * 1e-3) / 1e9 if kern[dom]["avg_ms"] > 0 else 0.0
 
+    # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
+    # (tools/summarize_pmc.py -> profiles/*_traffic.json); only quoted for the workload that was profiled
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if (w, h, n) == (160, 120, 10000):
+            for kname, rec in prof["kernels"].items():
+                if kname.split("<")[0].endswith(dom) and rec["hbm_corrected"] > 1e6:
+                    traffic = rec["hbm_corrected"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     result = {
         "metric": "AMV frames/sec/GPU (160x120 decode, bit-exact)" if (w, h) == (160, 120) else "AMV frames/sec/GPU (%dx%d decode, bit-exact)" % (w, h),
         "value": total_frames / elapsed,
@@ -161,7 +173,7 @@ def main():
                    "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % world,
                    "per_gpu_frames_per_s": total_frames / elapsed / world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernels": kern,
                      "path_achieved": algo_bytes / (elapsed / args.steps) / 1e9,
                      "entropy_sync_rounds": {"mean": sync["rounds"] / max(sync["frames"], 1), "max": sync["max_rounds"]}},
