@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "libamvhip.so")
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["csrc/amv_decode.hip", "csrc/amv_decode_sync.hip", "csrc/amv_reconstruct.hip", "csrc/amv_encode.hip", "csrc/amv_adpcm.hip", "csrc/amvhip_api.hip"]
+HIP_SOURCES = ["csrc/amv_decode.hip", "csrc/amv_decode_sync.hip", "csrc/amv_reconstruct.hip", "csrc/amv_encode.hip", "csrc/amv_encode_par.hip", "csrc/amv_adpcm.hip", "csrc/amvhip_api.hip"]
 C_SOURCES = ["host/amvlib_compat.c"]
 HEADERS = ["csrc/amv_tables.h", "csrc/amv_kernels.h", "../include/amvhip.h"]
 

@@ -219,14 +219,19 @@ __device__ __forceinline__ uint32_t slot_offset(uint32_t lane, uint32_t k) {
 __global__ __launch_bounds__(kWave) void amv_pack_kernel(
     const int16_t* __restrict__ coef, uint32_t n, uint32_t blocks_per_frame,
     const HuffEncodeImage* __restrict__ img, uint8_t* __restrict__ tmp, uint32_t bound,
-    uint32_t* __restrict__ lens) {
+    uint32_t* __restrict__ lens, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
     __shared__ uint32_t s_book[4][256];
     __shared__ __attribute__((aligned(16))) uint4 s_slots[kWave * 8];
+    __shared__ uint32_t s_frame[kWave];
 
+    // with a list (frames amv_pack_wave_kernel handed back): frames list[0 .. *list_count)
     const uint32_t lane = threadIdx.x;
     const uint32_t f0 = blockIdx.x * kWave;
-    const uint32_t frame = f0 + lane;
-    const bool live = frame < n;
+    if (list) n = *list_count;
+    if (f0 >= n) return;
+    const uint32_t frame = f0 + lane < n ? (list ? list[f0 + lane] : f0 + lane) : 0xffffffffu;
+    s_frame[lane] = frame;
+    const bool live = frame != 0xffffffffu;
     for (int i = lane; i < 4 * 256; i += kWave) (&s_book[0][0])[i] = (&img->code[0][0])[i];
 
     BitWriter w;
@@ -246,8 +251,9 @@ __global__ __launch_bounds__(kWave) void amv_pack_kernel(
             const uint32_t c = i * kWave + lane;
             const uint32_t s = c >> 3, part = c & 7u;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (f0 + s < n)
-                v = reinterpret_cast<const uint4*>(coef + ((uint64_t)(f0 + s) * blocks_per_frame + b) * 64u)[part];
+            const uint32_t fr = s_frame[s];
+            if (fr != 0xffffffffu)
+                v = reinterpret_cast<const uint4*>(coef + ((uint64_t)fr * blocks_per_frame + b) * 64u)[part];
             s_slots[s * 8u + (part ^ (s & 7u))] = v;
         }
         __syncthreads();
@@ -282,11 +288,12 @@ __global__ __launch_bounds__(kWave) void amv_pack_kernel(
 }
 
 void launch_pack(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img,
-                 uint8_t* tmp, uint32_t bound, uint32_t* lens, hipStream_t s) {
+                 uint8_t* tmp, uint32_t bound, uint32_t* lens, const uint32_t* list, const uint32_t* list_count,
+                 hipStream_t s) {
     if (n == 0) return;
-    const uint32_t grid = (n + kWave - 1) / kWave;
+    const uint32_t grid = (n + kWave - 1) / kWave;   // with a list: upper bound, surplus groups exit at once
     hipLaunchKernelGGL(amv_pack_kernel, dim3(grid), dim3(kWave), 0, s, coef, n, g.blocks, d_img, tmp,
-                       bound, lens);
+                       bound, lens, list, list_count);
 }
 
 // ============================================================================================

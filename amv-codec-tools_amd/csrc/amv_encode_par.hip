@@ -1,0 +1,223 @@
+// amv_encode_par.hip -- the entropy coder with parallelism inside a frame (gfx950).
+//
+// Unlike decoding, encoding has no serial chain that cannot be cut: the DC difference of a block
+// needs only the previous block of its component (mjpegenc.c:390-401), and once every block's code
+// length is known the bit position of every block is a prefix sum.  One wave per frame:
+//
+//   1. each lane takes blocks lane, lane+64, ...: loads the block's 64 quantised coefficients (one
+//      128-byte line) into registers and adds up the length of its code (encode_block,
+//      mjpegenc.c:379-435, without writing);
+//   2. a wave prefix sum over the block lengths gives every block's first bit;
+//   3. each lane codes its blocks again, this time OR-ing the bits into the frame's bit string in
+//      LDS (32-bit big-endian words; neighbouring blocks share words, hence the atomic OR);
+//   4. the tail is padded with ones (ff_mjpeg_encode_stuffing :338-343), FF bytes are counted and
+//      the string is written out as FF D8, bytes with 00 after every FF (escape_FF :282-336), FF D9.
+//
+// Frames whose bit string does not fit the LDS window are left to amv_pack_kernel (one lane per
+// frame), through the same kind of hand-back list the decoder uses.  Output is byte-identical to
+// that kernel's and to the CPU oracle's (tests).
+#include "amv_kernels.h"
+
+namespace amv {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxWaves = 4;   // frames per workgroup (they share the code book); fewer when the window is large
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane, uint32_t& total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    total = __shfl(x, kWave - 1);
+    return x - v;
+}
+
+__device__ __forceinline__ int coef_at(const uint32_t (&c)[32], int i) {
+    return (i & 1) ? ((int)c[i >> 1] >> 16) : (int)(int16_t)(c[i >> 1] & 0xffffu);
+}
+
+// Bits of one block appended at an arbitrary bit position of the LDS string.
+struct Emitter {
+    uint32_t* words;
+    uint32_t wi;        // word being filled
+    uint64_t acc;       // pending bits, right aligned
+    int nacc;
+    uint32_t nbits;     // total length so far (both modes)
+};
+
+template <bool kEmit>
+__device__ __forceinline__ void put(Emitter& e, uint32_t entry, int extra_bits, uint32_t extra) {
+    const int len = (int)(entry >> 16) + extra_bits;
+    e.nbits += (uint32_t)len;
+    if (!kEmit) return;
+    e.acc = (e.acc << len) | ((uint64_t)(entry & 0xffffu) << extra_bits) | extra;
+    e.nacc += len;
+    if (e.nacc >= 32) {
+        e.nacc -= 32;
+        atomicOr(&e.words[e.wi++], (uint32_t)(e.acc >> e.nacc));
+    }
+}
+
+// encode_block (mjpegenc.c:379-435) over a block held in registers; prev_dc = the component's predictor
+template <bool kEmit>
+__device__ __forceinline__ void code_block(Emitter& e, const uint32_t (&c)[32], int prev_dc, const uint32_t* dcbook,
+                                           const uint32_t* acbook) {
+    int diff = coef_at(c, 0) - prev_dc;
+    {   // ff_mjpeg_encode_dc :357-377
+        int mant = diff;
+        if (diff < 0) { diff = -diff; mant--; }
+        const int nb = 32 - __clz(diff);   // 0 for diff == 0
+        put<kEmit>(e, dcbook[nb], nb, (uint32_t)mant & ((1u << nb) - 1u));
+    }
+    int run = 0;
+#pragma unroll
+    for (int k = 1; k < 64; ++k) {
+        int v = coef_at(c, k);
+        if (v == 0) { ++run; continue; }
+        while (run >= 16) { put<kEmit>(e, acbook[0xf0], 0, 0u); run -= 16; }   // ZRL :408-411
+        int mant = v;
+        if (v < 0) { v = -v; mant--; }
+        const int nb = 32 - __clz(v);
+        put<kEmit>(e, acbook[(run << 4) | nb], nb, (uint32_t)mant & ((1u << nb) - 1u));
+        run = 0;
+    }
+    if (run) put<kEmit>(e, acbook[0], 0, 0u);   // EOB :430-431
+}
+
+// the block whose DC is this block's predictor (same component), or -1 for the first MCU
+__device__ __forceinline__ int pred_block(uint32_t b) {
+    const uint32_t k6 = b % 6u;
+    if (k6 >= 4u) return (int)b - 6;
+    return k6 == 0u ? (int)b - 3 : (int)b - 1;
+}
+
+}  // namespace
+
+// dynamic LDS: [ code book 4 KB | per wave: bits[cap_words] | block lengths[blocks_cap] ]
+__global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
+    const int16_t* __restrict__ coef, uint32_t n, uint32_t blocks_per_frame, uint32_t blocks_cap,
+    uint32_t cap_words, const HuffEncodeImage* __restrict__ img, uint8_t* __restrict__ tmp, uint32_t bound,
+    uint32_t* __restrict__ lens, uint32_t* __restrict__ retry_list, uint32_t* __restrict__ retry_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    uint32_t* book = reinterpret_cast<uint32_t*>(s_mem);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) book[i] = (&img->code[0][0])[i];
+    __syncthreads();
+    const uint32_t frame = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (frame >= n) return;
+
+    uint32_t* bits = reinterpret_cast<uint32_t*>(s_mem + 4096u + wave * (cap_words + blocks_cap) * 4u);
+    uint32_t* blen = bits + cap_words;
+    const int16_t* fcoef = coef + (uint64_t)frame * blocks_per_frame * 64u;
+    for (uint32_t i = lane; i < cap_words; i += kWave) bits[i] = 0u;
+
+    // ---- 1. code length of every block
+    for (uint32_t b = lane; b < blocks_per_frame; b += kWave) {
+        uint32_t c[32];
+        const uint4* src = reinterpret_cast<const uint4*>(fcoef + (uint64_t)b * 64u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const uint4 q = src[i]; c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w; }
+        const int pb = pred_block(b);
+        const int prev = pb >= 0 ? (int)fcoef[(uint64_t)pb * 64u] : 0;
+        const uint32_t cls = (b % 6u) >= 4u ? 1u : 0u;
+        Emitter e{nullptr, 0u, 0ull, 0, 0u};
+        code_block<false>(e, c, prev, book + cls * 256u, book + (2u + cls) * 256u);
+        blen[b] = e.nbits;
+    }
+    wave_sync();
+
+    // ---- 2. first bit of every block: each lane owns a run of consecutive blocks for the scan
+    const uint32_t per = (blocks_per_frame + kWave - 1) / kWave;
+    const uint32_t lo = min(blocks_per_frame, lane * per), hi = min(blocks_per_frame, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; ++b) sum += blen[b];
+    uint32_t total_bits;
+    uint32_t run_pos = wave_excl_sum(sum, lane, total_bits);
+    for (uint32_t b = lo; b < hi; ++b) { const uint32_t l = blen[b]; blen[b] = run_pos; run_pos += l; }
+    wave_sync();
+    const uint32_t nbytes = (total_bits + 7u) >> 3;
+    if (nbytes + 8u > cap_words * 4u) {   // does not fit the window: the one-lane-per-frame kernel takes it
+        if (lane == 0) retry_list[atomicAdd(retry_count, 1u)] = frame;
+        return;
+    }
+
+    // ---- 3. the bits
+    for (uint32_t b = lane; b < blocks_per_frame; b += kWave) {
+        uint32_t c[32];
+        const uint4* src = reinterpret_cast<const uint4*>(fcoef + (uint64_t)b * 64u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const uint4 q = src[i]; c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w; }
+        const int pb = pred_block(b);
+        const int prev = pb >= 0 ? (int)fcoef[(uint64_t)pb * 64u] : 0;
+        const uint32_t cls = (b % 6u) >= 4u ? 1u : 0u;
+        const uint32_t pos = blen[b];
+        Emitter e{bits, pos >> 5, 0ull, (int)(pos & 31u), 0u};   // the word's earlier bits belong to the previous block: zeros here, OR-ed in
+        code_block<true>(e, c, prev, book + cls * 256u, book + (2u + cls) * 256u);
+        if (e.nacc) atomicOr(&e.words[e.wi], (uint32_t)(e.acc << (32 - e.nacc)));
+    }
+    wave_sync();
+    if (lane == 0 && (total_bits & 7u))   // ff_mjpeg_encode_stuffing: ones up to the byte boundary
+        atomicOr(&bits[total_bits >> 5], ((1u << (8u - (total_bits & 7u))) - 1u) << (24u - (total_bits & 24u)));
+    wave_sync();
+
+    // ---- 4. FF D8, the bytes with 00 after every FF, FF D9
+    uint8_t* out = tmp + (uint64_t)frame * bound;
+    uint32_t ff_before = 0;
+    for (uint32_t w0 = 0; w0 * 4u < nbytes; w0 += kWave) {
+        const uint32_t wi = w0 + lane;
+        const uint32_t word = wi * 4u < nbytes ? bits[wi] : 0u;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+            cnt += (wi * 4u + j < nbytes && ((word >> (24u - 8u * j)) & 0xffu) == 0xffu) ? 1u : 0u;
+        uint32_t tile;
+        uint32_t o = 2u + wi * 4u + ff_before + wave_excl_sum(cnt, lane, tile);
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (wi * 4u + j >= nbytes) break;
+            const uint32_t byte = (word >> (24u - 8u * j)) & 0xffu;
+            out[o++] = (uint8_t)byte;
+            if (byte == 0xffu) out[o++] = 0;
+        }
+        ff_before += tile;
+    }
+    if (lane == 0) {
+        out[0] = 0xff; out[1] = 0xd8;                          // SOI only, mjpegenc.c:201-204
+        const uint32_t end = 2u + nbytes + ff_before;
+        out[end] = 0xff; out[end + 1] = 0xd9;                  // EOI :354
+        lens[frame] = end + 2u;
+    }
+}
+
+bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img, uint8_t* tmp,
+                      uint32_t bound, uint32_t* lens, uint32_t* retry_list, uint32_t* retry_count, hipStream_t s) {
+    // bit-string window: ~2x the 0.2 bytes per pixel AMV runs at
+    uint32_t cap_bytes = ((g.width * g.height * 2u / 5u) + 1023u) & ~1023u;
+    if (cap_bytes < 2048u) cap_bytes = 2048u;
+    const uint32_t blocks_cap = (g.blocks + 3u) & ~3u;
+    const uint32_t per_wave = cap_bytes + blocks_cap * 4u;
+    uint32_t waves = kMaxWaves;
+    while (waves > 1u && 4096u + waves * per_wave > 79u * 1024u) waves >>= 1;   // aim at two workgroups per CU
+    const uint32_t lds = 4096u + waves * per_wave;
+    if (lds > 150u * 1024u) return false;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_pack_wave_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    hipLaunchKernelGGL(amv_pack_wave_kernel, dim3((n + waves - 1) / waves), dim3(kWave * waves), lds, s, coef, n,
+                       g.blocks, blocks_cap, cap_bytes / 4u, d_img, tmp, bound, lens, retry_list, retry_count);
+    return true;
+}
+
+}  // namespace amv

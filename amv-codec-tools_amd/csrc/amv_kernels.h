@@ -61,7 +61,12 @@ void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_
                     const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s);
 // entropy coder: one lane per frame, writes FFD8 + escaped scan + FFD9 into tmp[i*bound..]
 void launch_pack(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img,
-                 uint8_t* tmp, uint32_t bound, uint32_t* lens, hipStream_t s);
+                 uint8_t* tmp, uint32_t bound, uint32_t* lens, const uint32_t* list, const uint32_t* list_count,
+                 hipStream_t s);
+// entropy coder, one wave per frame (amv_encode_par.hip); frames whose bit string does not fit its LDS
+// window are appended to retry_list for launch_pack(list).  false: geometry too large, use launch_pack.
+bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img, uint8_t* tmp,
+                      uint32_t bound, uint32_t* lens, uint32_t* retry_list, uint32_t* retry_count, hipStream_t s);
 // exclusive scan of lens -> offs (single workgroup), then gather tmp -> blob
 void launch_compact(const uint8_t* tmp, uint32_t bound, const uint32_t* lens, uint32_t n,
                     uint64_t* offs, uint8_t* blob, uint64_t blob_cap, int32_t* overflow, hipStream_t s);

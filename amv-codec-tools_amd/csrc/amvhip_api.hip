@@ -431,13 +431,27 @@ extern "C" int amvhip_encode_batch_dev(amvhip_ctx* c, const uint8_t* d_pix, uint
     if (int r = ensure(c, c->tmp, (size_t)n * bound)) return r;
     if (int r = ensure(c, c->flag, 16)) return r;
     if (int r = amvhip_encode_coefs_dev(c, d_pix, pix_stride, is_bgr, n, w, h, qbias, (int16_t*)c->coef.p, stream)) return r;
-    {
+    if (int r = ensure(c, c->retry, ((size_t)n + 4) * 8)) return r;
+    uint32_t* retry_count = (uint32_t*)c->retry.p;
+    uint32_t* retry_list = retry_count + 8;
+    HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, (hipStream_t)stream));
+    bool par = false;
+    if (c->entropy_mode != AMVHIP_ENTROPY_SERIAL) {
         Timed t(c, AMVHIP_K_PACK, (hipStream_t)stream);
-        launch_pack((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens, (hipStream_t)stream);
+        par = launch_pack_wave((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens, retry_list,
+                               retry_count, (hipStream_t)stream);
+    }
+    {   // the one-lane-per-frame coder: everything, or the frames handed back (usually none)
+        Timed t(c, AMVHIP_K_PACK_SERIAL, (hipStream_t)stream);
+        launch_pack((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens,
+                    par ? retry_list : nullptr, par ? retry_count : nullptr, (hipStream_t)stream);
     }
     if (int r = check_launch(c, "pack")) return r;
-    launch_compact((const uint8_t*)c->tmp.p, bound, d_lens, n, d_offs, d_blob, blob_cap, (int32_t*)c->flag.p,
-                   (hipStream_t)stream);
+    {
+        Timed t(c, AMVHIP_K_COMPACT, (hipStream_t)stream);
+        launch_compact((const uint8_t*)c->tmp.p, bound, d_lens, n, d_offs, d_blob, blob_cap, (int32_t*)c->flag.p,
+                       (hipStream_t)stream);
+    }
     return check_launch(c, "compact");
 }
 
@@ -664,7 +678,9 @@ extern "C" const char* amvhip_kernel_name(int kernel) {
         case AMVHIP_K_HUFFMAN_SERIAL: return "amv_huffman_kernel";
         case AMVHIP_K_RECON: return "amv_reconstruct_kernel";
         case AMVHIP_K_FDCT: return "amv_forward_kernel";
-        case AMVHIP_K_PACK: return "amv_pack_kernel";
+        case AMVHIP_K_PACK: return "amv_pack_wave_kernel";
+        case AMVHIP_K_PACK_SERIAL: return "amv_pack_kernel";
+        case AMVHIP_K_COMPACT: return "amv_scan_kernel+amv_gather_kernel";
         case AMVHIP_K_ADPCM_DEC: return "amv_adpcm_decode_kernel";
         case AMVHIP_K_ADPCM_ENC: return "amv_adpcm_encode_kernel";
         case AMVHIP_K_SYNTH: return "amv_synth_frames_kernel";

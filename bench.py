@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- AMV decode throughput on MI355X (BASELINE.json: 160x120 decode, bit-exact vs amvlib).
+"""bench.py -- AMV codec throughput on MI355X.  Default: BASELINE.json's metric (160x120 decode,
+bit-exact vs amvlib) on its configs[1].
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the decode hot path (entropy kernel + reconstruction kernel, through the
-C ABI entry amvhip_decode_batch_dev) over one batch: a synthetic 160x120 AMV stream of --frames
-frames per GPU (default 10 000), compressed chunks already resident in HBM
-when the timed region starts, decoded BGR24 frames left in HBM.  Frames shard by contiguous range,
-one process per GPU, no collective inside the codec path ("scaling": "weak": every GPU decodes
-its own --frames frames).  The stream is made on the device, outside the timed region, by the
-library's own generator + encoder (both proven byte-identical to the CPU oracle by the tests and
-spot-checked again here).
+One step = one pass of the hot path, through the C ABI, over one batch that is already resident in
+HBM when the timed region starts; results stay in HBM.  Frames shard by contiguous range, one
+process per GPU, no collective inside the codec path ("scaling": "weak": every GPU works on its own
+--frames frames).  Synthetic sources are made on the device, outside the timed region, by the
+library's generator (+ encoder), both proven byte-identical to the CPU oracle by the tests and
+spot-checked again here before anything is timed.
+
+  --workload decode      (default) --frames chunks of WxH (160x120) -> BGR24 frames      configs[1], [3]
+  --workload encode      RGB24 frames of WxH (320x240) -> chunks; the round trip through the
+                         bit-exact decoder is PSNR-checked against the source                configs[2]
+  --workload coresident  WxH (320x240) video decode on one HIP stream with IMA-ADPCM decode +
+                         encode of the frames' audio chunks on a second stream               configs[4]
+  --workload adpcm       IMA-ADPCM chunks -> PCM -> chunks, audio alone
 
 Extra objects on the JSON line:
   roofline     the dominant kernel against the HBM roof: algorithmic bytes of the path per launch
-               (sum of chunk bytes + 3*W*H per frame) / that kernel's mean duration
-               measured with HIP events on the launch stream inside the timed region.
-  cpu_baseline the CPU oracle (a port of amvlib's algorithm; the reference itself cannot travel to
-               the GPU box) decoding a bounded sample of the same stream on the host cores.
+               (video: chunk bytes + 3*W*H per frame; audio: chunk bytes + 2 per sample)
+               / that kernel's mean duration measured with HIP events on the launch stream inside the
+               timed region.
+  cpu_baseline the CPU oracle (a port of the reference's algorithm; the reference itself cannot
+               travel to the GPU box) on a bounded sample of the same workload on the host cores.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -37,40 +45,16 @@ import __graft_entry__ as entry  # noqa: E402
 
 SEED = 0xA11CE
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SAMPLES_PER_FRAME = 1378  # 22050 Hz mono at 16 fps: the audio chunk that travels with one video frame
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step")
-    ap.add_argument("--width", type=int, default=160)
-    ap.add_argument("--height", type=int, default=120)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="frames of the stream the CPU baseline decodes")
-    args = ap.parse_args()
+class Env:
+    pass
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL over xGMI
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the decode path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
-    pkg = entry.load_package()
-    sh = entry._load(entry.PKG_NAME + ".sharding", os.path.join(entry.PKG_DIR, "sharding.py"))
-    ctx = pkg.Context(local)
-    w, h, n = args.width, args.height, args.frames
-    stream = torch.cuda.current_stream().cuda_stream
-    fb = ctx.frame_bytes(w, h)
-
-    # ---- the stream of this rank: frames [rank*n, (rank+1)*n) of the seeded source, encoded on the device
-    first = rank * n
+def make_video_stream(E, first, n, w, h):
+    """frames [first, first+n) of the seeded source, encoded on the device -> blob, cap, offs, lens, bytes"""
+    ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
     cap = max(1 << 20, n * w * h)             # ~0.2 B/pixel in practice; checked below
     d_blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
     d_offs = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -89,15 +73,90 @@ def main():
         pos = (pos + 3) & ~3                  # keep every slice's base 4-byte aligned
         if pos > cap:
             raise SystemExit("synthetic stream overflowed its buffer")
-    del d_rgb
-    stream_bytes = int(d_lens.sum().item())
+    return d_blob, cap, d_offs, d_lens, int(d_lens.sum().item())
+
+
+def timed(E, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    E.ctx.prof_enable(True)
+    E.ctx.prof_reset()
+    if E.world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if E.world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    E.ctx.prof_enable(False)
+    return E.sh.max_over_ranks(elapsed, E.dev)
+
+
+def kernel_times(E, ids):
+    kern = {}
+    for k in ids:
+        launches, ms = E.ctx.prof_read(k)
+        if launches:
+            kern[E.ctx.kernel_name(k)] = {"launches": launches, "avg_ms": ms / launches}
+    return kern
+
+
+def profiled_traffic(tag, dom):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of this same command
+    (tools/summarize_pmc.py -> profiles/r01_traffic*.json); only quoted for the workload that was profiled"""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic%s.json" % tag)))
+        for kname, rec in prof["kernels"].items():
+            if kname.split("<")[0].endswith(dom) and rec["hbm_corrected"] > 1e6:
+                return rec["hbm_corrected"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def cpu_cores():
+    # a one-GPU box owns a 16-core share of the host whatever cpu_count says
+    return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("AMV_BENCH_CORES", "16"))))
+
+
+def base_result(E, args, metric, unit, units_per_step_per_gpu, elapsed):
+    total = E.sh.sum_over_ranks(float(units_per_step_per_gpu * args.steps), E.dev)
+    return {
+        "metric": metric, "value": total / elapsed, "unit": unit, "n_gpus": E.world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+    }
+
+
+def roofline(kern, algo_bytes, elapsed_per_step, traffic, extra=None):
+    dom = max(kern, key=lambda name: kern[name]["avg_ms"])
+    achieved = algo_bytes / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic(dom) if callable(traffic) else traffic,
+         "algorithmic_bytes_per_launch": algo_bytes, "kernels": kern,
+         "path_achieved": algo_bytes / elapsed_per_step / 1e9}
+    if extra:
+        r.update(extra)
+    return r
+
+
+# ---------------------------------------------------------------------------------------------
+def run_decode(E, args):
+    ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
+    w, h, n = args.width or 160, args.height or 120, args.frames or 10000
+    first = E.rank * n
+    d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, first, n, w, h)
     d_out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
     d_st = torch.empty(n, dtype=torch.int32, device=dev)
 
     def step():
         ctx.decode_batch_dev(d_blob, cap, d_offs, d_lens, n, w, h, 0, d_out, d_st, stream)
 
-    # ---- correctness gate before any timing: sample frames against the CPU oracle (checker only)
+    # correctness gate before any timing: sample frames against the CPU oracle (checker only)
     step()
     torch.cuda.synchronize()
     if int((d_st != 0).sum().item()) != 0:
@@ -112,79 +171,26 @@ def main():
         if ch != orc.encode_frame(orc.synth_frame(SEED, first + i, w, h), w, h):
             raise SystemExit("device-made stream differs from the oracle's encoder at frame %d" % (first + i))
 
-    # ---- timed region
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.prof_enable(False)
-    elapsed = sh.max_over_ranks(elapsed, dev)
-    total_frames = sh.sum_over_ranks(float(n * args.steps), dev)
-
+    elapsed = timed(E, step, args.steps, args.warmup)
+    kern = kernel_times(E, (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON))
     ctx.entropy_stats(True)          # one extra, untimed step: how many synchronisation rounds the frames needed
     step()
     sync = ctx.entropy_stats(False)
 
-    kern = {}
-    for k in (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON):
-        launches, ms = ctx.prof_read(k)
-        kern[ctx.kernel_name(k)] = {"launches": launches, "avg_ms": ms / max(launches, 1)}
-    dom = max(kern, key=lambda name: kern[name]["avg_ms"])
-    algo_bytes = stream_bytes + n * 3 * w * h                 # per launch (= per step, per GPU)
-    achieved = algo_bytes / (kern[dom]["avg_ms"] * 1e-3) / 1e9 if kern[dom]["avg_ms"] > 0 else 0.0
+    result = base_result(E, args, "AMV frames/sec/GPU (%dx%d decode, bit-exact)" % (w, h), "frames/s", n, elapsed)
+    result["config"] = {"workload": "%dx%d AMV decode, %d-frame synthetic stream per GPU, chunks resident in HBM" % (w, h, n),
+                        "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % E.world,
+                        "per_gpu_frames_per_s": result["value"] / E.world}
+    result["roofline"] = roofline(
+        kern, stream_bytes + n * 3 * w * h, elapsed / args.steps,
+        (lambda dom: profiled_traffic("", dom)) if (w, h, n) == (160, 120, 10000) else None,
+        {"entropy_sync_rounds": {"mean": sync["rounds"] / max(sync["frames"], 1), "max": sync["max_rounds"]}})
 
-    # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
-    # (tools/summarize_pmc.py -> profiles/*_traffic.json); only quoted for the workload that was profiled
-    traffic = None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if (w, h, n) == (160, 120, 10000):
-            for kname, rec in prof["kernels"].items():
-                if kname.split("<")[0].endswith(dom) and rec["hbm_corrected"] > 1e6:
-                    traffic = rec["hbm_corrected"]
-    except (OSError, ValueError, KeyError):
-        pass
-
-    result = {
-        "metric": "AMV frames/sec/GPU (160x120 decode, bit-exact)" if (w, h) == (160, 120) else "AMV frames/sec/GPU (%dx%d decode, bit-exact)" % (w, h),
-        "value": total_frames / elapsed,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "int32",
-        "data": "synthetic",
-        "config": {"workload": "%dx%d AMV decode, %d-frame synthetic stream per GPU, chunks resident in HBM" % (w, h, n),
-                   "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % world,
-                   "per_gpu_frames_per_s": total_frames / elapsed / world},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": algo_bytes, "kernels": kern,
-                     "path_achieved": algo_bytes / (elapsed / args.steps) / 1e9,
-                     "entropy_sync_rounds": {"mean": sync["rounds"] / max(sync["frames"], 1), "max": sync["max_rounds"]}},
-    }
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
         m = min(args.cpu_sample, n)
         blob_h = d_blob[: int(offs_h[m - 1]) + int(lens_h[m - 1]) + 16].cpu().numpy()
         o64, l32 = offs_h[:m].astype(np.uint64), lens_h[:m].astype(np.uint32)
-        # a one-GPU box owns a 16-core share of the host whatever cpu_count says
-        cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("AMV_BENCH_CORES", "16"))))
+        cores = cpu_cores()
         t = time.perf_counter()
         _, st1 = orc.decode_batch(blob_h, o64, l32, w, h, 0, threads=1)
         t1 = time.perf_counter() - t
@@ -199,10 +205,239 @@ def main():
                                   "sample": "first %d frames of the same stream, CPU oracle (amvlib algorithm restated in C), "
                                             "frame-sharded over %d OpenMP threads, %d passes" % (m, cores, reps),
                                   "single_thread_value": m / t1}
-    if rank == 0:
+    return result
+
+
+# ---------------------------------------------------------------------------------------------
+def run_encode(E, args):
+    ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
+    w, h, n = args.width or 320, args.height or 240, args.frames or 2000
+    if args.psnr_floor is None:
+        args.psnr_floor = 26.6 if (w, h) == (320, 240) else 25.4
+    first = E.rank * n
+    d_rgb = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+    ctx.synth_frames_dev(SEED, first, n, w, h, d_rgb, stream)
+    cap = max(1 << 20, n * w * h)
+    d_blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    d_offs = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_lens = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def step():
+        ctx.encode_batch_dev(d_rgb, w * 3, 0, n, w, h, pkg.QBIAS_AMV, d_blob, cap, d_offs, d_lens, stream)
+
+    # gate: chunks byte-identical to the oracle's encoder on sample frames; whole batch round-trips through
+    # the bit-exact decoder with PSNR against the source above the stated floor
+    step()
+    torch.cuda.synchronize()
+    stream_bytes = int(d_lens.sum().item())
+    if int(d_offs[-1].item()) + int(d_lens[-1].item()) > cap:
+        raise SystemExit("encoded stream overflowed its buffer")
+    orc = entry.load_oracle()
+    offs_h, lens_h = d_offs.cpu().numpy(), d_lens.cpu().numpy()
+    for i in sorted({0, 1, n // 2, n - 1}):
+        ch = d_blob[int(offs_h[i]):int(offs_h[i]) + int(lens_h[i])].cpu().numpy().tobytes()
+        if ch != orc.encode_frame(d_rgb[i].cpu().numpy(), w, h):
+            raise SystemExit("HIP encode differs from the oracle's encoder at frame %d" % (first + i))
+    d_out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
+    d_st = torch.empty(n, dtype=torch.int32, device=dev)
+    ctx.decode_batch_dev(d_blob, cap, d_offs, d_lens, n, w, h, 0, d_out, d_st, stream)
+    torch.cuda.synchronize()
+    if int((d_st != 0).sum().item()) != 0:
+        raise SystemExit("round trip: the decoder rejected an encoded frame")
+    sq = 0.0
+    for lo in range(0, n, 256):                # decoder output is BGR, rows padded to the stride
+        a = d_out[lo:lo + 256, :, : w * 3].reshape(-1, h, w, 3).flip(-1).to(torch.int32)
+        sq += float(((a - d_rgb[lo:lo + 256].to(torch.int32)) ** 2).sum().item())
+    psnr = 10.0 * math.log10(255.0 ** 2 / (sq / (n * h * w * 3)))
+    one = orc.psnr(d_out[0, :, : w * 3].reshape(h, w, 3).flip(-1).cpu().numpy(), d_rgb[0].cpu().numpy())
+    if psnr < args.psnr_floor:
+        raise SystemExit("round-trip PSNR %.2f dB is below the %.1f dB floor" % (psnr, args.psnr_floor))
+
+    elapsed = timed(E, step, args.steps, args.warmup)
+    kern = kernel_times(E, (pkg.K_FDCT, pkg.K_PACK, pkg.K_PACK_SERIAL, pkg.K_COMPACT))
+    result = base_result(E, args, "AMV frames/sec/GPU (%dx%d encode, PSNR-checked round trip)" % (w, h), "frames/s", n, elapsed)
+    result["config"] = {"workload": "%dx%d AMV encode (rgb24 -> yuvj420p, fdct, quantise, Huffman), %d synthetic frames per GPU "
+                                    "resident in HBM" % (w, h, n),
+                        "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % E.world,
+                        "round_trip_psnr_db": psnr, "psnr_floor_db": args.psnr_floor, "frame0_psnr_db_cpu_checker": one,
+                        "bit_exact_vs_cpu_encoder": True}
+    result["roofline"] = roofline(kern, stream_bytes + n * 3 * w * h, elapsed / args.steps,
+                                  (lambda dom: profiled_traffic("_encode", dom)) if (w, h, n) == (320, 240, 2000) else None)
+
+    if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
+        m = min(256, n)
+        src = d_rgb[:m].cpu().numpy()
+        t = time.perf_counter()
+        for i in range(m):
+            orc.encode_frame(src[i], w, h)
+        t1 = time.perf_counter() - t
+        result["cpu_baseline"] = {"value": m / t1, "unit": "frames/s", "cores": 1, "kind": "port",
+                                  "sample": "first %d frames of the same source, CPU oracle (the reference build's encoder "
+                                            "algorithm restated in C), one thread" % m}
+    return result
+
+
+# ---------------------------------------------------------------------------------------------
+def make_audio(E, first_chunk, n):
+    """n audio chunks of SAMPLES_PER_FRAME samples: pcm, pcm_offs, nsamp, chunk offs/lens"""
+    dev = E.dev
+    spf = SAMPLES_PER_FRAME
+    d_pcm = torch.empty(n * spf, dtype=torch.int16, device=dev)
+    E.ctx.synth_audio_dev(SEED, first_chunk * spf, n * spf, d_pcm, E.stream)
+    d_pcm_offs = torch.arange(n, dtype=torch.int64, device=dev) * spf
+    d_nsamp = torch.full((n,), spf, dtype=torch.int32, device=dev)
+    clen = 8 + spf // 2
+    d_offs = torch.arange(n, dtype=torch.int64, device=dev) * clen
+    d_lens = torch.full((n,), clen, dtype=torch.int32, device=dev)
+    d_chunks = torch.zeros(n * clen + 16, dtype=torch.uint8, device=dev)
+    return d_pcm, d_pcm_offs, d_nsamp, d_chunks, d_offs, d_lens, clen
+
+
+def audio_gate(E, A, n):
+    """encode on the device == oracle's encoder (index carried), decode on the device == oracle's decoder"""
+    d_pcm, d_pcm_offs, d_nsamp, d_chunks, d_offs, d_lens, clen = A
+    orc = entry.load_oracle()
+    spf = SAMPLES_PER_FRAME
+    m = min(n, 64)
+    pcm = d_pcm[: m * spf].cpu().numpy()
+    got = d_chunks[: m * clen].cpu().numpy()
+    idx = 0
+    for i in range(m):
+        want, idx = orc.adpcm_encode_chunk(pcm[i * spf:(i + 1) * spf], idx)
+        if got[i * clen:(i + 1) * clen].tobytes() != want:
+            raise SystemExit("HIP ADPCM encode differs from the oracle at chunk %d" % i)
+    return orc
+
+
+def run_adpcm(E, args, with_video=False):
+    ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
+    spf = SAMPLES_PER_FRAME
+    if with_video:
+        w, h, n = args.width or 320, args.height or 240, args.frames or 2000
+        first = E.rank * n
+        d_blob, cap, d_voffs, d_vlens, stream_bytes = make_video_stream(E, first, n, w, h)
+        d_out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
+        d_st = torch.empty(n, dtype=torch.int32, device=dev)
+        na = n
+    else:
+        na = args.frames or 200000
+        first = E.rank * na
+    A = make_audio(E, first, na)
+    d_pcm, d_pcm_offs, d_nsamp, d_chunks, d_offs, d_lens, clen = A
+    d_pcm2 = torch.zeros(na * spf + 8, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()                   # the sources were made on the main stream
+    side = torch.cuda.Stream(device=dev) if with_video else None
+    astream = side.cuda_stream if with_video else stream
+
+    def audio():
+        ctx.adpcm_encode_batch_dev(d_pcm, d_pcm_offs, d_nsamp, na, None, d_chunks, d_offs, astream)
+        ctx.adpcm_decode_batch_dev(d_chunks, na * clen, d_offs, d_lens, na, d_pcm2, d_pcm_offs, None, astream)
+
+    def step():
+        if with_video:
+            ctx.decode_batch_dev(d_blob, cap, d_voffs, d_vlens, n, w, h, 0, d_out, d_st, stream)
+        audio()
+
+    step()
+    torch.cuda.synchronize()
+    orc = audio_gate(E, A, na)
+    got = d_pcm2[: spf * min(na, 64)].cpu().numpy()
+    chunks_h = d_chunks[: clen * min(na, 64)].cpu().numpy()
+    for i in range(min(na, 64)):
+        want, _ = orc.adpcm_decode_chunk(chunks_h[i * clen:(i + 1) * clen])
+        if not (got[i * spf:(i + 1) * spf] == want[:spf]).all():
+            raise SystemExit("HIP ADPCM decode differs from the oracle at chunk %d" % i)
+    if with_video:
+        if int((d_st != 0).sum().item()) != 0:
+            raise SystemExit("decode reported errors on the synthetic stream")
+        offs_h, lens_h = d_voffs.cpu().numpy(), d_vlens.cpu().numpy()
+        for i in sorted({0, n - 1}):
+            ch = d_blob[int(offs_h[i]):int(offs_h[i]) + int(lens_h[i])].cpu().numpy().tobytes()
+            want, st, _ = orc.decode_frame(ch, w, h)
+            if st != 0 or not (d_out[i].cpu().numpy() == want).all():
+                raise SystemExit("HIP decode differs from the oracle at frame %d" % (first + i))
+
+    elapsed = timed(E, step, args.steps, args.warmup)
+    audio_bytes = na * (clen + 2 * spf)
+    if with_video:
+        kern = kernel_times(E, (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON, pkg.K_ADPCM_DEC, pkg.K_ADPCM_ENC))
+        result = base_result(E, args, "AMV frames/sec/GPU (%dx%d decode with co-resident IMA-ADPCM, bit-exact)" % (w, h),
+                             "frames/s", n, elapsed)
+        result["config"] = {"workload": "%dx%d AMV decode of %d frames per GPU on one HIP stream, IMA-ADPCM encode + decode of "
+                                        "the frames' %d-sample audio chunks on a second stream" % (w, h, n, spf),
+                            "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % E.world,
+                            "adpcm_samples_per_s": 2.0 * na * spf * args.steps * E.world / elapsed}
+        result["roofline"] = roofline(kern, stream_bytes + n * 3 * w * h, elapsed / args.steps, None)
+    else:
+        kern = kernel_times(E, (pkg.K_ADPCM_DEC, pkg.K_ADPCM_ENC))
+        result = base_result(E, args, "IMA-ADPCM samples/sec/GPU (encode + decode, bit-exact)", "samples/s", 2 * na * spf, elapsed)
+        result["dtype"] = "int32"
+        result["config"] = {"workload": "%d AMV audio chunks of %d samples per GPU: PCM -> ADPCM (step index carried through "
+                                        "the stream, as the reference encoder does) -> PCM" % (na, spf),
+                            "chunks_per_gpu": na, "parallelism": "chunk-range x%d" % E.world}
+        result["roofline"] = roofline(kern, audio_bytes, elapsed / args.steps, None)
+
+    if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline and not with_video:
+        m = min(na, 4096)
+        pcm = d_pcm[: m * spf].cpu().numpy()
+        ch = d_chunks[: m * clen].cpu().numpy()
+        t = time.perf_counter()
+        idx = 0
+        for i in range(m):
+            _, idx = orc.adpcm_encode_chunk(pcm[i * spf:(i + 1) * spf], idx)
+            orc.adpcm_decode_chunk(ch[i * clen:(i + 1) * clen])
+        t1 = time.perf_counter() - t
+        result["cpu_baseline"] = {"value": 2 * m * spf / t1, "unit": "samples/s", "cores": 1, "kind": "port",
+                                  "sample": "first %d chunks of the same audio, CPU oracle encode + decode, one thread "
+                                            "(includes the ctypes call per chunk)" % m}
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("decode", "encode", "coresident", "adpcm"), default="decode")
+    ap.add_argument("--frames", type=int, default=None, help="frames (audio chunks) per GPU per step; default per workload")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--psnr-floor", type=float, default=None,
+                    help="encode: round-trip PSNR the batch must reach (dB); default = the floor frozen from the CPU "
+                         "encoder in tests/test_oracle_pin.py::test_encode_round_trip_quality (26.6 at 320x240, 25.4 below: "
+                         "amvlib's colour matrix is not the inverse of the encoder's, which bounds the figure)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="frames of the stream the CPU baseline decodes")
+    args = ap.parse_args()
+
+    E = Env()
+    E.world = int(os.environ.get("WORLD_SIZE", "1"))
+    E.rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if E.world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=E.rank, world_size=E.world)   # RCCL over xGMI
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the codec path has no CPU fallback")
+    torch.cuda.set_device(local)
+    E.dev = torch.device("cuda", local)
+    E.pkg = entry.load_package()
+    E.sh = entry._load(entry.PKG_NAME + ".sharding", os.path.join(entry.PKG_DIR, "sharding.py"))
+    E.ctx = E.pkg.Context(local)
+    E.stream = torch.cuda.current_stream().cuda_stream
+
+    if args.workload == "decode":
+        result = run_decode(E, args)
+    elif args.workload == "encode":
+        result = run_encode(E, args)
+    elif args.workload == "coresident":
+        result = run_adpcm(E, args, with_video=True)
+    else:
+        result = run_adpcm(E, args, with_video=False)
+    if E.rank == 0:
         print(json.dumps(result))
-    ctx.close()
-    if world > 1:
+    E.ctx.close()
+    if E.world > 1:
         dist.destroy_process_group()
 
 

@@ -293,7 +293,9 @@ int amvhip_synth_audio_dev(amvhip_ctx *ctx, uint32_t seed, uint64_t first_sample
 #define AMVHIP_K_SYNTH 6
 #define AMVHIP_K_HUFFMAN_SERIAL 7
 #define AMVHIP_K_UNSTUFF 8
-#define AMVHIP_K_COUNT 10
+#define AMVHIP_K_PACK_SERIAL 9
+#define AMVHIP_K_COMPACT 10   /* amv_scan_kernel + amv_gather_kernel, timed as one */
+#define AMVHIP_K_COUNT 12
 void amvhip_prof_enable(amvhip_ctx *ctx, int on);
 void amvhip_prof_reset(amvhip_ctx *ctx);
 int amvhip_prof_read(amvhip_ctx *ctx, int kernel, uint64_t *launches, double *total_ms);

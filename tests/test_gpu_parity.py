@@ -262,7 +262,7 @@ def test_encode_matches_oracle(ctx, orc, w, h, n, bgr, qbias):
         pos += len(want_chunk)
 
 
-def test_encode_extreme_content(ctx, orc):
+def test_encode_extreme_content(ctx, pkg, orc):
     """flat, saturated and pure-noise frames: long zero runs (ZRL), large coefficients, many FF bytes"""
     import torch
     w, h = 160, 120
@@ -277,10 +277,18 @@ def test_encode_extreme_content(ctx, orc):
     blob = np.zeros(cap, np.uint8)
     offs = np.zeros(n, np.uint64)
     lens = np.zeros(n, np.uint32)
-    ctx.encode_batch(src, w * 3, 0, n, w, h, 0, blob, cap, offs, lens)
-    for i in range(n):
-        want = orc.encode_frame(src[i], w, h)
-        assert blob[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes() == want, i
+    try:
+        # the wave-per-frame coder (the noise frames overflow its LDS window and are handed back to the
+        # lane-per-frame coder) and the lane-per-frame coder alone
+        for mode in (pkg.ENTROPY_AUTO, pkg.ENTROPY_SERIAL):
+            ctx.set_entropy_mode(mode)
+            blob[:] = 0
+            ctx.encode_batch(src, w * 3, 0, n, w, h, 0, blob, cap, offs, lens)
+            for i in range(n):
+                want = orc.encode_frame(src[i], w, h)
+                assert blob[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes() == want, (mode, i)
+    finally:
+        ctx.set_entropy_mode(pkg.ENTROPY_AUTO)
     got, st = _gpu_decode(ctx, [blob[int(o):int(o) + int(l)].tobytes() for o, l in zip(offs, lens)], w, h, 1)
     assert (st == 0).all()
 
