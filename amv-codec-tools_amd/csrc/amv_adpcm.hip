@@ -6,11 +6,17 @@
 //            and :461-498 (AMV framing: le16 first sample, le16 step index, le32 sample count).
 //
 // The predictor loop is a serial chain inside a chunk; chunks are independent on decode (each
-// carries predictor + step index), so one lane owns one chunk.  On encode the reference carries
-// step_index from chunk to chunk.  That chain is cut with the fact that step_index has only 89
-// values: amv_adpcm_map_kernel runs every chunk from all 89 starts (state only, no output),
-// amv_adpcm_chain_kernel walks the 89-entry maps, and the real encode then runs one lane per
-// chunk from its now-known start.
+// carries predictor + step index), so one lane owns one chunk: it reads 16 chunk bytes at a time
+// (one unaligned 16-byte load), walks the 32 nibbles with the index chain running ahead of the
+// step-table lookups (LDS) and those ahead of the predictor chain, and stores the 32 samples as
+// one 64-byte run.  On encode the reference carries step_index from chunk to chunk, and the end
+// index of a chunk does depend on where it started (measured on the synthetic audio: 69 % of the
+// chunks, 8.6 distinct encoder states still alive at the end of a chunk), so guessing does not
+// work.  The chain is cut with the fact that step_index has only 89 values:
+// amv_adpcm_map_kernel runs every chunk from all 89 starts (state only, no output, one lane per
+// (chunk, start) pair), the amv_adpcm_chain_* kernels compose the 89-entry maps (256 chunks per
+// workgroup through LDS, then the workgroup maps, then back down), and the real encode runs one
+// lane per chunk from its now-known start.
 #include "amv_kernels.h"
 
 namespace amv {
@@ -20,26 +26,78 @@ namespace {
 __device__ __forceinline__ int clip16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int clip_index(int v) { return min(max(v, 0), 88); }
 
+// under-aligned wide accesses: gfx950 under HSA serves them in hardware, one instruction each
+struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t w[4]; };
+struct __attribute__((packed, aligned(1))) Bytes8 { uint32_t w[2]; };
+struct __attribute__((packed, aligned(2))) Pcm8 { uint32_t w[4]; };
+struct __attribute__((packed, aligned(2))) Pcm32 { uint32_t w[16]; };
+
+// the step table in LDS (indexed per lane on the critical path; a constant-memory table would be a
+// dependent global load per sample)
+__device__ __forceinline__ void load_steps(uint32_t* s_step) {
+    for (uint32_t i = threadIdx.x; i < 89u; i += blockDim.x) s_step[i] = (uint32_t)kImaStep[i];
+    __syncthreads();
+}
+
+// kImaIndexAdjust[nibble] = {-1,-1,-1,-1,2,4,6,8} on the magnitude bits
+__device__ __forceinline__ int index_adjust(uint32_t mag3) {
+    const int t = 2 * (int)mag3 - 6;
+    return t > 0 ? t : -1;
+}
+
 // AdpcmImaExpandNibble, AdpcmIma.c:170-204 with shift 3
-__device__ __forceinline__ int expand(int& predictor, int& index, uint32_t nibble) {
-    const int step = kImaStep[index];
-    index = clip_index(index + kImaIndexAdjust[nibble]);
+__device__ __forceinline__ int expand(int& predictor, int& index, uint32_t nibble, const uint32_t* s_step) {
+    const int step = (int)s_step[index];
+    index = clip_index(index + index_adjust(nibble & 7u));
     const int diff = ((2 * (int)(nibble & 7u) + 1) * step) >> 3;
     predictor = clip16((nibble & 8u) ? predictor - diff : predictor + diff);
     return predictor;
 }
 
-// adpcm_ima_compress_sample, adpcm.c:219-227
-__device__ __forceinline__ uint32_t compress(int& prev, int& index, int sample) {
+// adpcm_ima_compress_sample, adpcm.c:219-227.  min(7, |delta|*4/step) is taken bit by bit (the
+// classic IMA quantiser ladder: identical quotient, no integer division on the chain).
+__device__ __forceinline__ uint32_t compress(int& prev, int& index, int sample, const uint32_t* s_step) {
     const int delta = sample - prev;
-    const int step = kImaStep[index];
-    const int q = min(7, abs(delta) * 4 / step);
-    const uint32_t nibble = (uint32_t)q + (delta < 0 ? 8u : 0u);
-    const int mag = (step * (2 * q + 1)) / 8;   // step * yamaha_difflookup[nibble] / 8, C division
+    const uint32_t step = s_step[index];
+    uint32_t d4 = (uint32_t)abs(delta) << 2;
+    uint32_t q = 0;
+    if (d4 >= step * 4u) { q = 4u; d4 -= step * 4u; }
+    if (d4 >= step * 2u) { q |= 2u; d4 -= step * 2u; }
+    if (d4 >= step) q |= 1u;
+    const int mag = (int)((step * (2u * q + 1u)) >> 3);   // step * yamaha_difflookup[nibble] / 8
     prev = clip16(delta < 0 ? prev - mag : prev + mag);
-    index = clip_index(index + kImaIndexAdjust[nibble]);
-    return nibble;
+    index = clip_index(index + index_adjust(q));
+    return q + (delta < 0 ? 8u : 0u);
 }
+
+// a chunk's samples from (prev, index): 16 samples per 32-byte load pair, 8 bytes out.  m is even.
+template <bool kWrite>
+__device__ __forceinline__ void encode_run(const int16_t* __restrict__ x, uint32_t m, int& prev, int& index,
+                                           uint8_t* __restrict__ d, const uint32_t* s_step) {
+    uint32_t k = 0;
+    for (; k + 16u <= m; k += 16u) {
+        const Pcm8 a = *reinterpret_cast<const Pcm8*>(x + k);
+        const Pcm8 b = *reinterpret_cast<const Pcm8*>(x + k + 8u);
+        Bytes8 o;
+        o.w[0] = 0u;
+        o.w[1] = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t word = j < 8 ? a.w[j >> 1] : b.w[(j - 8) >> 1];
+            const int sample = (j & 1) ? ((int)word >> 16) : (int)(int16_t)(word & 0xffffu);
+            const uint32_t nib = compress(prev, index, sample, s_step);
+            o.w[j >> 3] |= nib << (8 * ((j >> 1) & 3) + ((j & 1) ? 0 : 4));   // :489-493 high nibble = earlier sample
+        }
+        if (kWrite) *reinterpret_cast<Bytes8*>(d + (k >> 1)) = o;
+    }
+    for (; k < m; k += 2u) {
+        const uint32_t hi = compress(prev, index, x[k], s_step);
+        const uint32_t lo = compress(prev, index, x[k + 1u], s_step);
+        if (kWrite) d[k >> 1] = (uint8_t)((hi << 4) | lo);
+    }
+}
+
+constexpr uint32_t kChainBlock = 256;   // chunks whose maps one workgroup composes through LDS (24 KB)
 
 }  // namespace
 
@@ -47,6 +105,8 @@ __global__ __launch_bounds__(64) void amv_adpcm_decode_kernel(
     const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offs,
     const uint32_t* __restrict__ lens, uint32_t n, int16_t* __restrict__ pcm,
     const uint64_t* __restrict__ pcm_offs, int32_t* __restrict__ final_state) {
+    __shared__ uint32_t s_step[96];
+    load_steps(s_step);
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n) return;
     const uint64_t off = offs[i];
@@ -56,10 +116,38 @@ __global__ __launch_bounds__(64) void amv_adpcm_decode_kernel(
     int predictor = (int16_t)(c[0] | (c[1] << 8));   // AMVDec.c:312
     int index = clip_index(c[2]);                    // AMVDec.c:313 (the reference indexes its table unchecked)
     int16_t* o = pcm + pcm_offs[i];
-    for (uint32_t k = 8; k < len; ++k) {             // AdpcmIma.c:225-237
-        const uint32_t byte = c[k];
-        *o++ = (int16_t)expand(predictor, index, byte >> 4);
-        *o++ = (int16_t)expand(predictor, index, byte & 15u);
+    const uint8_t* p = c + 8;
+    const uint32_t nb = len - 8u;
+    uint32_t k = 0;
+    for (; k + 16u <= nb; k += 16u) {                // AdpcmIma.c:225-237, 32 samples per trip
+        const Bytes16 in = *reinterpret_cast<const Bytes16*>(p + k);
+        Pcm32 out;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t nib[8];
+            int st[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {            // the index chain needs only the nibbles
+                nib[j] = (in.w[w] >> (8 * (j >> 1) + ((j & 1) ? 0 : 4))) & 15u;
+                st[j] = index;
+                index = clip_index(index + index_adjust(nib[j] & 7u));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st[j] = (int)s_step[st[j]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int diff = ((2 * (int)(nib[j] & 7u) + 1) * st[j]) >> 3;
+                predictor = clip16((nib[j] & 8u) ? predictor - diff : predictor + diff);
+                if (j & 1) out.w[4 * w + (j >> 1)] |= (uint32_t)predictor << 16;
+                else out.w[4 * w + (j >> 1)] = (uint32_t)predictor & 0xffffu;
+            }
+        }
+        *reinterpret_cast<Pcm32*>(o + 2u * k) = out;
+    }
+    for (; k < nb; ++k) {
+        const uint32_t byte = p[k];
+        o[2u * k] = (int16_t)expand(predictor, index, byte >> 4, s_step);
+        o[2u * k + 1u] = (int16_t)expand(predictor, index, byte & 15u, s_step);
     }
     if (final_state) { final_state[2 * i] = predictor; final_state[2 * i + 1] = index; }
 }
@@ -100,32 +188,87 @@ __global__ void amv_adpcm_wav_encode_kernel(const int16_t* __restrict__ x, int g
     state[1] = index;
 }
 
-// state-only run of chunk i from start index s: where does step_index end up?
-__global__ __launch_bounds__(128) void amv_adpcm_map_kernel(
+// state-only run of chunk i from start index s: where does step_index end up?  One lane per
+// (chunk, start) pair, pairs packed densely into waves.
+__global__ __launch_bounds__(64) void amv_adpcm_map_kernel(
     const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs,
     const uint32_t* __restrict__ nsamp, uint32_t n, uint8_t* __restrict__ map /* [n][96] */) {
-    const uint32_t i = blockIdx.x, s = threadIdx.x;
-    if (i >= n || s >= 89) return;
+    __shared__ uint32_t s_step[96];
+    load_steps(s_step);
+    const uint64_t pair = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    const uint32_t i = (uint32_t)(pair / 89u), s = (uint32_t)(pair % 89u);
+    if (i >= n) return;
     const int16_t* x = pcm + pcm_offs[i];
     const uint32_t m = nsamp[i] & ~1u;
     int prev = m ? x[0] : 0, index = (int)s;
-    for (uint32_t k = 0; k < m; ++k) compress(prev, index, x[k]);
-    map[i * 96u + s] = (uint8_t)index;
+    encode_run<false>(x, m, prev, index, nullptr, s_step);
+    map[(uint64_t)i * 96u + s] = (uint8_t)index;
 }
 
-__global__ void amv_adpcm_chain_kernel(const uint8_t* __restrict__ map, uint32_t n, int32_t* __restrict__ start) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t s = 0;   // the encoder context starts zeroed
-    for (uint32_t i = 0; i < n; ++i) {
-        start[i] = (int32_t)s;
-        s = map[i * 96u + s];
+// composition of the maps of kChainBlock consecutive chunks: bmap[b][s] = where start s ends up
+__global__ __launch_bounds__(128) void amv_adpcm_chain_block_kernel(const uint8_t* __restrict__ map, uint32_t n,
+                                                                    uint8_t* __restrict__ bmap) {
+    __shared__ uint32_t s_map[kChainBlock * 24u];
+    const uint32_t c0 = blockIdx.x * kChainBlock, cnt = min(kChainBlock, n - c0);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(map + (uint64_t)c0 * 96u);
+    for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x >= 89u) return;
+    const uint8_t* m8 = reinterpret_cast<const uint8_t*>(s_map);
+    uint32_t v = threadIdx.x;
+    for (uint32_t c = 0; c < cnt; ++c) v = m8[c * 96u + v];
+    bmap[(uint64_t)blockIdx.x * 96u + threadIdx.x] = (uint8_t)v;
+}
+
+// the serial walk over the workgroup maps (n / 256 steps through LDS): start index of every block
+__global__ __launch_bounds__(128) void amv_adpcm_chain_top_kernel(const uint8_t* __restrict__ bmap, uint32_t nb,
+                                                                  int32_t* __restrict__ bstart) {
+    __shared__ uint32_t s_map[kChainBlock * 24u];
+    uint32_t v = 0;   // the encoder context starts zeroed
+    for (uint32_t t0 = 0; t0 < nb; t0 += kChainBlock) {
+        const uint32_t cnt = min(kChainBlock, nb - t0);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(bmap + (uint64_t)t0 * 96u);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint8_t* m8 = reinterpret_cast<const uint8_t*>(s_map);
+            for (uint32_t c = 0; c < cnt; ++c) {
+                bstart[t0 + c] = (int32_t)v;
+                v = m8[c * 96u + v];
+            }
+        }
     }
+}
+
+// back down: start index of every chunk of a block from the block's start
+__global__ __launch_bounds__(128) void amv_adpcm_chain_fill_kernel(const uint8_t* __restrict__ map, uint32_t n,
+                                                                   const int32_t* __restrict__ bstart,
+                                                                   int32_t* __restrict__ start) {
+    __shared__ uint32_t s_map[kChainBlock * 24u];
+    __shared__ int32_t s_start[kChainBlock];
+    const uint32_t c0 = blockIdx.x * kChainBlock, cnt = min(kChainBlock, n - c0);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(map + (uint64_t)c0 * 96u);
+    for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint8_t* m8 = reinterpret_cast<const uint8_t*>(s_map);
+        uint32_t v = (uint32_t)bstart[blockIdx.x];
+        for (uint32_t c = 0; c < cnt; ++c) {
+            s_start[c] = (int32_t)v;
+            v = m8[c * 96u + v];
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < cnt; c += 128u) start[c0 + c] = s_start[c];
 }
 
 __global__ __launch_bounds__(64) void amv_adpcm_encode_kernel(
     const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs,
     const uint32_t* __restrict__ nsamp, uint32_t n, const int32_t* __restrict__ step_in,
     uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs) {
+    __shared__ uint32_t s_step[96];
+    load_steps(s_step);
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n) return;
     const int16_t* x = pcm + pcm_offs[i];
@@ -139,11 +282,7 @@ __global__ __launch_bounds__(64) void amv_adpcm_encode_kernel(
     d[3] = 0;
     const uint32_t cnt = pairs << 1;                // :479 le32 sample count
     d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
-    for (uint32_t k = 0; k < pairs; ++k) {          // :489-493 high nibble = earlier sample
-        const uint32_t hi = compress(prev, index, x[2 * k]);
-        const uint32_t lo = compress(prev, index, x[2 * k + 1]);
-        d[8 + k] = (uint8_t)((hi << 4) | lo);
-    }
+    encode_run<true>(x, cnt, prev, index, d + 8, s_step);
 }
 
 void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
@@ -160,10 +299,20 @@ void launch_adpcm_wav_encode(const int16_t* samples, int groups, int32_t* state,
 
 void launch_adpcm_map(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,
                       uint8_t* map, int32_t* start, hipStream_t s) {
+    // map: (n + nb) * 96 bytes, start: n + nb words, nb = adpcm_chain_blocks(n)
     if (n == 0) return;
-    hipLaunchKernelGGL(amv_adpcm_map_kernel, dim3(n), dim3(128), 0, s, pcm, pcm_offs, nsamp, n, map);
-    hipLaunchKernelGGL(amv_adpcm_chain_kernel, dim3(1), dim3(64), 0, s, map, n, start);
+    const uint32_t nb = adpcm_chain_blocks(n);
+    uint8_t* bmap = map + (uint64_t)n * 96u;
+    int32_t* bstart = start + n;
+    const uint64_t pairs = (uint64_t)n * 89u;
+    hipLaunchKernelGGL(amv_adpcm_map_kernel, dim3((uint32_t)((pairs + 63u) / 64u)), dim3(64), 0, s, pcm, pcm_offs, nsamp,
+                       n, map);
+    hipLaunchKernelGGL(amv_adpcm_chain_block_kernel, dim3(nb), dim3(128), 0, s, map, n, bmap);
+    hipLaunchKernelGGL(amv_adpcm_chain_top_kernel, dim3(1), dim3(128), 0, s, bmap, nb, bstart);
+    hipLaunchKernelGGL(amv_adpcm_chain_fill_kernel, dim3(nb), dim3(128), 0, s, map, n, bstart, start);
 }
+
+uint32_t adpcm_chain_blocks(uint32_t n) { return (n + kChainBlock - 1u) / kChainBlock; }
 
 void launch_adpcm_encode(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp,
                          uint32_t n, const int32_t* step_in, uint8_t* blob, const uint64_t* offs,

@@ -76,6 +76,7 @@ void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_
                          const uint32_t* lens, uint32_t n, int16_t* pcm, const uint64_t* pcm_offs,
                          int32_t* final_state, hipStream_t s);
 // 89-way state map of every chunk + serial walk of the maps -> start[i] (reference step_index carry)
+uint32_t adpcm_chain_blocks(uint32_t n);   // launch_adpcm_map needs map[(n + blocks) * 96] and start[n + blocks]
 void launch_adpcm_map(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,
                       uint8_t* map, int32_t* start, hipStream_t s);
 // amvlib's IMA-WAV-layout frame encoder (AdpcmIma.c:43-160), one lane

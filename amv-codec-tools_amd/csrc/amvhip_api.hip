@@ -510,8 +510,9 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
     std::lock_guard<std::mutex> lk(c->mu);
     Timed t(c, AMVHIP_K_ADPCM_ENC, (hipStream_t)stream);
     if (!d_step_in) {  // the reference's behaviour: step_index runs through the whole stream
-        if (int r = ensure(c, c->map, (size_t)n * 96)) return r;
-        if (int r = ensure(c, c->start, (size_t)n * 4)) return r;
+        const size_t slots = (size_t)n + adpcm_chain_blocks(n);
+        if (int r = ensure(c, c->map, slots * 96)) return r;
+        if (int r = ensure(c, c->start, slots * 4)) return r;
         launch_adpcm_map(d_pcm, d_pcm_offs, d_nsamp, n, (uint8_t*)c->map.p, (int32_t*)c->start.p, (hipStream_t)stream);
         d_step_in = (const int32_t*)c->start.p;
     }
