@@ -11,9 +11,9 @@
 // one uses amvlib's fixed tables (AmvJpeg.c:30-61) and a true -128 level shift so that amvlib
 // and the patched FFmpeg both decode it.
 //
-//   amv_forward_kernel  data parallel: one wave per MCU-row segment; colour conversion into
-//                       LDS planes, row and column DCT passes one 8-point transform per lane,
-//                       quantise + zig-zag, 128-byte lines out.
+//   amv_forward_kernel  data parallel: one wave per MCU-row segment; colour conversion of 4x2-pixel
+//                       patches into LDS planes, then one 8x8 block per lane held in registers:
+//                       row passes, column passes, quantise, scan order, one 128-byte line out.
 //   amv_pack_kernel     serial inside a frame (DC prediction + variable-length output), so
 //                       one lane per frame; a wave stages block b of its 64 frames in LDS with
 //                       whole-line loads and every lane codes its own block from there.
@@ -65,112 +65,180 @@ __device__ __forceinline__ void fdct8(int (&d)[8]) {
 
 }  // namespace
 
+namespace {
+
+struct __attribute__((packed, aligned(1))) Px12 { uint32_t w[3]; };   // four RGB pixels, any alignment
+
+// LDS plane pitches in samples: multiples of 8 (16-byte rows for ds_read_b128), padded so that the
+// two luma block rows of an MCU do not start on the same bank
+constexpr uint32_t kPitchY = kSegMcus * 16 + 8, kPitchC = kSegMcus * 8 + 8;
+
+// RGB_TO_Y / RGB_TO_U / RGB_TO_V of colorspace.h:78-88 with the channel order folded into the weights
+struct Weights { int y0, y2, u0, u2, v0, v2; };
+
+__device__ __forceinline__ int luma(const Weights& k, int c0, int c1, int c2) {
+    return ((k.y0 * c0 + 601 * c1 + k.y2 * c2 + 512) >> 10) - 128;
+}
+__device__ __forceinline__ int chroma_u(const Weights& k, int s0, int s1, int s2) {   // 2x2 sums, shift 2
+    return (k.u0 * s0 - 339 * s1 + k.u2 * s2 + 2047) >> 12;                           // +128 -128
+}
+__device__ __forceinline__ int chroma_v(const Weights& k, int s0, int s1, int s2) {
+    return (k.v0 * s0 - 429 * s1 + k.v2 * s2 + 2047) >> 12;
+}
+
+__device__ __forceinline__ void unpack12(const Px12& v, int (&b)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) b[i] = (int)((v.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+}
+
+}  // namespace
+
+// One wave per MCU-row segment of up to kSegMcus MCUs.
+//  1. colour conversion: every lane takes 4x2-pixel patches (two unaligned 12-byte loads), writes
+//     8 luma and 2+2 chroma samples into the LDS planes.  Bitstream row k is picture row h-1-k
+//     (mjpegenc.c:462-467); rows and columns outside the picture repeat the nearest edge sample.
+//  2. one lane per 8x8 block, the block in registers: 8 row passes, DCTELEM truncation, 8 column
+//     passes, dct_quantize_c, scan order (a compile-time permutation), one 128-byte line out.
 __global__ __launch_bounds__(kWave) void amv_forward_kernel(
     const uint8_t* __restrict__ pix, uint32_t pix_stride, int is_bgr, uint32_t n, FrameGeom g,
-    uint32_t nseg, uint32_t qbias, int16_t* __restrict__ coef) {
-    __shared__ __attribute__((aligned(16))) int16_t s_y[16 * kSegMcus * 16];
-    __shared__ __attribute__((aligned(16))) int16_t s_cb[8 * kSegMcus * 8];
-    __shared__ __attribute__((aligned(16))) int16_t s_cr[8 * kSegMcus * 8];
-    __shared__ __attribute__((aligned(16))) int16_t s_d[kSegMcus * 6 * 64];   // after the row pass
-    __shared__ __attribute__((aligned(16))) int16_t s_o[kSegMcus * 6 * 64];   // quantised, scan order
-    __shared__ int s_qmat[2][64];                                              // by scan position
+    uint32_t nseg, uint32_t per_seg, uint32_t qbias, int16_t* __restrict__ coef) {
+    __shared__ __attribute__((aligned(16))) int16_t s_y[16 * kPitchY];
+    __shared__ __attribute__((aligned(16))) int16_t s_cb[8 * kPitchC];
+    __shared__ __attribute__((aligned(16))) int16_t s_cr[8 * kPitchC];
 
-    constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;
     const uint32_t lane = threadIdx.x;
     uint32_t bid = blockIdx.x;
     const uint32_t seg = bid % nseg;
     bid /= nseg;
     const uint32_t my = bid % g.mcu_rows;
     const uint32_t f = bid / g.mcu_rows;
-    const uint32_t m0 = seg * kSegMcus;
-    const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
+    const uint32_t m0 = seg * per_seg;
+    if (m0 >= g.mcu_cols) return;          // very wide pictures: the balanced split can leave the last segment empty
+    const uint32_t cnt = min(per_seg, g.mcu_cols - m0);
     const uint32_t nb = cnt * 6;
-    const uint32_t w = g.width, h = g.height, cw = w >> 1, ch = h >> 1;
+    const uint32_t w = g.width, h = g.height, cw = w >> 1;
     const uint8_t* src = pix + (uint64_t)f * pix_stride * h;
-    const int ro = is_bgr ? 2 : 0, bo = is_bgr ? 0 : 2;
+    const Weights k = is_bgr ? Weights{117, 306, 512, -173, -83, 512} : Weights{306, 117, -173, 512, 512, -83};
 
-    // ff_convert_matrix (mpegvideo_enc.c:80-91) with qscale 8: (1<<22)/(8*Q); [0] unused (DC)
-    s_qmat[0][lane] = (int)((1u << 22) / (8u * kQuantLuma[lane]));
-    s_qmat[1][lane] = (int)((1u << 22) / (8u * kQuantChroma[lane]));
-
-    // luma plane of this segment.  Bitstream row k is picture row h-1-k (mjpegenc.c:462-467);
-    // rows and columns outside the picture repeat the nearest edge sample.
-    for (uint32_t t = lane; t < 16 * cnt * 16; t += kWave) {
-        const uint32_t i = t / (cnt * 16), j = t % (cnt * 16);
-        const uint32_t k = my * 16 + i, c = m0 * 16 + j;
-        const uint32_t sy = k < h ? h - 1 - k : 0, sx = c < w ? c : w - 1;
-        const uint8_t* p = src + (uint64_t)sy * pix_stride + sx * 3u;
-        const int r = p[ro], gg = p[1], b = p[bo];
-        s_y[i * kPitchY + j] = (int16_t)(((306 * r + 601 * gg + 117 * b + 512) >> 10) - 128);  // RGB_TO_Y colorspace.h:78-80
-    }
-    // chroma planes: 2x2 sums (imgconvert_template.h:668-695, RGB_TO_U/V colorspace.h:82-88, shift 2)
-    for (uint32_t t = lane; t < 8 * cnt * 8; t += kWave) {
-        const uint32_t i = t / (cnt * 8), j = t % (cnt * 8);
-        const uint32_t k = my * 8 + i, c = m0 * 8 + j;
-        const uint32_t sy = k < ch ? ch - 1 - k : 0, sx = c < cw ? c : cw - 1;
-        const uint8_t* p0 = src + (uint64_t)(2 * sy) * pix_stride + (2 * sx) * 3u;
-        const uint8_t* p1 = p0 + pix_stride;
-        const int r1 = p0[ro] + p0[3 + ro] + p1[ro] + p1[3 + ro];
-        const int g1 = p0[1] + p0[4] + p1[1] + p1[4];
-        const int b1 = p0[bo] + p0[3 + bo] + p1[bo] + p1[3 + bo];
-        s_cb[i * kPitchC + j] = (int16_t)((-173 * r1 - 339 * g1 + 512 * b1 + 2047) >> 12);         // +128 -128
-        s_cr[i * kPitchC + j] = (int16_t)((512 * r1 - 429 * g1 - 83 * b1 + 2047) >> 12);
+    const uint32_t d4 = cnt * 4u, inv = (65536u + d4 - 1u) / d4;   // t / d4 == (t * inv) >> 16 for t < 8 * d4 <= 320
+    for (uint32_t t = lane; t < 8u * d4; t += kWave) {
+        const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
+        const uint32_t k0 = my * 16u + 2u * i2;                    // bitstream rows k0, k0 + 1
+        const bool inside = k0 < h;                                // h is even
+        const uint32_t row_a = inside ? h - 1u - k0 : 1u, row_b = inside ? h - 2u - k0 : 0u;
+        const uint32_t c = m0 * 16u + 4u * p;
+        const uint8_t* pa = src + (uint64_t)row_a * pix_stride;
+        const uint8_t* pb = src + (uint64_t)row_b * pix_stride;
+        int ya[4], yb[4], u[2], v[2];
+        if (c + 3u < w) {
+            int a[12], b[12];
+            unpack12(*reinterpret_cast<const Px12*>(pa + c * 3u), a);
+            unpack12(*reinterpret_cast<const Px12*>(pb + c * 3u), b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ya[q] = luma(k, a[3 * q], a[3 * q + 1], a[3 * q + 2]);
+                yb[q] = luma(k, b[3 * q], b[3 * q + 1], b[3 * q + 2]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int s0 = a[6 * e] + a[6 * e + 3] + b[6 * e] + b[6 * e + 3];
+                const int s1 = a[6 * e + 1] + a[6 * e + 4] + b[6 * e + 1] + b[6 * e + 4];
+                const int s2 = a[6 * e + 2] + a[6 * e + 5] + b[6 * e + 2] + b[6 * e + 5];
+                u[e] = chroma_u(k, s0, s1, s2);
+                v[e] = chroma_v(k, s0, s1, s2);
+            }
+        } else {                                                   // right edge of a picture whose width is not 0 mod 16
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = min(c + (uint32_t)q, w - 1u) * 3u;
+                ya[q] = luma(k, pa[x], pa[x + 1], pa[x + 2]);
+                yb[q] = luma(k, pb[x], pb[x + 1], pb[x + 2]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t x = min((c >> 1) + (uint32_t)e, cw - 1u) * 6u;
+                const int s0 = pa[x] + pa[x + 3] + pb[x] + pb[x + 3];
+                const int s1 = pa[x + 1] + pa[x + 4] + pb[x + 1] + pb[x + 4];
+                const int s2 = pa[x + 2] + pa[x + 5] + pb[x + 2] + pb[x + 5];
+                u[e] = chroma_u(k, s0, s1, s2);
+                v[e] = chroma_v(k, s0, s1, s2);
+            }
+        }
+        if (!inside) {                                             // below the picture: luma repeats picture row 0
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ya[q] = yb[q];
+        }
+        uint2 la, lb;
+        la.x = ((uint32_t)ya[0] & 0xffffu) | ((uint32_t)ya[1] << 16);
+        la.y = ((uint32_t)ya[2] & 0xffffu) | ((uint32_t)ya[3] << 16);
+        lb.x = ((uint32_t)yb[0] & 0xffffu) | ((uint32_t)yb[1] << 16);
+        lb.y = ((uint32_t)yb[2] & 0xffffu) | ((uint32_t)yb[3] << 16);
+        *reinterpret_cast<uint2*>(s_y + (2u * i2) * kPitchY + 4u * p) = la;
+        *reinterpret_cast<uint2*>(s_y + (2u * i2 + 1u) * kPitchY + 4u * p) = lb;
+        *reinterpret_cast<uint32_t*>(s_cb + i2 * kPitchC + 2u * p) = ((uint32_t)u[0] & 0xffffu) | ((uint32_t)u[1] << 16);
+        *reinterpret_cast<uint32_t*>(s_cr + i2 * kPitchC + 2u * p) = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
     }
     __syncthreads();
+    if (lane >= nb) return;
 
-    // row pass (get_pixels + row_fdct): one (block, row) per lane
-    for (uint32_t t = lane; t < nb * 8; t += kWave) {
-        const uint32_t blk = t >> 3, r = t & 7u, m = blk / 6u, k6 = blk % 6u;
-        const int16_t* in = k6 < 4 ? s_y + ((k6 >> 1) * 8u + r) * kPitchY + m * 16u + (k6 & 1u) * 8u
-                                   : (k6 == 4 ? s_cb : s_cr) + r * kPitchC + m * 8u;
-        int d[8];
+    const uint32_t m = lane / 6u, k6 = lane - 6u * m;
+    const bool is_c = k6 >= 4u;
+    const int16_t* in = is_c ? (k6 == 4u ? s_cb : s_cr) + m * 8u
+                             : s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u;
+    const uint32_t pitch = is_c ? kPitchC : kPitchY;
+    int d[8][8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) d[c] = in[c];
-        fdct8<0>(d);
-        int16_t* o = s_d + blk * 64u + r * 8u;
+    for (int r = 0; r < 8; ++r) {                                  // get_pixels + row_fdct
+        const uint4 q = *reinterpret_cast<const uint4*>(in + r * pitch);
+        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (int16_t)d[c];   // DCTELEM is 16 bit (dsputil.h:38)
+        for (int c = 0; c < 8; ++c) d[r][c] = (c & 1) ? ((int)ws[c >> 1] >> 16) : (int)(int16_t)(ws[c >> 1] & 0xffffu);
+        fdct8<0>(d[r]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) d[r][c] = (int16_t)d[r][c];    // DCTELEM is 16 bit (dsputil.h:38)
     }
-    __syncthreads();
-
-    // column pass + dct_quantize_c: one (block, column) per lane
     const int bias = (int)(qbias << 14);   // intra_quant_bias << (QMAT_SHIFT - QUANT_BIAS_SHIFT), :3679
-    for (uint32_t t = lane; t < nb * 8; t += kWave) {
-        const uint32_t blk = t >> 3, c = t & 7u, cls = (blk % 6u) >= 4u ? 1u : 0u;
-        int d[8];
+    uint32_t out[32];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) d[r] = s_d[blk * 64u + r * 8u + c];
-        fdct8<1>(d);
-        int16_t* o = s_o + blk * 64u;
+    for (int i = 0; i < 32; ++i) out[i] = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                                  // column pass + dct_quantize_c
+        int col[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) col[r] = d[r][c];
+        fdct8<1>(col);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const uint32_t scan = kScanOfNatural[r * 8 + c];
-            const int x = (int16_t)d[r];
+            const int scan = kScanOfNatural[r * 8 + c];
+            const int x = (int16_t)col[r];
             int a;
             if (r == 0 && c == 0) {        // DC: (block[0] + q/2) / q with q = 8 * step, :3670-3676
-                const int q = cls ? 8 * kQuantChroma[0] : 8 * kQuantLuma[0];
-                a = (abs(x) + (q >> 1)) / q;
-            } else {                       // AC: (bias + |level|) >> QMAT_SHIFT, :3702-3712
-                const int level = x * s_qmat[cls][scan];
+                constexpr int ql = 8 * kQuantLuma[0], qc = 8 * kQuantChroma[0];
+                const int ax = abs(x);
+                a = is_c ? (ax + (qc >> 1)) / qc : (ax + (ql >> 1)) / ql;
+            } else {                       // AC: (bias + |level|) >> QMAT_SHIFT with ff_convert_matrix's
+                                           // (1<<22)/(8*Q) (mpegvideo_enc.c:80-91, qscale 8), :3702-3712
+                const int ml = (int)((1u << 22) / (8u * kQuantLuma[scan])), mc = (int)((1u << 22) / (8u * kQuantChroma[scan]));
+                const int level = x * (is_c ? mc : ml);
                 a = (abs(level) + bias) >> 22;
             }
-            o[scan] = (int16_t)(x < 0 ? -a : a);
+            const uint32_t val = (uint32_t)(x < 0 ? -a : a) & 0xffffu;
+            out[scan >> 1] |= val << (16 * (scan & 1));
         }
     }
-    __syncthreads();
-
-    uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)f * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u);
-    const uint4* so = reinterpret_cast<const uint4*>(s_o);
-    for (uint32_t i = lane; i < nb * 8; i += kWave) dst[i] = so[i];
+    uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)f * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u + lane * 64u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
 }
 
 void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n,
                     const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s) {
     if (n == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
+    const uint32_t per_seg = (g.mcu_cols + nseg - 1) / nseg;      // balanced: 11 columns -> 6 + 5
     const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
     hipLaunchKernelGGL(amv_forward_kernel, dim3((uint32_t)grid), dim3(kWave), 0, s, pix, pix_stride,
-                       is_bgr, n, g, nseg, qbias, coef);
+                       is_bgr, n, g, nseg, per_seg, qbias, coef);
 }
 
 // ============================================================================================
