@@ -96,11 +96,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t s_out[16 * kPitchOut];
 
     const uint32_t lane = threadIdx.x;
-    uint32_t bid = blockIdx.x;
-    const uint32_t seg = bid % nseg;
-    bid /= nseg;
-    const uint32_t my = bid % g.mcu_rows;
-    const uint32_t f = bid / g.mcu_rows;
+    const uint32_t f = blockIdx.x, my = blockIdx.y, seg = blockIdx.z;   // no integer division to find them
     const uint32_t m0 = seg * kSegMcus;
     const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
     const uint32_t nb = cnt * 6;
@@ -166,7 +162,9 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
 #pragma unroll
         for (int col = 0; col < 8; ++col)
             idct8<true>(v[col], v[8 + col], v[16 + col], v[24 + col], v[32 + col], v[40 + col], v[48 + col], v[56 + col]);
-        // GetYUV (AmvJpeg.c:754-787) + the +128 of IQtIZzBlock (:1023,1047): one 16-byte row at a time
+        // GetYUV (AmvJpeg.c:754-787) + the +128 of IQtIZzBlock (:1023,1047): one 16-byte row at a time.
+        // (The +128 cannot ride through the column pass on the DC term: the reference's 32-bit arithmetic
+        // wraps on absurd coefficients, and the parity tests hold the kernel to that.)
         const int offset = chroma ? 0 : 128;
         int16_t* dst = chroma ? (k6 == 4u ? s_u : s_v) + m * 8u
                               : s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u;
@@ -176,9 +174,9 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
             uint32_t w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t lo = (uint32_t)(clamp_iclp(v[8 * r + 2 * q]) + offset) & 0xffffu;
-                const uint32_t hi = (uint32_t)(clamp_iclp(v[8 * r + 2 * q + 1]) + offset) & 0xffffu;
-                w[q] = lo | (hi << 16);
+                const int lo = clamp_iclp(v[8 * r + 2 * q]) + offset;
+                const int hi = clamp_iclp(v[8 * r + 2 * q + 1]) + offset;
+                w[q] = __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);   // low halves: lo | hi << 16
             }
             *reinterpret_cast<uint4*>(dst + r * pitch) = make_uint4(w[0], w[1], w[2], w[3]);
         }
@@ -187,33 +185,52 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
 
     // ---- D: StoreBuffer (AmvJpeg.c:789-840) into the staged image.  Picture row my*16+i lands in
     // destination row H-1-(my*16+i) (:800): staged slot vr-1-i, so that slots ascend in memory.
-    const uint32_t vr = min(16u, g.height - my * 16u);                 // rows of this MCU row inside the picture (:798)
+    // A lane takes a 4x2-pixel patch: the two rows share their chroma samples, whose three products
+    // (:808-810) are formed once; (y*256 + c) >> 8 == y + (c >> 8) exactly, so a pixel costs an add
+    // and a clamp per channel.  MCUs that were not decoded get y = -1024, c = 0: every channel clamps to 0.
+    const uint32_t vr = min(16u, g.height - my * 16u);                 // rows of this MCU row inside the picture (:798); even
     const uint32_t px = min(cnt * 16u, g.width - m0 * 16u);            // pixels of this segment inside it (:803)
     const uint32_t groups = cnt * 4u;
-    for (uint32_t t = lane; t < vr * groups; t += kWave) {
-        const uint32_t i = t / groups, gi = t % groups, lc = gi * 4u;
+    const uint32_t inv_groups = (65536u + groups - 1u) / groups;       // t / groups == (t * inv) >> 16 for t < 8 * 40
+    for (uint32_t t = lane; t < ((vr + 1u) >> 1) * groups; t += kWave) {
+        const uint32_t i2 = (t * inv_groups) >> 16, gi = t - i2 * groups, lc = gi * 4u;
         const bool decoded = (my * g.mcu_cols + m0 + (gi >> 2)) < ok;
-        const uint2 yy = *reinterpret_cast<const uint2*>(s_y + i * kPitchY + lc);
-        const uint32_t uu = *reinterpret_cast<const uint32_t*>(s_u + (i >> 1) * kPitchC + (lc >> 1));
-        const uint32_t vv = *reinterpret_cast<const uint32_t*>(s_v + (i >> 1) * kPitchC + (lc >> 1));
-        uint32_t b[12];
+        uint2 ya = *reinterpret_cast<const uint2*>(s_y + (2u * i2) * kPitchY + lc);
+        uint2 yb = *reinterpret_cast<const uint2*>(s_y + (2u * i2 + 1u) * kPitchY + lc);
+        uint32_t uu = *reinterpret_cast<const uint32_t*>(s_u + i2 * kPitchC + (lc >> 1));
+        uint32_t vv = *reinterpret_cast<const uint32_t*>(s_v + i2 * kPitchC + (lc >> 1));
+        constexpr uint32_t kDark = 0xfc00fc00u;                        // two int16 of -1024
+        ya.x = decoded ? ya.x : kDark; ya.y = decoded ? ya.y : kDark;
+        yb.x = decoded ? yb.x : kDark; yb.y = decoded ? yb.y : kDark;
+        uu = decoded ? uu : 0u;
+        vv = decoded ? vv : 0u;
+        int cr[2], cg[2], cb[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t yw = j < 2 ? yy.x : yy.y;
-            const int y = (j & 1) ? ((int)yw >> 16) : (int)(int16_t)(yw & 0xffffu);
-            const int u = j < 2 ? (int)(int16_t)(uu & 0xffffu) : ((int)uu >> 16);
-            const int w = j < 2 ? (int)(int16_t)(vv & 0xffffu) : ((int)vv >> 16);
-            const int rr = (y * 256 + 18 * u + 367 * w) >> 8;    // :808-810
-            const int gg = (y * 256 - 159 * u - 220 * w) >> 8;
-            const int bb = (y * 256 + 411 * u - 29 * w) >> 8;
-            b[3 * j + 0] = decoded ? clamp_u8(bb) : 0u;          // :829-831 B,G,R
-            b[3 * j + 1] = decoded ? clamp_u8(gg) : 0u;
-            b[3 * j + 2] = decoded ? clamp_u8(rr) : 0u;
+        for (int e = 0; e < 2; ++e) {
+            const int u = e ? ((int)uu >> 16) : (int)(int16_t)(uu & 0xffffu);
+            const int w = e ? ((int)vv >> 16) : (int)(int16_t)(vv & 0xffffu);
+            cr[e] = (18 * u + 367 * w) >> 8;                         // :808-810
+            cg[e] = (-159 * u - 220 * w) >> 8;
+            cb[e] = (411 * u - 29 * w) >> 8;
         }
-        uint32_t* d32 = reinterpret_cast<uint32_t*>(s_out + (vr - 1u - i) * kPitchOut + lc * 3u);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            d32[q] = b[4 * q] | (b[4 * q + 1] << 8) | (b[4 * q + 2] << 16) | (b[4 * q + 3] << 24);
+        for (int row = 0; row < 2; ++row) {
+            const uint2 yy = row ? yb : ya;
+            uint32_t b[12];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t yw = j < 2 ? yy.x : yy.y;
+                const int y = (j & 1) ? ((int)yw >> 16) : (int)(int16_t)(yw & 0xffffu);
+                b[3 * j + 0] = clamp_u8(y + cb[j >> 1]);               // :829-831 B,G,R
+                b[3 * j + 1] = clamp_u8(y + cg[j >> 1]);
+                b[3 * j + 2] = clamp_u8(y + cr[j >> 1]);
+            }
+            if (2u * i2 + (uint32_t)row >= vr) break;                      // odd picture height: the last pair has one row
+            uint32_t* d32 = reinterpret_cast<uint32_t*>(s_out + (vr - 1u - 2u * i2 - (uint32_t)row) * kPitchOut + lc * 3u);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                d32[q] = b[4 * q] | (b[4 * q + 1] << 8) | (b[4 * q + 2] << 16) | (b[4 * q + 3] << 24);
+        }
     }
     __syncthreads();
 
@@ -221,9 +238,10 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     uint8_t* dst0 = out + (uint64_t)f * g.frame_bytes + (uint64_t)(g.height - my * 16u - vr) * g.stride + m0 * 48u;
     const uint32_t row_bytes = px * 3u;
     if (kVec16) {   // stride, frame size and base are multiples of 16: whole 16-byte chunks, then the tail
-        const uint32_t chunks = row_bytes >> 4;
+        const uint32_t chunks = row_bytes >> 4;                        // <= 30
+        const uint32_t inv_chunks = chunks ? (65536u + chunks - 1u) / chunks : 0u;
         for (uint32_t t = lane; t < vr * chunks; t += kWave) {
-            const uint32_t s = t / chunks, ch = t % chunks;
+            const uint32_t s = (t * inv_chunks) >> 16, ch = t - s * chunks;
             *reinterpret_cast<uint4*>(dst0 + (uint64_t)s * g.stride + ch * 16u) =
                 *reinterpret_cast<const uint4*>(s_out + s * kPitchOut + ch * 16u);
         }
@@ -233,9 +251,10 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
             dst0[(uint64_t)s * g.stride + o] = s_out[s * kPitchOut + o];
         }
     } else {        // rows are only 4-byte aligned (AmvJpeg.c:1524): dwords, then the tail
-        const uint32_t words = row_bytes >> 2;
+        const uint32_t words = row_bytes >> 2;                         // <= 120
+        const uint32_t inv_words = words ? (65536u + words - 1u) / words : 0u;
         for (uint32_t t = lane; t < vr * words; t += kWave) {
-            const uint32_t s = t / words, wd = t % words;
+            const uint32_t s = (t * inv_words) >> 16, wd = t - s * words;
             *reinterpret_cast<uint32_t*>(dst0 + (uint64_t)s * g.stride + wd * 4u) =
                 *reinterpret_cast<const uint32_t*>(s_out + s * kPitchOut + wd * 4u);
         }
@@ -251,13 +270,13 @@ void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
     if (n == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
-    const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
+    const dim3 grid(n, g.mcu_rows, nseg);
     const bool vec16 = (g.stride % 16u) == 0 && (g.frame_bytes % 16u) == 0 && ((uintptr_t)out % 16u) == 0;
     if (vec16)
-        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, dim3((uint32_t)grid), dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
+        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, grid, dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
                            nseg, flags, out);
     else
-        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, dim3((uint32_t)grid), dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
+        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, grid, dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
                            nseg, flags, out);
 }
 

@@ -19,6 +19,7 @@ ap.add_argument("--width", type=int, default=160)
 ap.add_argument("--height", type=int, default=120)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--serial", action="store_true")
+ap.add_argument("--same", type=int, default=-1, help="every frame of the batch is a copy of this frame (no spread in sync rounds)")
 a = ap.parse_args()
 pkg = entry.load_package()
 ctx = pkg.Context(0)
@@ -39,6 +40,9 @@ for lo in range(0, n, 2000):
     torch.cuda.synchronize()
     offs[lo:lo + cnt] = toffs[:cnt] + pos
     pos = (int(offs[lo + cnt - 1]) + int(lens[lo + cnt - 1]) + 3) & ~3
+if a.same >= 0:
+    offs[:] = offs[a.same].clone()
+    lens[:] = lens[a.same].clone()
 nblk = ((w + 15) // 16) * ((h + 15) // 16) * 6
 coef = torch.empty((n, nblk, 64), dtype=torch.int16, device=dev)
 st = torch.empty(n, dtype=torch.int32, device=dev)
