@@ -10,11 +10,11 @@
 //      one select for amvlib's [3][4] table entry), dequantisation one multiply per coefficient,
 //      then 8 row transforms and 8 column transforms with the reference's exact integer
 //      arithmetic -- no transposition, no LDS between the passes;
-//   C. results go to 16-row Y and 8-row U/V planes in LDS (one 16-byte store per block row);
-//   D. colour conversion, 4 pixels per lane step, into an LDS image of the destination rows in
-//      MEMORY order (the picture is stored bottom-up, so the segment's rows are one run of
-//      consecutive destination rows);
-//   E. that image goes out as 16-byte stores, 1 KiB per wave instruction, whole lines only.
+//   C. results go to 16-row Y and 8-row U/V planes in LDS (one 16-byte store per block row; the
+//      planes reuse the space of the records' image, which every lane has read by then);
+//   D. colour conversion of a 4x2-pixel patch per lane step; the 12 bytes of each patch row go
+//      straight to the frame (the lanes of a step cover consecutive 12-byte pieces of a row, so a
+//      wave store is one contiguous run; the picture is stored bottom-up, AmvJpeg.c:800).
 //
 // Pixels of MCUs at or after a frame's first decode error are zero (AMVDec.c:283 + the reference
 // stopping at the error).  Compiled with -fwrapv, as the reference's arithmetic wraps.
@@ -23,6 +23,8 @@
 namespace amv {
 
 namespace {
+
+struct __attribute__((aligned(4))) Px12 { uint32_t w[3]; };   // four BGR pixels
 
 constexpr int kWave = 64;
 constexpr int kSegMcus = 10;   // MCUs per wave: 60 of 64 lanes busy in the transform
@@ -83,17 +85,17 @@ __device__ __forceinline__ int coef_at(const uint32_t (&c)[32], int i) {
 
 }  // namespace
 
-template <bool kVec16>
 __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n,
     FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
     const int16_t* __restrict__ coef = in.coef;
     constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;   // int16 units
-    constexpr uint32_t kPitchOut = kSegMcus * 48;                            // bytes per staged row
-    __shared__ __attribute__((aligned(16))) int16_t s_y[16 * kPitchY];
-    __shared__ __attribute__((aligned(16))) int16_t s_u[8 * kPitchC];
-    __shared__ __attribute__((aligned(16))) int16_t s_v[8 * kPitchC];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[16 * kPitchOut];
+    // 7 680 bytes: first the records' image of the 60 blocks (128 bytes each), then the three planes
+    __shared__ __attribute__((aligned(16))) int16_t s_mem[16 * kPitchY + 2 * 8 * kPitchC];
+    int16_t* const s_y = s_mem;
+    int16_t* const s_u = s_mem + 16 * kPitchY;
+    int16_t* const s_v = s_u + 8 * kPitchC;
+    uint8_t* const s_img = reinterpret_cast<uint8_t*>(s_mem);
 
     const uint32_t lane = threadIdx.x;
     const uint32_t f = blockIdx.x, my = blockIdx.y, seg = blockIdx.z;   // no integer division to find them
@@ -104,15 +106,15 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     const uint32_t ok = nmcu_ok[f];
     const uint32_t mcu0 = my * g.mcu_cols + m0;                       // first MCU of this segment
     const bool records = in.rec != nullptr && in.rec_count[f] != 0xffffffffu;
-    if (records) {   // records -> dense image of the segment's blocks in LDS (s_out is free until phase D)
-        uint4* img16 = reinterpret_cast<uint4*>(s_out);
+    if (records) {   // records -> dense image of the segment's blocks in LDS
+        uint4* img16 = reinterpret_cast<uint4*>(s_img);
         for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
         const uint32_t* ms = in.mcu_start + (uint64_t)f * (g.mcus + 1u);
         const uint32_t r0 = ms[mcu0], r1 = ms[mcu0 + cnt_ok];
         const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec;
-        int16_t* img = reinterpret_cast<int16_t*>(s_out);
+        int16_t* img = reinterpret_cast<int16_t*>(s_img);
         for (uint32_t r = r0 + lane; r < r1; r += kWave) {
             const uint32_t w = rec[r];
             const uint32_t b = ((w >> 6) & 0x3fffu) - mcu0 * 6u, k = w & 63u;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
         const bool chroma = k6 >= 4u;
         uint32_t c[32];
         if (records) {
-            const uint4* src = reinterpret_cast<const uint4*>(s_out) + lane * 8u;
+            const uint4* src = reinterpret_cast<const uint4*>(s_img) + lane * 8u;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const uint4 q = src[(uint32_t)i ^ (lane & 7u)];
@@ -183,9 +185,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     }
     __syncthreads();
 
-    // ---- D: StoreBuffer (AmvJpeg.c:789-840) into the staged image.  Picture row my*16+i lands in
-    // destination row H-1-(my*16+i) (:800): staged slot vr-1-i, so that slots ascend in memory.
-    // A lane takes a 4x2-pixel patch: the two rows share their chroma samples, whose three products
+    // ---- D: StoreBuffer (AmvJpeg.c:789-840), straight to the frame.  A lane takes a 4x2-pixel patch: the two rows share their chroma samples, whose three products
     // (:808-810) are formed once; (y*256 + c) >> 8 == y + (c >> 8) exactly, so a pixel costs an add
     // and a clamp per channel.  MCUs that were not decoded get y = -1024, c = 0: every channel clamps to 0.
     const uint32_t vr = min(16u, g.height - my * 16u);                 // rows of this MCU row inside the picture (:798); even
@@ -225,43 +225,22 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
                 b[3 * j + 1] = clamp_u8(y + cg[j >> 1]);
                 b[3 * j + 2] = clamp_u8(y + cr[j >> 1]);
             }
-            if (2u * i2 + (uint32_t)row >= vr) break;                      // odd picture height: the last pair has one row
-            uint32_t* d32 = reinterpret_cast<uint32_t*>(s_out + (vr - 1u - 2u * i2 - (uint32_t)row) * kPitchOut + lc * 3u);
+            const uint32_t i = 2u * i2 + (uint32_t)row;                    // row inside the MCU row
+            if (i >= vr || lc >= px) break;                                // odd picture height / right of the picture
+            // picture row my*16+i is destination row H-1-(my*16+i) (:800)
+            uint8_t* d8 = out + (uint64_t)f * g.frame_bytes + (uint64_t)(g.height - 1u - my * 16u - i) * g.stride +
+                          (m0 * 16u + lc) * 3u;
+            if (lc + 4u <= px) {                                           // rows are 4-byte aligned (AmvJpeg.c:1524), lc*3 is 0 mod 4
+                Px12 v;
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                d32[q] = b[4 * q] | (b[4 * q + 1] << 8) | (b[4 * q + 2] << 16) | (b[4 * q + 3] << 24);
-        }
-    }
-    __syncthreads();
-
-    // ---- E: staged rows -> destination rows [H - my*16 - vr, H - my*16), bytes [m0*48, m0*48 + px*3)
-    uint8_t* dst0 = out + (uint64_t)f * g.frame_bytes + (uint64_t)(g.height - my * 16u - vr) * g.stride + m0 * 48u;
-    const uint32_t row_bytes = px * 3u;
-    if (kVec16) {   // stride, frame size and base are multiples of 16: whole 16-byte chunks, then the tail
-        const uint32_t chunks = row_bytes >> 4;                        // <= 30
-        const uint32_t inv_chunks = chunks ? (65536u + chunks - 1u) / chunks : 0u;
-        for (uint32_t t = lane; t < vr * chunks; t += kWave) {
-            const uint32_t s = (t * inv_chunks) >> 16, ch = t - s * chunks;
-            *reinterpret_cast<uint4*>(dst0 + (uint64_t)s * g.stride + ch * 16u) =
-                *reinterpret_cast<const uint4*>(s_out + s * kPitchOut + ch * 16u);
-        }
-        const uint32_t tail = row_bytes & 15u;
-        for (uint32_t t = lane; t < vr * tail; t += kWave) {
-            const uint32_t s = t / tail, o = (row_bytes & ~15u) + t % tail;
-            dst0[(uint64_t)s * g.stride + o] = s_out[s * kPitchOut + o];
-        }
-    } else {        // rows are only 4-byte aligned (AmvJpeg.c:1524): dwords, then the tail
-        const uint32_t words = row_bytes >> 2;                         // <= 120
-        const uint32_t inv_words = words ? (65536u + words - 1u) / words : 0u;
-        for (uint32_t t = lane; t < vr * words; t += kWave) {
-            const uint32_t s = (t * inv_words) >> 16, wd = t - s * words;
-            *reinterpret_cast<uint32_t*>(dst0 + (uint64_t)s * g.stride + wd * 4u) =
-                *reinterpret_cast<const uint32_t*>(s_out + s * kPitchOut + wd * 4u);
-        }
-        const uint32_t tail = row_bytes & 3u;
-        for (uint32_t t = lane; t < vr * tail; t += kWave) {
-            const uint32_t s = t / tail, o = (row_bytes & ~3u) + t % tail;
-            dst0[(uint64_t)s * g.stride + o] = s_out[s * kPitchOut + o];
+                for (int q = 0; q < 3; ++q)
+                    v.w[q] = b[4 * q] | (b[4 * q + 1] << 8) | (b[4 * q + 2] << 16) | (b[4 * q + 3] << 24);
+                *reinterpret_cast<Px12*>(d8) = v;
+            } else {                                                       // the picture's last 1-3 pixels
+#pragma unroll
+                for (uint32_t q = 0; q < 9u; ++q)
+                    if (q < (px - lc) * 3u) d8[q] = (uint8_t)b[q];
+            }
         }
     }
 }
@@ -270,14 +249,8 @@ void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
     if (n == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
-    const dim3 grid(n, g.mcu_rows, nseg);
-    const bool vec16 = (g.stride % 16u) == 0 && (g.frame_bytes % 16u) == 0 && ((uintptr_t)out % 16u) == 0;
-    if (vec16)
-        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, grid, dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
-                           nseg, flags, out);
-    else
-        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, grid, dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
-                           nseg, flags, out);
+    hipLaunchKernelGGL(amv_reconstruct_kernel, dim3(n, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok, n, g, nseg,
+                       flags, out);
 }
 
 }  // namespace amv
