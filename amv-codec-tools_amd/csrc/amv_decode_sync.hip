@@ -46,7 +46,9 @@ namespace amv {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWaves = 4;                 // waves per workgroup (they share only the tables)
+constexpr int kMaxWaves = 10;             // waves per workgroup (they share only the tables); the launch takes as many as
+                                          // the CU's LDS holds pools for, so that one workgroup fills a CU
+constexpr uint32_t kLdsPerCu = 160u * 1024u;
 constexpr uint32_t kNever = 0xffffffffu;
 constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + 4u * kLut2PagesPerTable * (1u << kLut2Bits) * 2u;
 
@@ -357,7 +359,7 @@ struct SyncOut {
 // With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).  Frames
 // whose words do not fit what is left of their wave's pool are appended to defer_list.
 template <int L, bool kRec>
-__global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
+__global__ __launch_bounds__(kWave* kMaxWaves) void amv_huffman_sync_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
     uint32_t blocks_per_frame, uint32_t cap_words, uint32_t pool_bytes,
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
     {   // tables, shared by the four waves
         const uint4* src = reinterpret_cast<const uint4*>(&img->m1[0][0]);
         uint4* dst = reinterpret_cast<uint4*>(s_mem);
-        for (uint32_t i = threadIdx.x; i < kTableBytes / 16u; i += kWave * kWaves) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < kTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
     if (list) n = *list_count;
@@ -538,12 +540,20 @@ __global__ __launch_bounds__(kWave* kWaves) void amv_huffman_sync_kernel(
 
 namespace {
 
+// waves per workgroup for a pool size: one workgroup takes the CU's whole LDS
+uint32_t sync_waves(uint32_t pool_bytes) {
+    uint32_t waves = (kLdsPerCu - kTableBytes) / pool_bytes;
+    if (waves > (uint32_t)kMaxWaves) waves = kMaxWaves;
+    return waves ? waves : 1u;
+}
+
 template <int L, bool kRec>
 void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
                  const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, uint32_t pool_bytes,
                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
                  uint32_t* defer_list, uint32_t* defer_count, uint32_t* queue, unsigned long long* stats, hipStream_t s) {
-    constexpr uint32_t kPerGroup = (uint32_t)(kWave / L) * kWaves;
+    const uint32_t waves = sync_waves(pool_bytes);
+    const uint32_t per_group = (uint32_t)(kWave / L) * waves;
     static bool raised = false;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L, kRec>),
@@ -551,42 +561,44 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
         raised = true;
     }
     // enough workgroups to fill the chip (LDS allows a few per CU), never more than there are tasks
-    const uint32_t lds = kTableBytes + kWaves * pool_bytes;
-    uint32_t grid = (n + kPerGroup - 1) / kPerGroup;
-    const uint32_t resident = 256u * (160u * 1024u / lds > 0 ? 160u * 1024u / lds : 1u);
+    const uint32_t lds = kTableBytes + waves * pool_bytes;
+    uint32_t grid = (n + per_group - 1) / per_group;
+    const uint32_t resident = 256u * (kLdsPerCu / lds > 0 ? kLdsPerCu / lds : 1u);
     if (grid > resident) grid = resident;
-    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * kWaves), lds, s, ws, ws_bytes, n, list,
+    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * waves), lds, s, ws, ws_bytes, n, list,
                        list_count, g.blocks, cap_words, pool_bytes, d_img, out, status, nmcu_ok, defer_list, defer_count,
                        queue, stats);
 }
 
 }  // namespace
 
-// The launch plan for a geometry.  First pass: as few lanes per frame as `wanted` allows while two
-// workgroups (8 waves) fit a CU's LDS, with a pool that holds its frames at ~70 % of the window each.
+// The launch plan for a geometry: as few lanes per frame as `wanted` allows while at least 8 waves
+// fit a CU's LDS, each with a pool that holds its frames at ~60 % of the window; the launch then takes
+// as many waves per workgroup (one workgroup per CU) as that pool size allows.
 // lanes == 0: frames too large for any configuration, use the serial kernel.
 SyncPlan huffman_sync_plan(const FrameGeom& g, uint32_t cap_words, int wanted) {
     (void)g;
     SyncPlan plan{0, 0u, 0u};
     const uint32_t one = cap_words * 4u + 16u;          // the largest frame plus its zero piece
+    const uint32_t avail = kLdsPerCu - kTableBytes;
     plan.pool_single = one;
-    if (kTableBytes + kWaves * one > 150u * 1024u) return plan;
-    const uint32_t budget = (78u * 1024u - kTableBytes) / kWaves;   // per wave, two workgroups per CU
+    if (one > avail) return plan;
     const int tries[4] = {8, 16, 32, 64};
     for (int i = 0; i < 4; ++i) {
         const int lanes = tries[i];
         if (lanes < wanted) continue;
         const uint32_t frames = (uint32_t)(kWave / lanes);
-        if (lanes != 64 && (frames * one * 7u) / 10u > budget) continue;   // frames would not fit their pool
-        uint32_t pool = lanes == 64 ? one : budget;
+        uint32_t least = lanes == 64 ? one : (frames * one * 6u) / 10u;
+        if (least < one) least = one;
+        uint32_t waves = avail / least;
+        if (waves > (uint32_t)kMaxWaves) waves = kMaxWaves;
+        if (lanes != 64 && waves < 8u) continue;          // too few waves per CU: take more lanes per frame instead
+        uint32_t pool = (avail / waves) & ~15u;           // what each of those waves can have
         if (pool > frames * one) pool = frames * one;
-        if (pool < one) pool = one;
         plan.lanes = lanes;
-        plan.pool = pool & ~15u;
+        plan.pool = pool;
         return plan;
     }
-    plan.lanes = 64;
-    plan.pool = one;
     return plan;
 }
 
