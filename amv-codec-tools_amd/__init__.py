@@ -102,6 +102,10 @@ SYMBOLS = {
     "amvhip_prof_reset": (None, [_vp]),
     "amvhip_prof_read": (_int, [_vp, _int, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double)]),
     "amvhip_kernel_name": (ctypes.c_char_p, [_int]),
+    # container writer (host C)
+    "amvhip_mux_open": (_vp, [ctypes.c_char_p, _u32, _u32, _u32, _u32, _u32, _u32]),
+    "amvhip_mux_write_frame": (_int, [_vp, _u8p, _u32, _u8p, _u32]),
+    "amvhip_mux_close": (_int, [_vp]),
 }
 
 _lib = None

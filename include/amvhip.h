@@ -280,6 +280,22 @@ int amvhip_synth_audio_dev(amvhip_ctx *ctx, uint32_t seed, uint64_t first_sample
                            int16_t *d_pcm, void *stream);
 
 /*
+ * AMV container writer (host C, no device work): the muxer half of the path, with the layout
+ * AMVmuxer/ffmpeg/libavformat/amvenc.c writes -- 304-byte header (amvh :128-177, two strl lists
+ * :181-262), "movi" at 0x138, unpadded 00dc/01wb chunks (:317-321) in strict video/audio alternation
+ * (:378-406), counters and duration patched at close (:72-114), "AMV_END_" trailer (:332).  The reader
+ * half is AmvOpen / AmvReadNextFrame above.  bit rates: what FFmpeg's codec contexts would hold
+ * (its defaults are 200000 and 64000); they only fill the two byte-rate fields.
+ * open: NULL on error; write_frame / close: 0 or -1.
+ */
+typedef struct amvhip_muxer amvhip_muxer;
+amvhip_muxer *amvhip_mux_open(const char *path, uint32_t width, uint32_t height, uint32_t fps,
+                              uint32_t sample_rate, uint32_t video_bit_rate, uint32_t audio_bit_rate);
+int amvhip_mux_write_frame(amvhip_muxer *m, const uint8_t *video, uint32_t video_len, const uint8_t *audio,
+                           uint32_t audio_len);
+int amvhip_mux_close(amvhip_muxer *m);
+
+/*
  * Kernel timing with HIP events recorded on the launch stream around every kernel
  * launch (bench.py's roofline leg).  Off by default.  amvhip_prof_read synchronises the
  * events recorded since the last reset and returns launches / summed milliseconds.

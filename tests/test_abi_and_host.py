@@ -112,3 +112,49 @@ def test_product_never_touches_the_oracle():
                     assert "amvo_" not in text and "libamvoracle" not in text and "amv_oracle" not in text, os.path.join(dirpath, f)
     out = subprocess.run(["ldd", os.path.join(ROOT, "amv-codec-tools_amd", "libamvhip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_container_writer_round_trip(pkg, amv1, tmp_path):
+    """amvhip_mux_* (amvenc.c semantics): a file written from the reference clip's chunks has the fixed
+    header layout of the reference fixture, reads back chunk for chunk through AmvOpen / AmvReadNextFrame
+    and through the test-side parser, and passes the checks of compare_amv.c (movi at 0x138, same section
+    ids and lengths, AMV_END_)."""
+    lib = pkg.load_library()
+    out = str(tmp_path / "rewritten.amv")
+    w, h, fps = 128, 96, 12
+    m = lib.amvhip_mux_open(out.encode(), w, h, fps, 16000, 200000, 64000)
+    assert m
+    for v, a in zip(amv1["video"], amv1["audio"]):
+        vb, ab = np.frombuffer(v, np.uint8), np.frombuffer(a, np.uint8)
+        assert lib.amvhip_mux_write_frame(m, vb.ctypes.data, len(v), ab.ctypes.data, len(a)) == 0
+    assert lib.amvhip_mux_close(m) == 0
+    got = open(out, "rb").read()
+    ref = open(amv1["path"], "rb").read()
+    # same skeleton as the real AMV file: every four-cc and every header chunk size at the same offset
+    for off in (0, 8, 12, 20, 24, 88, 96, 100, 164, 208, 216, 220, 276, 304, 312):
+        assert got[off:off + 4] == ref[off:off + 4], off
+    for off in (28, 104, 168, 224, 280):
+        assert got[off:off + 4] == ref[off:off + 4], off
+    assert got[0x138:0x13c] == b"movi" and got.endswith(b"AMV_END_")
+    le32 = lambda o: int.from_bytes(got[o:o + 4], "little")
+    n = len(amv1["video"])
+    assert le32(32) == 1000000 // fps and le32(48) == n and le32(64) == w and le32(68) == h and le32(72) == fps
+    assert (got[84], got[85], int.from_bytes(got[86:88], "little")) == ((n // fps) % 60, (n // fps) // 60, (n // fps) // 3600)
+    assert le32(4) == len(got) - 8 and le32(16) == 304 - 20 and le32(308) == len(got) - 312 - 8   # RIFF, hdrl and movi sizes
+    assert le32(140) == n and le32(260) == n                                 # stream lengths = packet counts
+    assert got[284:288] == b"\x01\x00\x01\x00" and le32(288) == 16000 and got[296:300] == b"\x02\x00\x10\x00"
+    # the payload region is identical to the fixture's (same chunks, same order, no padding)
+    assert got[316:-8] == ref[316:316 + len(got) - 324]
+    # and the library's own reader walks it
+    dec = lib.AmvOpen(out.encode())
+    assert dec
+    d = dec.contents
+    assert (d.amvinfo.dwWidth, d.amvinfo.dwHeight, d.amvinfo.dwSpeed) == (w, h, fps)
+    for v, a in zip(amv1["video"], amv1["audio"]):
+        assert lib.AmvReadNextFrame(dec) == 0
+        fb = d.framebuf
+        assert ctypes.string_at(fb.videobuff, fb.videobufflen) == v and ctypes.string_at(fb.audiobuff, fb.audiobufflen) == a
+    assert lib.AmvReadNextFrame(dec) == 0 and d.framebuf.framenum == -1
+    lib.AmvClose(dec)
+    assert lib.amvhip_mux_open(None, w, h, fps, 16000, 0, 0) is None
+    assert lib.amvhip_mux_write_frame(None, None, 0, None, 0) == -1 and lib.amvhip_mux_close(None) == -1
