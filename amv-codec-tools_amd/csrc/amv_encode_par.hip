@@ -2,12 +2,14 @@
 //
 // Unlike decoding, encoding has no serial chain that cannot be cut: the DC difference of a block
 // needs only the previous block of its component (mjpegenc.c:390-401), and once every block's code
-// length is known the bit position of every block is a prefix sum.  One wave per frame:
+// length is known the bit position of every block is a prefix sum.  One team of lanes per frame (one
+// wave for small frames, four waves = the whole workgroup from 1 024 blocks up):
 //
-//   1. each lane takes blocks lane, lane+64, ...: loads the block's 64 quantised coefficients (one
+//   1. each lane takes blocks lane, lane+team size, ...: loads the block's 64 quantised coefficients (one
 //      128-byte line) into registers and adds up the length of its code (encode_block,
 //      mjpegenc.c:379-435, without writing);
-//   2. a wave prefix sum over the block lengths gives every block's first bit;
+//   2. a prefix sum over the block lengths (wave scan, plus partial sums through LDS across the
+//      waves of a team) gives every block's first bit;
 //   3. each lane codes its blocks again, this time OR-ing the bits into the frame's bit string in
 //      LDS (32-bit big-endian words; neighbouring blocks share words, hence the atomic OR);
 //   4. the tail is padded with ones (ff_mjpeg_encode_stuffing :338-343), FF bytes are counted and
@@ -102,26 +104,58 @@ __device__ __forceinline__ int pred_block(uint32_t b) {
 
 }  // namespace
 
-// dynamic LDS: [ code book 4 KB | per wave: bits[cap_words] | block lengths[blocks_cap] ]
+// A team = the lanes that share one frame: one wave (kTeam == 1, several frames per workgroup) or the
+// whole workgroup of kTeam waves (large frames: more lanes per frame, more frames resident per CU).
+template <int kTeam>
+__device__ __forceinline__ void team_sync() {
+    if (kTeam == 1) wave_sync();
+    else __syncthreads();
+}
+
+template <int kTeam>
+__device__ __forceinline__ uint32_t team_excl_sum(uint32_t v, uint32_t tl, uint32_t& total, uint32_t* s_part) {
+    uint32_t wave_total;
+    const uint32_t x = wave_excl_sum(v, tl & 63u, wave_total);
+    if (kTeam == 1) { total = wave_total; return x; }
+    const uint32_t w = tl >> 6;
+    __syncthreads();                                   // the previous sum's partials have been read
+    if ((tl & 63u) == 0u) s_part[w] = wave_total;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < kTeam; ++i) {
+        const uint32_t part = s_part[i];
+        before += (uint32_t)i < w ? part : 0u;
+        all += part;
+    }
+    total = all;
+    return x + before;
+}
+
+// dynamic LDS: [ code book 4 KB | per team: bits[cap_words] | block lengths[blocks_cap] | 8 words of partial sums ]
+template <int kTeam>
 __global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
     const int16_t* __restrict__ coef, uint32_t n, uint32_t blocks_per_frame, uint32_t blocks_cap,
     uint32_t cap_words, const HuffEncodeImage* __restrict__ img, uint8_t* __restrict__ tmp, uint32_t bound,
     uint32_t* __restrict__ lens, uint32_t* __restrict__ retry_list, uint32_t* __restrict__ retry_count) {
+    constexpr uint32_t kLanes = kWave * kTeam;         // lanes per frame
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     uint32_t* book = reinterpret_cast<uint32_t*>(s_mem);
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t team = kTeam == 1 ? threadIdx.x >> 6 : 0u;
+    const uint32_t tl = kTeam == 1 ? threadIdx.x & 63u : threadIdx.x;   // lane inside the team
     for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) book[i] = (&img->code[0][0])[i];
     __syncthreads();
-    const uint32_t frame = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (frame >= n) return;
+    const uint32_t frame = kTeam == 1 ? blockIdx.x * (blockDim.x >> 6) + team : blockIdx.x;
+    if (frame >= n) return;                            // kTeam > 1: the whole workgroup leaves
 
-    uint32_t* bits = reinterpret_cast<uint32_t*>(s_mem + 4096u + wave * (cap_words + blocks_cap) * 4u);
+    uint32_t* bits = reinterpret_cast<uint32_t*>(s_mem + 4096u + team * (cap_words + blocks_cap + 8u) * 4u);
     uint32_t* blen = bits + cap_words;
+    uint32_t* s_part = blen + blocks_cap;
     const int16_t* fcoef = coef + (uint64_t)frame * blocks_per_frame * 64u;
-    for (uint32_t i = lane; i < cap_words; i += kWave) bits[i] = 0u;
+    for (uint32_t i = tl; i < cap_words; i += kLanes) bits[i] = 0u;
 
     // ---- 1. code length of every block
-    for (uint32_t b = lane; b < blocks_per_frame; b += kWave) {
+    for (uint32_t b = tl; b < blocks_per_frame; b += kLanes) {
         uint32_t c[32];
         const uint4* src = reinterpret_cast<const uint4*>(fcoef + (uint64_t)b * 64u);
 #pragma unroll
@@ -133,25 +167,25 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
         code_block<false>(e, c, prev, book + cls * 256u, book + (2u + cls) * 256u);
         blen[b] = e.nbits;
     }
-    wave_sync();
+    team_sync<kTeam>();
 
     // ---- 2. first bit of every block: each lane owns a run of consecutive blocks for the scan
-    const uint32_t per = (blocks_per_frame + kWave - 1) / kWave;
-    const uint32_t lo = min(blocks_per_frame, lane * per), hi = min(blocks_per_frame, lo + per);
+    const uint32_t per = (blocks_per_frame + kLanes - 1) / kLanes;
+    const uint32_t lo = min(blocks_per_frame, tl * per), hi = min(blocks_per_frame, lo + per);
     uint32_t sum = 0;
     for (uint32_t b = lo; b < hi; ++b) sum += blen[b];
     uint32_t total_bits;
-    uint32_t run_pos = wave_excl_sum(sum, lane, total_bits);
+    uint32_t run_pos = team_excl_sum<kTeam>(sum, tl, total_bits, s_part);
     for (uint32_t b = lo; b < hi; ++b) { const uint32_t l = blen[b]; blen[b] = run_pos; run_pos += l; }
-    wave_sync();
+    team_sync<kTeam>();
     const uint32_t nbytes = (total_bits + 7u) >> 3;
     if (nbytes + 8u > cap_words * 4u) {   // does not fit the window: the one-lane-per-frame kernel takes it
-        if (lane == 0) retry_list[atomicAdd(retry_count, 1u)] = frame;
+        if (tl == 0) retry_list[atomicAdd(retry_count, 1u)] = frame;
         return;
     }
 
     // ---- 3. the bits
-    for (uint32_t b = lane; b < blocks_per_frame; b += kWave) {
+    for (uint32_t b = tl; b < blocks_per_frame; b += kLanes) {
         uint32_t c[32];
         const uint4* src = reinterpret_cast<const uint4*>(fcoef + (uint64_t)b * 64u);
 #pragma unroll
@@ -164,23 +198,23 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
         code_block<true>(e, c, prev, book + cls * 256u, book + (2u + cls) * 256u);
         if (e.nacc) atomicOr(&e.words[e.wi], (uint32_t)(e.acc << (32 - e.nacc)));
     }
-    wave_sync();
-    if (lane == 0 && (total_bits & 7u))   // ff_mjpeg_encode_stuffing: ones up to the byte boundary
+    team_sync<kTeam>();
+    if (tl == 0 && (total_bits & 7u))   // ff_mjpeg_encode_stuffing: ones up to the byte boundary
         atomicOr(&bits[total_bits >> 5], ((1u << (8u - (total_bits & 7u))) - 1u) << (24u - (total_bits & 24u)));
-    wave_sync();
+    team_sync<kTeam>();
 
     // ---- 4. FF D8, the bytes with 00 after every FF, FF D9
     uint8_t* out = tmp + (uint64_t)frame * bound;
     uint32_t ff_before = 0;
-    for (uint32_t w0 = 0; w0 * 4u < nbytes; w0 += kWave) {
-        const uint32_t wi = w0 + lane;
+    for (uint32_t w0 = 0; w0 * 4u < nbytes; w0 += kLanes) {
+        const uint32_t wi = w0 + tl;
         const uint32_t word = wi * 4u < nbytes ? bits[wi] : 0u;
         uint32_t cnt = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j)
             cnt += (wi * 4u + j < nbytes && ((word >> (24u - 8u * j)) & 0xffu) == 0xffu) ? 1u : 0u;
         uint32_t tile;
-        uint32_t o = 2u + wi * 4u + ff_before + wave_excl_sum(cnt, lane, tile);
+        uint32_t o = 2u + wi * 4u + ff_before + team_excl_sum<kTeam>(cnt, tl, tile, s_part);
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
             if (wi * 4u + j >= nbytes) break;
@@ -190,7 +224,7 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
         }
         ff_before += tile;
     }
-    if (lane == 0) {
+    if (tl == 0) {
         out[0] = 0xff; out[1] = 0xd8;                          // SOI only, mjpegenc.c:201-204
         const uint32_t end = 2u + nbytes + ff_before;
         out[end] = 0xff; out[end + 1] = 0xd9;                  // EOI :354
@@ -204,18 +238,27 @@ bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const
     uint32_t cap_bytes = ((g.width * g.height * 2u / 5u) + 1023u) & ~1023u;
     if (cap_bytes < 2048u) cap_bytes = 2048u;
     const uint32_t blocks_cap = (g.blocks + 3u) & ~3u;
-    const uint32_t per_wave = cap_bytes + blocks_cap * 4u;
-    uint32_t waves = kMaxWaves;
-    while (waves > 1u && 4096u + waves * per_wave > 79u * 1024u) waves >>= 1;   // aim at two workgroups per CU
-    const uint32_t lds = 4096u + waves * per_wave;
-    if (lds > 150u * 1024u) return false;
+    const uint32_t per_team = cap_bytes + blocks_cap * 4u + 32u;
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_pack_wave_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_pack_wave_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_pack_wave_kernel<4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
-    hipLaunchKernelGGL(amv_pack_wave_kernel, dim3((n + waves - 1) / waves), dim3(kWave * waves), lds, s, coef, n,
+    if (g.blocks >= 1024u) {   // large frames: four waves per frame, one frame per workgroup
+        const uint32_t lds = 4096u + per_team;
+        if (lds > 150u * 1024u) return false;
+        hipLaunchKernelGGL(amv_pack_wave_kernel<4>, dim3(n), dim3(kWave * 4), lds, s, coef, n, g.blocks, blocks_cap,
+                           cap_bytes / 4u, d_img, tmp, bound, lens, retry_list, retry_count);
+        return true;
+    }
+    uint32_t waves = kMaxWaves;
+    while (waves > 1u && 4096u + waves * per_team > 79u * 1024u) waves >>= 1;   // aim at two workgroups per CU
+    const uint32_t lds = 4096u + waves * per_team;
+    if (lds > 150u * 1024u) return false;
+    hipLaunchKernelGGL(amv_pack_wave_kernel<1>, dim3((n + waves - 1) / waves), dim3(kWave * waves), lds, s, coef, n,
                        g.blocks, blocks_cap, cap_bytes / 4u, d_img, tmp, bound, lens, retry_list, retry_count);
     return true;
 }
