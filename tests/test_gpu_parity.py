@@ -484,3 +484,32 @@ def test_full_size_stream_properties(ctx, orc):
         chunk = blob[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes()
         assert chunk == orc.encode_frame(orc.synth_frame(SEED, i, w, h), w, h)
         assert (d_out[i].cpu().numpy() == orc.decode_frame(chunk, w, h)[0]).all()
+
+
+def test_adpcm_encode_long_stream_index_chain(ctx, orc):
+    """the step index is carried through 700 chunks (three 256-chunk workgroup maps composed): every chunk
+    equals the oracle's sequential encode, and decoding the device's chunks on the device equals the oracle's decode"""
+    rng = np.random.default_rng(5)
+    n = 700
+    sizes = [1378 if k % 7 else 2 * int(rng.integers(1, 900)) for k in range(n)]
+    pcm_offs = np.cumsum([0] + sizes).astype(np.uint64)
+    pcm = orc.synth_audio(SEED, 12345, int(pcm_offs[-1]) + 2)
+    pcm[200000:230000] = rng.integers(-30000, 30000, 30000)            # a loud stretch: the index climbs
+    pcm[500000:520000] = 0                                             # silence: it falls back to 0
+    offs = np.cumsum([0] + [8 + s // 2 for s in sizes]).astype(np.uint64)
+    nsamp = np.array(sizes, np.uint32)
+    blob = np.zeros(int(offs[-1]), np.uint8)
+    ctx.adpcm_encode_batch(pcm, pcm.size, pcm_offs[:-1].copy(), nsamp, n, None, blob, blob.size, offs[:-1].copy())
+    idx, seen = 0, set()
+    for i in range(n):
+        seen.add(idx)
+        want, idx = orc.adpcm_encode_chunk(pcm[int(pcm_offs[i]):int(pcm_offs[i + 1])], idx)
+        assert blob[int(offs[i]):int(offs[i + 1])].tobytes() == want, i
+    assert len(seen) > 20
+    lens = np.diff(offs).astype(np.uint32)
+    out = np.zeros(int(pcm_offs[-1]) + 8, np.int16)
+    fin = np.zeros((n, 2), np.int32)
+    ctx.adpcm_decode_batch(blob, blob.size, offs[:-1].copy(), lens, n, out, out.size, pcm_offs[:-1].copy(), fin)
+    for i in (0, 1, 255, 256, 257, 511, 512, 699):
+        want, _ = orc.adpcm_decode_chunk(blob[int(offs[i]):int(offs[i + 1])])
+        assert (out[int(pcm_offs[i]):int(pcm_offs[i + 1])] == want[: sizes[i]]).all(), i
