@@ -513,3 +513,37 @@ def test_adpcm_encode_long_stream_index_chain(ctx, orc):
     for i in (0, 1, 255, 256, 257, 511, 512, 699):
         want, _ = orc.adpcm_decode_chunk(blob[int(offs[i]):int(offs[i + 1])])
         assert (out[int(pcm_offs[i]):int(pcm_offs[i + 1])] == want[: sizes[i]]).all(), i
+
+
+def test_decode_fuzz_geometries_and_damage(ctx, orc):
+    """random even geometries (partial MCUs on both edges, more than one segment per MCU row, frames larger
+    than the synchronising kernel's LDS window next to tiny ones), random content and random damage:
+    status and every output byte equal the oracle's"""
+    rng = np.random.default_rng(77)
+    for case in range(8):
+        w = 2 * int(rng.integers(8, 200))
+        h = 2 * int(rng.integers(8, 150))
+        n = int(rng.integers(3, 40))
+        chunks = []
+        for t in range(n):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                src = orc.synth_frame(SEED, 1000 * case + t, w, h)
+            elif kind == 1:
+                src = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)                      # noise: long chunks
+            elif kind == 2:
+                src = np.full((h, w, 3), int(rng.integers(0, 256)), np.uint8)              # flat: tiny chunks
+            else:
+                src = (orc.synth_frame(SEED, t, w, h).astype(np.int32) + rng.integers(-40, 41, (h, w, 3))).clip(0, 255).astype(np.uint8)
+            c = bytearray(orc.encode_frame(src, w, h, qbias=int(rng.integers(0, 2)) * 128))
+            if rng.random() < 0.3 and len(c) > 8:                                          # damage
+                for _ in range(int(rng.integers(1, 4))):
+                    c[int(rng.integers(2, len(c) - 2))] ^= 1 << int(rng.integers(0, 8))
+            if rng.random() < 0.1:
+                c = c[: int(rng.integers(2, len(c)))]                                      # truncation
+            chunks.append(bytes(c))
+        flags = case & 1
+        got, st = _gpu_decode(ctx, chunks, w, h, flags, pad_front=int(rng.integers(0, 4)))
+        want, wst = _oracle_decode(orc, chunks, w, h, flags)
+        assert (st == wst).all(), (case, w, h, st, wst)
+        assert (got == want).all(), (case, w, h)
