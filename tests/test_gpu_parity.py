@@ -547,3 +547,31 @@ def test_decode_fuzz_geometries_and_damage(ctx, orc):
         want, wst = _oracle_decode(orc, chunks, w, h, flags)
         assert (st == wst).all(), (case, w, h, st, wst)
         assert (got == want).all(), (case, w, h)
+
+
+def test_encode_fuzz_geometries(ctx, orc):
+    """random even geometries (right and bottom edge replication, widths that are not 0 mod 4 or mod 16),
+    padded source rows, both channel orders and both quantiser biases: chunks byte-identical to the oracle's"""
+    import torch
+    rng = np.random.default_rng(99)
+    sizes = [(18, 10), (30, 34), (150, 98), (162, 122)] + [(2 * int(rng.integers(4, 180)), 2 * int(rng.integers(4, 130))) for _ in range(6)]
+    for case, (w, h) in enumerate(sizes):
+        n = int(rng.integers(2, 12))
+        bgr = case & 1
+        qbias = 128 * ((case >> 1) & 1)
+        stride = w * 3 + int(rng.integers(0, 3)) * 5
+        src = np.zeros((n, h, stride), np.uint8)
+        pix = rng.integers(0, 256, (n, h, w, 3)).astype(np.uint8) if case % 3 == 0 else \
+            np.stack([orc.synth_frame(SEED, 31 * case + t, w, h) for t in range(n)])
+        src[:, :, : w * 3] = pix.reshape(n, h, w * 3)
+        src[:, :, w * 3:] = 0xEE                                              # must never be read as pixels
+        cap = ctx.encode_bound(w, h) * n
+        d_blob = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+        d_offs = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+        d_lens = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        ctx.encode_batch_dev(_t(src), stride, bgr, n, w, h, qbias, d_blob, cap, d_offs, d_lens)
+        torch.cuda.synchronize()
+        blob, offs, lens = d_blob.cpu().numpy(), d_offs.cpu().numpy(), d_lens.cpu().numpy()
+        for i in range(n):
+            want = orc.encode_frame(np.ascontiguousarray(pix[i]), w, h, bgr=bool(bgr), qbias=qbias)
+            assert int(lens[i]) == len(want) and blob[int(offs[i]):int(offs[i]) + len(want)].tobytes() == want, (w, h, i)
