@@ -10,10 +10,12 @@
 //      copies the scan into a workspace as big-endian words with the byte after every FF removed
 //      (ReadByte, AmvJpeg.c:1061-1071), so that a decoder state is just a bit index.
 //
-//   amv_huffman_sync_kernel<L> (4 independent waves per workgroup sharing the tables; L lanes per
-//   frame, 64/L frames per wave)
+//   amv_huffman_sync_kernel<L, records> (one workgroup per CU: as many independent waves as the
+//   LDS holds stream pools for, sharing the tables; L lanes per frame, 64/L frames per wave; waves
+//   take tasks of 64/L frames from an atomic queue)
 //   0. the wave copies its frames' unstuffed words into LDS, packed back to back (whole-line
-//      loads), and zeroes their coefficient lines; from here on the bit stream is read from LDS;
+//      loads); from here on the bit stream is read from LDS (dense form: the frames' coefficient
+//      lines are zeroed meanwhile);
 //   1. the bit stream is cut into L equal subsequences; lane i walks subsequence i from a GUESSED
 //      state (its first bit, "the DC symbol of block 0 comes next") up to the first symbol boundary
 //      past its end and remembers the state it arrives in: (bit, index in block, block in MCU).
@@ -28,9 +30,13 @@
 //      rounds: still correct).  These walks only look at symbol lengths and index advances, in a
 //      branch-free loop whose three LDS reads (two table levels, next stream word) go out together;
 //   3. a prefix sum of "blocks finished per lane" gives every lane its first block number;
-//   4. one strict pass decodes values and writes them (2-byte stores into the frame's zeroed
-//      coefficient lines).  DC prediction (ycoef/ucoef/vcoef, AmvJpeg.c:1200-1221) is a running sum
-//      per component: each lane stores sums relative to its own start,
+//   3'. records form: a prefix sum of "value-carrying AC symbols per lane" gives every lane its first
+//      record;
+//   4. one strict pass decodes values and writes them: records form, one 32-bit word per non-zero
+//      AC coefficient (index, block, value) in stream order + a DC array + the first record of every
+//      MCU -- what amv_reconstruct_kernel scatters into LDS; dense form, 2-byte stores into the
+//      frame's zeroed coefficient lines.  DC prediction (ycoef/ucoef/vcoef, AmvJpeg.c:1200-1221) is a
+//      running sum per component: each lane stores sums relative to its own start,
 //   5. a prefix sum over the lanes' totals gives every lane its three bases, which it adds to the DC
 //      values it stored itself.
 //
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_huffman_sync_kernel(
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slot = lane / L, sub = lane % L;
 
-    {   // tables, shared by the four waves
+    {   // tables, shared by the waves of the workgroup
         const uint4* src = reinterpret_cast<const uint4*>(&img->m1[0][0]);
         uint4* dst = reinterpret_cast<uint4*>(s_mem);
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
