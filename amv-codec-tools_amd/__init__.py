@@ -119,6 +119,13 @@ def load_library():
             raise RuntimeError(
                 "libamvhip.so is not built (%s). Run `python amv-codec-tools_amd/build.py`; there is no CPU fallback."
                 % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 and the tensors this binding is
+        # handed live in it.  If libamvhip.so were loaded first it would bring in the system runtime, and
+        # the second runtime to initialise finds no usable device.  So torch (when present) goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
