@@ -10,12 +10,13 @@
 //      copies the scan into a workspace as big-endian words with the byte after every FF removed
 //      (ReadByte, AmvJpeg.c:1061-1071), so that a decoder state is just a bit index.
 //
-//   amv_huffman_sync_kernel<L, records> (one workgroup per CU: as many independent waves as the
-//   LDS holds stream pools for, sharing the tables; L lanes per frame, 64/L frames per wave; waves
-//   take tasks of 64/L frames from an atomic queue)
-//   0. the wave copies its frames' unstuffed words into LDS, packed back to back (whole-line
-//      loads); from here on the bit stream is read from LDS (dense form: the frames' coefficient
-//      lines are zeroed meanwhile);
+//   amv_huffman_sync_kernel<L, records> (12 independent waves per workgroup sharing the tables, two
+//   workgroups per CU; L lanes per frame, 64/L frames per wave; waves take tasks of 64/L frames from
+//   an atomic queue)
+//   0. a lane reads its part of the stream through a 16-word window in LDS that it refills from the
+//      workspace (L2) with 16-byte loads whenever any lane of the wave has used its window up, so a
+//      wave needs 4 KB of LDS whatever the frame size (dense form: the frames' coefficient lines are
+//      zeroed first);
 //   1. the bit stream is cut into L equal subsequences; lane i walks subsequence i from a GUESSED
 //      state (its first bit, "the DC symbol of block 0 comes next") up to the first symbol boundary
 //      past its end and remembers the state it arrives in: (bit, index in block, block in MCU).
@@ -29,6 +30,8 @@
 //      luma/chroma phase of the MCU, a 1-in-6 guess) and the loop ends early (worst case L-1
 //      rounds: still correct).  These walks only look at symbol lengths and index advances, in a
 //      branch-free loop whose three LDS reads (two table levels, next stream word) go out together;
+//      the number of lanes per frame follows the batch size (huffman_sync_lanes): as many as keep
+//      every task resident at once, because the launch lasts as long as one task does;
 //   3. a prefix sum of "blocks finished per lane" gives every lane its first block number;
 //   3'. records form: a prefix sum of "value-carrying AC symbols per lane" gives every lane its first
 //      record;
@@ -42,9 +45,8 @@
 //
 // Statuses equal the serial kernel's bit for bit (tests): the first error on the true path stops
 // the frame, nmcu_ok counts whole MCUs before it, TRUNCATED compares consumed with stored bits.
-// Chunks larger than the per-frame window, or with a run of FF bytes longer than the 7-byte
-// look-back of the unstuffer (never in a valid stream), are queued for amv_huffman_kernel; frames
-// that find their wave's LDS pool full are queued for a second launch with one frame per wave.
+// Chunks larger than the per-frame workspace window, or with a run of FF bytes longer than the 7-byte
+// look-back of the unstuffer (never in a valid stream), are queued for amv_huffman_kernel.
 #include "amv_kernels.h"
 
 namespace amv {
@@ -52,9 +54,9 @@ namespace amv {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kMaxWaves = 10;             // waves per workgroup (they share only the tables); the launch takes as many as
-                                          // the CU's LDS holds pools for, so that one workgroup fills a CU
-constexpr uint32_t kLdsPerCu = 160u * 1024u;
+constexpr int kWavesPerGroup = 10;        // independent waves per workgroup (they share only the tables)
+constexpr int kGroupsPerCu = 2;           // 20 waves per CU: what the kernel's VGPR count allows (5 per SIMD)
+constexpr uint32_t kRingWords = 16;       // LDS words per lane: the window of its stream a lane works in
 constexpr uint32_t kNever = 0xffffffffu;
 constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + 4u * kLut2PagesPerTable * (1u << kLut2Bits) * 2u;
 
@@ -169,12 +171,70 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
 
 namespace {
 
-struct Window {          // a lane's view of its frame's bit stream in LDS
-    const uint32_t* words;
-    uint32_t last;       // index of a word that is always zero; reads past the data are clamped to it
+// A lane's view of its frame's unstuffed words.  The frame stays in the global workspace (L2); the lane
+// works in a window of kRingWords = 16 words kept in LDS -- word x of lane l at ring[(x % 16) * 64 + l], so
+// the bank depends on the lane only and no two lanes ever collide.  The next eight words are always on
+// their way from memory in registers (requested one service earlier, so they have arrived when they are
+// needed) and replace the older half of the window once the lane has left it.
+// (Keeping whole frames in LDS, as an earlier version did, capped a CU at 40 frames of 160x120 and sent
+// frames larger than the LDS window to the serial kernel.)
+struct Stream {
+    const uint32_t* g;   // the frame's words, 16-byte aligned; words at or past nwords read as zero
+    uint32_t nwords;     // multiple of 4 (the unstuffer zeroes the tail of the last 16-byte piece)
+    uint32_t* ring;      // this lane's column of the wave's ring
+    uint32_t hi;         // the ring holds the lane's words [hi - 16, hi); multiple of 8
+    uint4 pf0, pf1;      // words [hi, hi + 8), requested
 };
 
-__device__ __forceinline__ uint32_t word_at(const Window& w, uint32_t i) { return w.words[min(i, w.last)]; }
+// A walk may run kStride symbols between services: a symbol is at most 27 bits (16 code + 11 magnitude),
+// so 10 of them move the read index by at most 9 words, and a service leaves every lane >= 9 words.
+constexpr int kStride = 10;
+
+__device__ __forceinline__ uint32_t ring_word(const Stream& s, uint32_t x) {
+    return s.ring[(x & (kRingWords - 1u)) * kWave];
+}
+
+__device__ __forceinline__ uint4 stream_piece(const Stream& s, uint32_t x) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (x < s.nwords) v = *reinterpret_cast<const uint4*>(s.g + x);
+    return v;
+}
+
+__device__ __forceinline__ void ring_put(const Stream& s, uint32_t x, const uint4& v) {   // x: multiple of 4
+    uint32_t* d = s.ring + (x & (kRingWords - 1u)) * kWave;
+    d[0] = v.x; d[kWave] = v.y; d[2 * kWave] = v.z; d[3 * kWave] = v.w;
+}
+
+__device__ __forceinline__ void stream_request(Stream& s) {
+    s.pf0 = stream_piece(s, s.hi);
+    s.pf1 = stream_piece(s, s.hi + 4u);
+}
+
+// the requested words take the place of the older half of the window; the next eight are requested
+__device__ __forceinline__ void stream_advance(Stream& s) {
+    ring_put(s, s.hi, s.pf0);
+    ring_put(s, s.hi + 4u, s.pf1);
+    s.hi += 8u;
+    stream_request(s);
+}
+
+// start of a walk at word `from`: the window holds words [from & ~7, +16)
+__device__ __forceinline__ void stream_open(Stream& s, uint32_t from) {
+    const uint32_t lo = from & ~7u;
+    const uint4 a = stream_piece(s, lo), b = stream_piece(s, lo + 4u), c = stream_piece(s, lo + 8u), d = stream_piece(s, lo + 12u);
+    ring_put(s, lo, a);
+    ring_put(s, lo + 4u, b);
+    ring_put(s, lo + 8u, c);
+    ring_put(s, lo + 12u, d);
+    s.hi = lo + kRingWords;
+    stream_request(s);
+}
+
+// between strides: a lane whose read index is within 9 words of the window's end moves the window on
+// (once, with words that arrived long ago; a second time, waiting, only after a run of maximal symbols)
+__device__ __forceinline__ void stream_service(Stream& s, uint32_t widx) {
+    while (widx + 9u > s.hi) stream_advance(s);
+}
 
 // tab = table number << kLut1Bits
 __device__ __forceinline__ uint32_t lookup(const uint16_t* __restrict__ m1, const uint16_t* __restrict__ m2,
@@ -194,40 +254,51 @@ __device__ __forceinline__ uint32_t table_of(uint32_t k, uint32_t k6) {
 
 // Speculative walk from `s` while s.p < limit: where symbols start and how the block position
 // moves, nothing else.  Returns the number of blocks finished.
-__device__ __forceinline__ uint32_t walk_skip(const Window& w, const uint16_t* __restrict__ m1,
+__device__ __forceinline__ uint32_t walk_skip(Stream& w, const uint16_t* __restrict__ m1,
                                               const uint16_t* __restrict__ m2, State& s, uint32_t limit,
                                               uint32_t& nrec_out) {
     uint32_t p = s.p, k = s.k, k6 = s.k6, nblk = 0, nrec = 0;
     nrec_out = 0u;
-    if (p >= limit) return 0u;
+    bool active = p < limit;
     uint32_t widx = p >> 5;
-    const uint32_t bo = p & 31u;
-    uint64_t acc = (((uint64_t)word_at(w, widx) << 32) | word_at(w, widx + 1u)) << bo;
-    int nb = 64 - (int)bo;
-    widx += 2u;
-    uint32_t nextw = word_at(w, widx);                 // appended when the window runs low
-    ++widx;
+    uint64_t acc = 0;
+    int nb = 0;
+    uint32_t nextw = 0;                                // appended when the register window runs low
+    if (active) {
+        stream_open(w, widx);
+        const uint32_t bo = p & 31u;
+        acc = (((uint64_t)ring_word(w, widx) << 32) | ring_word(w, widx + 1u)) << bo;
+        nb = 64 - (int)bo;
+        nextw = ring_word(w, widx + 2u);
+        widx += 3u;
+    }
     uint32_t tab = table_of(k, k6);
-    do {
-        const uint32_t cand = word_at(w, widx);        // the word after nextw, in flight with the look-ups
-        const uint32_t e = lookup(m1, m2, tab, (uint32_t)(acc >> 32));
-        const uint32_t used = max(e & 31u, 1u);        // nonsense under a guessed start: slip one bit
-        const uint32_t kn = k + ((e >> 5) & 63u);
-        nrec += (k != 0u && (e & 0x7800u) != 0u) ? 1u : 0u;   // an AC symbol that carries a value
-        acc <<= used;
-        nb -= (int)used;
-        p += used;
-        const bool need = nb <= 32;
-        acc |= need ? (uint64_t)nextw << (need ? 32 - nb : 0) : 0ull;
-        nb += need ? 32 : 0;
-        nextw = need ? cand : nextw;
-        widx += need ? 1u : 0u;
-        const bool end = kn >= 64u;                    // end of block, a full block, or an over-long run
-        k = end ? 0u : kn;
-        k6 = end ? (k6 == 5u ? 0u : k6 + 1u) : k6;
-        nblk += end ? 1u : 0u;
-        tab = table_of(k, k6);
-    } while (p < limit);
+    while (__ballot(active) != 0ull) {
+        if (active) stream_service(w, widx);
+        for (int it = 0; it < kStride; ++it) {
+            if (active) {
+                const uint32_t cand = ring_word(w, widx);      // the word after nextw, in flight with the look-ups
+                const uint32_t e = lookup(m1, m2, tab, (uint32_t)(acc >> 32));
+                const uint32_t used = max(e & 31u, 1u);        // nonsense under a guessed start: slip one bit
+                const uint32_t kn = k + ((e >> 5) & 63u);
+                nrec += (k != 0u && (e & 0x7800u) != 0u) ? 1u : 0u;   // an AC symbol that carries a value
+                acc <<= used;
+                nb -= (int)used;
+                p += used;
+                const bool need = nb <= 32;
+                acc |= need ? (uint64_t)nextw << (need ? 32 - nb : 0) : 0ull;
+                nb += need ? 32 : 0;
+                nextw = need ? cand : nextw;
+                widx += need ? 1u : 0u;
+                const bool end = kn >= 64u;                    // end of block, a full block, or an over-long run
+                k = end ? 0u : kn;
+                k6 = end ? (k6 == 5u ? 0u : k6 + 1u) : k6;
+                nblk += end ? 1u : 0u;
+                tab = table_of(k, k6);
+                active = p < limit;
+            }
+        }
+    }
     s.p = p; s.k = k; s.k6 = k6;
     nrec_out = nrec;
     return nblk;
@@ -257,7 +328,7 @@ struct Sink {
 
 // The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state.
 template <bool kRec>
-__device__ __forceinline__ WriteResult walk_write(const Window& w, const uint16_t* __restrict__ m1,
+__device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __restrict__ m1,
                                                   const uint16_t* __restrict__ m2, State s, uint32_t limit,
                                                   uint32_t blk, uint32_t blocks_per_frame, const Sink& out,
                                                   uint32_t recpos, uint32_t rec_cap) {
@@ -266,18 +337,22 @@ __device__ __forceinline__ WriteResult walk_write(const Window& w, const uint16_
     uint32_t p = s.p, k = s.k, k6 = s.k6;
     uint32_t widx = p >> 5;
     const uint32_t bo = p & 31u;
-    uint64_t acc = (((uint64_t)word_at(w, widx) << 32) | word_at(w, widx + 1u)) << bo;
+    stream_open(w, widx);
+    uint64_t acc = (((uint64_t)ring_word(w, widx) << 32) | ring_word(w, widx + 1u)) << bo;
     int nb = 64 - (int)bo;
-    widx += 2u;
-    uint32_t nextw = word_at(w, widx);
-    ++widx;
+    uint32_t nextw = ring_word(w, widx + 2u);
+    widx += 3u;
     r.dc_first = blk + (k ? 1u : 0u);
     int s0 = 0, s1 = 0, s2 = 0;
     bool alive = true;
     // one symbol per step; everything but the two stores is straight-line selects, so that lanes in
     // different states (DC / AC / end of block) share every instruction
-    while (alive && p < limit) {
-        const uint32_t cand = word_at(w, widx);
+    alive = p < limit;
+    while (__ballot(alive) != 0ull) {
+    if (alive) stream_service(w, widx);
+    for (int it = 0; it < kStride; ++it) {
+      if (alive) {
+        const uint32_t cand = ring_word(w, widx);
         const uint32_t v = (uint32_t)(acc >> 32);
         const uint32_t e = lookup(m1, m2, table_of(k, k6), v);
         const uint32_t used = e & 31u, size = (e >> 11) & 15u, adv = (e >> 5) & 63u;
@@ -338,6 +413,9 @@ __device__ __forceinline__ WriteResult walk_write(const Window& w, const uint16_
             r.done = finished;
             alive = false;
         }
+        alive = alive && p < limit;
+      }
+    }
     }
     r.sum[0] = s0; r.sum[1] = s1; r.sum[2] = s2;
     return r;
@@ -361,17 +439,15 @@ struct SyncOut {
     uint32_t* retry_count;
 };
 
-// dynamic LDS: [ m1 4 KB | m2 5 KB | per wave: pool of pool_bytes with the frames' stream words ]
-// With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).  Frames
-// whose words do not fit what is left of their wave's pool are appended to defer_list.
+// dynamic LDS: [ m1 4 KB | m2 5 KB | per wave: ring of kRingWords words per lane ]
+// With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).
 template <int L, bool kRec>
-__global__ __launch_bounds__(kWave* kMaxWaves) void amv_huffman_sync_kernel(
+__global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    uint32_t blocks_per_frame, uint32_t cap_words, uint32_t pool_bytes,
+    uint32_t blocks_per_frame, uint32_t cap_words,
     const HuffDecodeImage* __restrict__ img, SyncOut out, int32_t* __restrict__ status,
-    uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
-    uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
+    uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
     constexpr int kFrames = kWave / L;   // frames per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const uint16_t* m1 = reinterpret_cast<const uint16_t*>(s_mem);
@@ -385,6 +461,7 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_huffman_sync_kernel(
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
+    uint32_t* ring = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + wave * (kRingWords * kWave) + lane;
     if (list) n = *list_count;
     const uint32_t ntasks = (n + kFrames - 1) / kFrames;
     // Tasks (kFrames frames each) are handed out through a counter: a wave that finishes early -- the
@@ -395,7 +472,6 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_huffman_sync_kernel(
     if (lane == 0) task = atomicAdd(queue, 1u);
     task = __shfl(task, 0);
     if (task >= ntasks) return;
-    wave_sync();   // the previous task's LDS reads are done before its pool is refilled
 
     const bool timing = stats != nullptr && lane == 0;   // optional phase clock (amvhip_entropy_stats)
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
@@ -403,47 +479,21 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_huffman_sync_kernel(
 
     const uint32_t idx = task * kFrames + slot;
     const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
-    uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+    const uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
     if (kRec && frame != kNever && total == kNever && sub == 0) out.rec_count[frame] = kNever;
-    uint8_t* pool = s_mem + kTableBytes + wave * pool_bytes;
-
-    // ---- 0. stream words -> LDS, frames packed back to back (16-byte pieces, every lane helps with
-    // every frame), one zero piece behind each for clamped reads; dense form: coefficient lines zeroed
-    uint32_t my_off = 0, used_pool = 0;
-#pragma unroll
-    for (int f = 0; f < kFrames; ++f) {
-        const uint32_t t = __shfl(total, f * L);
-        const uint32_t fr = __shfl(frame, f * L);
-        if (t == kNever) continue;                // wave-uniform
-        const uint32_t pieces = (t + 15u) >> 4;
-        const uint32_t need = (pieces + 1u) * 16u;
-        if (used_pool + need > pool_bytes) {      // no room left in this wave's pool
-            if (lane == 0) defer_list[atomicAdd(defer_count, 1u)] = fr;
-            if (slot == (uint32_t)f) total = kNever;
-            continue;
-        }
-        const uint4* src = reinterpret_cast<const uint4*>(ws + (uint64_t)fr * cap_words);
-        uint4* dst = reinterpret_cast<uint4*>(pool + used_pool);
-        for (uint32_t i = lane; i < pieces; i += kWave) dst[i] = src[i];
-        if (lane == 0) dst[pieces] = make_uint4(0, 0, 0, 0);
-        if (slot == (uint32_t)f) my_off = used_pool;
-        used_pool += need;
-    }
-    bool live = total != kNever;
+    const bool live = total != kNever;
     const uint32_t fsafe = live ? frame : 0u;
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(pool + my_off);
     Sink sink;
     sink.coef = kRec ? nullptr : out.coef + (uint64_t)fsafe * blocks_per_frame * 64u;
     sink.rec = kRec ? out.rec + (uint64_t)fsafe * out.cap_rec : nullptr;
     sink.dcv = kRec ? out.dcv + (uint64_t)fsafe * blocks_per_frame : nullptr;
     sink.mcu_start = kRec ? out.mcu_start + (uint64_t)fsafe * (out.mcus + 1u) : nullptr;
     const uint32_t valid_bits = live ? total * 8u : 0u;
-    if (!kRec && live) {
+    if (!kRec && live) {   // dense form: the frame's coefficient lines start as zeros
         uint4* z = reinterpret_cast<uint4*>(sink.coef);
         for (uint32_t i = sub; i < blocks_per_frame * 8u; i += L) z[i] = make_uint4(0, 0, 0, 0);
     }
-    wave_sync();   // LDS fills are ordered before the walks; the zeroing stores stay in flight
-    Window win{words, live ? ((total + 15u) >> 4) * 4u : 0u};
+    Stream win{ws + (uint64_t)fsafe * cap_words, live ? ((total + 15u) >> 4) * 4u : 0u, ring, 0u, make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
 
     // ---- 1/2. speculative walks until every lane's start state equals its neighbour's arrival
     uint32_t S = ((valid_bits + L - 1) / L + 31u) & ~31u;   // bits per lane, a whole number of words
@@ -546,66 +596,40 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_huffman_sync_kernel(
 
 namespace {
 
-// waves per workgroup for a pool size: one workgroup takes the CU's whole LDS
-uint32_t sync_waves(uint32_t pool_bytes) {
-    uint32_t waves = (kLdsPerCu - kTableBytes) / pool_bytes;
-    if (waves > (uint32_t)kMaxWaves) waves = kMaxWaves;
-    return waves ? waves : 1u;
-}
-
 template <int L, bool kRec>
 void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
-                 const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, uint32_t pool_bytes,
+                 const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
-                 uint32_t* defer_list, uint32_t* defer_count, uint32_t* queue, unsigned long long* stats, hipStream_t s) {
-    const uint32_t waves = sync_waves(pool_bytes);
-    const uint32_t per_group = (uint32_t)(kWave / L) * waves;
+                 uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
+    constexpr uint32_t kPerGroup = (uint32_t)(kWave / L) * kWavesPerGroup;
+    constexpr uint32_t kLds = kTableBytes + kWavesPerGroup * kRingWords * kWave * 4u;
     static bool raised = false;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L, kRec>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
         raised = true;
     }
-    // enough workgroups to fill the chip (LDS allows a few per CU), never more than there are tasks
-    const uint32_t lds = kTableBytes + waves * pool_bytes;
-    uint32_t grid = (n + per_group - 1) / per_group;
-    const uint32_t resident = 256u * (kLdsPerCu / lds > 0 ? kLdsPerCu / lds : 1u);
-    if (grid > resident) grid = resident;
-    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * waves), lds, s, ws, ws_bytes, n, list,
-                       list_count, g.blocks, cap_words, pool_bytes, d_img, out, status, nmcu_ok, defer_list, defer_count,
-                       queue, stats);
+    // enough workgroups to fill the chip, never more than there are tasks (the rest come from the queue)
+    uint32_t grid = (n + kPerGroup - 1) / kPerGroup;
+    if (grid > cus * kGroupsPerCu) grid = cus * kGroupsPerCu;
+    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * kWavesPerGroup), kLds, s, ws, ws_bytes, n,
+                       list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
 }
 
 }  // namespace
 
-// The launch plan for a geometry: as few lanes per frame as `wanted` allows while at least 8 waves
-// fit a CU's LDS, each with a pool that holds its frames at ~60 % of the window; the launch then takes
-// as many waves per workgroup (one workgroup per CU) as that pool size allows.
-// lanes == 0: frames too large for any configuration, use the serial kernel.
-SyncPlan huffman_sync_plan(const FrameGeom& g, uint32_t cap_words, int wanted) {
-    (void)g;
-    SyncPlan plan{0, 0u, 0u};
-    const uint32_t one = cap_words * 4u + 16u;          // the largest frame plus its zero piece
-    const uint32_t avail = kLdsPerCu - kTableBytes;
-    plan.pool_single = one;
-    if (one > avail) return plan;
-    const int tries[4] = {8, 16, 32, 64};
-    for (int i = 0; i < 4; ++i) {
-        const int lanes = tries[i];
-        if (lanes < wanted) continue;
-        const uint32_t frames = (uint32_t)(kWave / lanes);
-        uint32_t least = lanes == 64 ? one : (frames * one * 6u) / 10u;
-        if (least < one) least = one;
-        uint32_t waves = avail / least;
-        if (waves > (uint32_t)kMaxWaves) waves = kMaxWaves;
-        if (lanes != 64 && waves < 8u) continue;          // too few waves per CU: take more lanes per frame instead
-        uint32_t pool = (avail / waves) & ~15u;           // what each of those waves can have
-        if (pool > frames * one) pool = frames * one;
-        plan.lanes = lanes;
-        plan.pool = pool;
-        return plan;
-    }
-    return plan;
+// Lanes per frame for a batch of n frames on a device with `cus` compute units.  More lanes per frame
+// mean shorter walks (a shorter launch when the chip is not full) but more speculative work per frame
+// (every lane needs ~4 400 bits to fall in step whatever its share of the frame).  Measured on MI355X at
+// 160x120 and 320x240: the fastest choice is the most lanes for which the batch is at most ~10 waves per
+// CU (10 000 frames: 16; 20 000: 8; 2 000: 64).  `wanted` (8, 16, 32 or 64) overrides.
+int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted) {
+    if (wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
+    const uint64_t waves = (uint64_t)cus * 10u;
+    if (n <= waves) return 64;
+    if (n <= 2u * waves) return 32;
+    if (n <= 4u * waves) return 16;
+    return 8;
 }
 
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
@@ -618,12 +642,11 @@ void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
 
 void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
                          const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
-                         uint32_t pool_bytes, const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status,
-                         uint32_t* nmcu_ok, uint32_t* defer_list, uint32_t* defer_count, uint32_t* queue,
-                         unsigned long long* stats, hipStream_t s) {
+                         const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status, uint32_t* nmcu_ok,
+                         uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
     if (n == 0) return;
     SyncOut out{sinks.coef, sinks.rec, sinks.cap_rec, sinks.dcv, sinks.mcu_start, g.mcus, sinks.rec_count, sinks.retry_list, sinks.retry_count};
-#define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, pool_bytes, d_img, out, status, nmcu_ok, defer_list, defer_count, queue, stats, s
+#define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, d_img, out, status, nmcu_ok, queue, stats, cus, s
     if (sinks.rec) {
         switch (lanes_per_frame) {
             case 64: launch_sync<64, true>(AMV_SYNC_ARGS); break;

@@ -23,12 +23,8 @@ void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
                     uint32_t cap_words, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
                     hipStream_t s);
-struct SyncPlan {
-    int lanes;             // lanes per frame of the first pass, 0 = serial kernel only
-    uint32_t pool;         // LDS stream pool of the first pass (bytes)
-    uint32_t pool_single;  // pool that holds any one frame (second pass, one frame per wave)
-};
-SyncPlan huffman_sync_plan(const FrameGeom& g, uint32_t cap_words, int wanted);
+// lanes per frame for a batch of n frames on a device with `cus` compute units (amv_decode_sync.hip)
+int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted);
 // Where the entropy stage puts its result.  rec == nullptr: dense coefficient lines in coef
 // ([n][blocks][64] int16).  Otherwise the records form, per frame: rec[cap_rec] (one word per
 // non-zero AC coefficient: bits 0-5 index in block, 6-19 block, 20-31 value), dcv[blocks] predicted
@@ -44,12 +40,11 @@ struct SyncSinks {
     uint32_t* retry_list;
     uint32_t* retry_count;
 };
-// list/list_count: optional frame list (second pass); defer_list/defer_count: frames that did not fit the pool
+// list/list_count: optional frame list; *queue: a zeroed task counter per launch
 void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
                          const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
-                         uint32_t pool_bytes, const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status,
-                         uint32_t* nmcu_ok, uint32_t* defer_list, uint32_t* defer_count, uint32_t* queue,
-                         unsigned long long* stats, hipStream_t s);   // *queue: a zeroed task counter per launch
+                         const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status, uint32_t* nmcu_ok,
+                         uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s);
 // dequantise + IDCT + YCbCr->BGR + flipped store: one wave per MCU-row segment
 // sinks.rec == nullptr: every frame is dense in sinks.coef; otherwise per frame as rec_count says
 void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n,

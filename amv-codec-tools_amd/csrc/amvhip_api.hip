@@ -41,7 +41,8 @@ struct amvhip_ctx {
     // workspace
     DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, dcv, mcu_start, rec_count;
     bool dense_intermediate = false;   // AMVHIP_DENSE=1: dense coefficient lines between the decode stages (experiments)
-    int sync_lanes = 8;   // minimum lanes per frame; the launch picks the smallest count whose LDS fits
+    int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
+    uint32_t cus = 256;   // compute units of the device
     bool want_stats = false;
     int entropy_mode = AMVHIP_ENTROPY_AUTO;
     // host-pointer staging
@@ -209,6 +210,8 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
     std::call_once(once, [] { build_images(dec, enc); });
     auto die = [&](int code) { amvhip_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = (uint32_t)cus;
     if (const char* e = getenv("AMVHIP_DENSE")) c->dense_intermediate = atoi(e) != 0;
     if (const char* e = getenv("AMVHIP_SYNC_LANES")) {   // tuning knob: lanes per frame of the entropy kernel
         const int v = atoi(e);
@@ -255,26 +258,22 @@ static int size_ok(uint32_t w, uint32_t h) { return w > 0 && h > 0 && w <= 16384
 static int entropy_stage(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offs,
                          const uint32_t* d_lens, uint32_t n, const FrameGeom& g, SyncSinks sinks, int32_t* d_status,
                          uint32_t* d_nmcu_ok, hipStream_t st) {
-    // window per frame for the unstuffed scan (global workspace and LDS): ~1.6x the 0.2 B/pixel AMV
-    // streams run at; larger chunks take the serial kernel
+    // window per frame for the unstuffed scan in the global workspace: ~1.6x the 0.2 B/pixel AMV streams
+    // run at; larger chunks take the serial kernel
     uint32_t cap_bytes = ((g.width * g.height * 5u / 16u) + 1023u) & ~1023u;
     if (cap_bytes < 2048u) cap_bytes = 2048u;
     const uint32_t cap_words = cap_bytes / 4u;
-    SyncPlan plan{0, 0u, 0u};
-    if (c->entropy_mode != AMVHIP_ENTROPY_SERIAL && g.blocks < 16384u) plan = huffman_sync_plan(g, cap_words, c->sync_lanes);
-    if (plan.lanes == 0) {
+    if (c->entropy_mode == AMVHIP_ENTROPY_SERIAL || g.blocks >= 16384u) {   // (the records' block field has 14 bits)
         if (sinks.rec) HIP_TRY(c, hipMemsetAsync(sinks.rec_count, 0xff, (size_t)n * 4, st));   // every frame dense
         Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
         launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, sinks.coef, d_status, d_nmcu_ok, nullptr, nullptr, st);
         return check_launch(c, "huffman");
     }
-    if (int r = ensure(c, c->retry, ((size_t)n + 4) * 8)) return r;   // [retry count x4 | defer count x4 | retry list n | defer list n]
+    if (int r = ensure(c, c->retry, ((size_t)n + 8) * 4)) return r;   // [retry count, task counter, 6 spare | retry list n]
     if (int r = ensure(c, c->ws, (size_t)n * cap_bytes)) return r;
     if (int r = ensure(c, c->ws_bytes, (size_t)n * 4)) return r;
     uint32_t* retry_count = (uint32_t*)c->retry.p;
-    uint32_t* defer_count = retry_count + 4;
     uint32_t* retry_list = retry_count + 8;
-    uint32_t* defer_list = retry_list + n;
     sinks.retry_list = retry_list;
     sinks.retry_count = retry_count;
     HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, st));
@@ -288,12 +287,8 @@ static int entropy_stage(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
         Timed t(c, AMVHIP_K_HUFFMAN, st);
         unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
         launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, cap_words,
-                            plan.lanes, plan.pool, c->d_dec, sinks, d_status, d_nmcu_ok, defer_list, defer_count, retry_count + 1,
-                            stats, st);
-        if (plan.lanes != 64)   // frames that found their wave's pool full: one frame per wave (usually none)
-            launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, defer_list, defer_count, g,
-                                cap_words, 64, plan.pool_single, c->d_dec, sinks, d_status, d_nmcu_ok, defer_list,
-                                defer_count, retry_count + 2, stats, st);
+                            huffman_sync_lanes(n, c->cus, c->sync_lanes), c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1,
+                            stats, c->cus, st);
     }
     if (int r = check_launch(c, "huffman_sync")) return r;
     {   // frames handed back (oversize chunks, long FF runs, too many coefficients): usually none, exits at once
