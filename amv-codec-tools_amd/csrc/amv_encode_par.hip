@@ -243,14 +243,20 @@ bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_pack_wave_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_pack_wave_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_pack_wave_kernel<4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
-    if (g.blocks >= 1024u) {   // large frames: four waves per frame, one frame per workgroup
-        const uint32_t lds = 4096u + per_team;
-        if (lds > 150u * 1024u) return false;
-        hipLaunchKernelGGL(amv_pack_wave_kernel<4>, dim3(n), dim3(kWave * 4), lds, s, coef, n, g.blocks, blocks_cap,
+    const uint32_t lds_team = 4096u + per_team;
+    if (g.blocks >= 1024u && lds_team <= 150u * 1024u) {   // large frames: four waves per frame, one frame per workgroup
+        hipLaunchKernelGGL(amv_pack_wave_kernel<4>, dim3(n), dim3(kWave * 4), lds_team, s, coef, n, g.blocks, blocks_cap,
+                           cap_bytes / 4u, d_img, tmp, bound, lens, retry_list, retry_count);
+        return true;
+    }
+    if (g.blocks >= 256u && lds_team <= 150u * 1024u) {    // medium frames: two waves per frame
+        hipLaunchKernelGGL(amv_pack_wave_kernel<2>, dim3(n), dim3(kWave * 2), lds_team, s, coef, n, g.blocks, blocks_cap,
                            cap_bytes / 4u, d_img, tmp, bound, lens, retry_list, retry_count);
         return true;
     }
