@@ -13,7 +13,7 @@ process per GPU, no collective inside the codec path ("scaling": "weak": every G
 library's generator (+ encoder), both proven byte-identical to the CPU oracle by the tests and
 spot-checked again here before anything is timed.
 
-  --workload decode      (default) --frames chunks of WxH (160x120) -> BGR24 frames      configs[1], [3]
+  --workload decode      (default) --frames (160 000) chunks of WxH (160x120) -> BGR24 frames  configs[1], [3]
   --workload encode      RGB24 frames of WxH (320x240) -> chunks; the round trip through the
                          bit-exact decoder is PSNR-checked against the source                configs[2]
   --workload coresident  WxH (320x240) video decode on one HIP stream with IMA-ADPCM decode +
@@ -46,6 +46,10 @@ import __graft_entry__ as entry  # noqa: E402
 SEED = 0xA11CE
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 SAMPLES_PER_FRAME = 1378  # 22050 Hz mono at 16 fps: the audio chunk that travels with one video frame
+# frames per GPU per step of the decode workload.  The path is throughput-bound only when the chip is full:
+# 10 000 frames of 160x120 are 2 500 waves of the entropy kernel (10 per CU) and the step then lasts as long
+# as one wave's serial chain; DESIGN.md section 9 has the sweep.  The line also carries the 10 000-frame figure.
+DECODE_FRAMES = 160000
 
 
 class Env:
@@ -110,9 +114,12 @@ def profiled_traffic(tag, dom):
     (tools/summarize_pmc.py -> profiles/r01_traffic*.json); only quoted for the workload that was profiled"""
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic%s.json" % tag)))
-        for kname, rec in prof["kernels"].items():
-            if kname.split("<")[0].endswith(dom) and rec["hbm_corrected"] > 1e6:
-                return rec["hbm_corrected"]
+        # several instantiations of a template may show up (the 10 000-frame extra runs another one): the
+        # timed batch is the big one
+        hits = [rec["hbm_corrected"] for kname, rec in prof["kernels"].items()
+                if kname.split("<")[0].endswith(dom) and rec["hbm_corrected"] > 1e6]
+        if hits:
+            return max(hits)
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -147,7 +154,7 @@ def roofline(kern, algo_bytes, elapsed_per_step, traffic, extra=None):
 # ---------------------------------------------------------------------------------------------
 def run_decode(E, args):
     ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
-    w, h, n = args.width or 160, args.height or 120, args.frames or 10000
+    w, h, n = args.width or 160, args.height or 120, args.frames or DECODE_FRAMES
     first = E.rank * n
     d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, first, n, w, h)
     d_out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
@@ -177,13 +184,28 @@ def run_decode(E, args):
     step()
     sync = ctx.entropy_stats(False)
 
+    small = None
+    if n > 10000:                    # untimed extra: the same path over a 10 000-frame batch (the stream of BASELINE.md)
+        def step_small():
+            ctx.decode_batch_dev(d_blob, cap, d_offs, d_lens, 10000, w, h, 0, d_out, d_st, stream)
+        for _ in range(2):
+            step_small()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step_small()
+        torch.cuda.synchronize()
+        small = 10000 * 10 / (time.perf_counter() - t0)
+
     result = base_result(E, args, "AMV frames/sec/GPU (%dx%d decode, bit-exact)" % (w, h), "frames/s", n, elapsed)
     result["config"] = {"workload": "%dx%d AMV decode, %d-frame synthetic stream per GPU, chunks resident in HBM" % (w, h, n),
                         "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % E.world,
                         "per_gpu_frames_per_s": result["value"] / E.world}
+    if small is not None:
+        result["config"]["frames_per_s_with_10000_frames_per_step"] = small
     result["roofline"] = roofline(
         kern, stream_bytes + n * 3 * w * h, elapsed / args.steps,
-        (lambda dom: profiled_traffic("", dom)) if (w, h, n) == (160, 120, 10000) else None,
+        (lambda dom: profiled_traffic("", dom)) if (w, h, n) == (160, 120, DECODE_FRAMES) else None,
         {"entropy_sync_rounds": {"mean": sync["rounds"] / max(sync["frames"], 1), "max": sync["max_rounds"]}})
 
     if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
