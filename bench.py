@@ -233,7 +233,7 @@ def run_decode(E, args):
 # ---------------------------------------------------------------------------------------------
 def run_encode(E, args):
     ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
-    w, h, n = args.width or 320, args.height or 240, args.frames or 2000
+    w, h, n = args.width or 320, args.height or 240, args.frames or 8000
     if args.psnr_floor is None:
         args.psnr_floor = 26.6 if (w, h) == (320, 240) else 25.4
     first = E.rank * n
@@ -284,7 +284,7 @@ def run_encode(E, args):
                         "round_trip_psnr_db": psnr, "psnr_floor_db": args.psnr_floor, "frame0_psnr_db_cpu_checker": one,
                         "bit_exact_vs_cpu_encoder": True}
     result["roofline"] = roofline(kern, stream_bytes + n * 3 * w * h, elapsed / args.steps,
-                                  (lambda dom: profiled_traffic("_encode", dom)) if (w, h, n) == (320, 240, 2000) else None)
+                                  (lambda dom: profiled_traffic("_encode", dom)) if (w, h, n) == (320, 240, 8000) else None)
 
     if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
         m = min(256, n)
@@ -335,7 +335,7 @@ def run_adpcm(E, args, with_video=False):
     ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
     spf = SAMPLES_PER_FRAME
     if with_video:
-        w, h, n = args.width or 320, args.height or 240, args.frames or 2000
+        w, h, n = args.width or 320, args.height or 240, args.frames or 16000
         first = E.rank * n
         d_blob, cap, d_voffs, d_vlens, stream_bytes = make_video_stream(E, first, n, w, h)
         d_out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8, device=dev)

@@ -11,7 +11,7 @@ python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 python3 bench.py --workload encode > $out/${tag}_bench_encode.json 2>> $out/${tag}_bench.err
 python3 bench.py --workload coresident > $out/${tag}_bench_coresident.json 2>> $out/${tag}_bench.err
 python3 bench.py --workload adpcm > $out/${tag}_bench_adpcm.json 2>> $out/${tag}_bench.err
-python3 bench.py --width 320 --height 240 --frames 2000 --no-cpu-baseline > $out/${tag}_bench_decode320.json 2>> $out/${tag}_bench.err
+python3 bench.py --width 320 --height 240 --frames 32000 --no-cpu-baseline > $out/${tag}_bench_decode320.json 2>> $out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o run --output-format csv -- python3 $root/bench.py --no-cpu-baseline > $out/${tag}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o run --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch.log 2>&1
