@@ -73,6 +73,11 @@ SYMBOLS = {
     "AmvRewindFrameStart": (_int, [ctypes.POINTER(AMVDecoder)]),
     "AmvVideoDecode": (_int, [ctypes.POINTER(AMVDecoder)]),
     "AmvAudioDecode": (_int, [ctypes.POINTER(AMVDecoder)]),
+    "AmvJpegPutHeader": (None, [_vp, ctypes.c_ushort, ctypes.c_ushort]),
+    "AmvCreateJpegFileFromFrameBuffer": (_int, [ctypes.POINTER(AMVDecoder), ctypes.c_char_p]),
+    "AmvCreateJpegFileFromBuffer": (_int, [ctypes.POINTER(AMVInfo), ctypes.POINTER(FRAMEBUFF), ctypes.c_char_p]),
+    "AmvConvertJpegFileToBmpFile": (_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "AmvCreateWavFileFromAmvFile": (_int, [ctypes.POINTER(AMVDecoder), _int, ctypes.c_char_p]),
     "decode_amv_frame": (_int, [_vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, _vp]),
     "encode_amv_frame": (_int, [_vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, _int, _vp, ctypes.c_uint]),
     "amvhip_create": (_int, [ctypes.POINTER(_vp), _int]),
@@ -82,6 +87,7 @@ SYMBOLS = {
     "amvhip_stride": (_u32, [_u32]),
     "amvhip_frame_bytes": (_u64, [_u32, _u32]),
     "amvhip_encode_bound": (_u32, [_u32, _u32]),
+    "amvhip_jpeg_header": (_u32, [ctypes.c_ushort, ctypes.c_ushort, _vp, _u32]),
     "amvhip_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "amvhip_decode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_huffman_decode_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),

@@ -667,6 +667,36 @@ extern "C" int amvhip_prof_read(amvhip_ctx* c, int kernel, uint64_t* launches, d
     return AMVHIP_OK;
 }
 
+// The JPEG file header amvlib puts in front of a chunk's scan (AmvJpegPutHeader, AmvJpeg.c:315-414):
+// SOI, JFIF APP0 (:282-313), two DQT segments with the fixed tables (:162-213), SOF0 4:2:0, the four
+// K.3 Huffman tables (:245-279), SOS.  Host-only; the tables come from amv_tables.h.
+extern "C" uint32_t amvhip_jpeg_header(uint16_t height, uint16_t width, uint8_t* out, uint32_t cap) {
+    std::vector<uint8_t> b;
+    auto put = [&](std::initializer_list<int> v) { for (int x : v) b.push_back((uint8_t)x); };
+    put({0xff, 0xd8});                                                              // SOI
+    put({0xff, 0xe0, 0x00, 0x10, 'J', 'F', 'I', 'F', 0x00, 0x01, 0x01, 0x01, 0x00, 0x60, 0x00, 0x60, 0x00, 0x00});
+    for (int t = 0; t < 2; ++t) {                                                   // DQT, 8-bit, table t
+        put({0xff, 0xdb, 0x00, 2 + 1 + 64, t});
+        for (int i = 0; i < 64; ++i) b.push_back(t ? kQuantChroma[i] : kQuantLuma[i]);
+    }
+    put({0xff, 0xc0, 0, 17, 8, height >> 8, height & 0xff, width >> 8, width & 0xff, 3,
+         1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1});                                      // SOF0
+    const int order[4] = {0, 2, 1, 3};                                              // DC luma, AC luma, DC chroma, AC chroma (:247-278)
+    for (int j = 0; j < 4; ++j) {
+        const int t = order[j];
+        int nsym = 0;
+        for (int l = 0; l < 16; ++l) nsym += kHuffCount[t][l];
+        const int len = 2 + 1 + 16 + nsym;                                          // 0x1F / 0xB5
+        put({0xff, 0xc4, len >> 8, len & 0xff, ((t >= 2 ? 1 : 0) << 4) | (t & 1)});
+        for (int l = 0; l < 16; ++l) b.push_back(kHuffCount[t][l]);
+        const uint8_t* syms = symbols_of(t);
+        for (int i = 0; i < nsym; ++i) b.push_back(syms[i]);
+    }
+    put({0xff, 0xda, 0, 12, 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0});               // SOS
+    if (out && cap >= b.size()) memcpy(out, b.data(), b.size());
+    return (uint32_t)b.size();
+}
+
 extern "C" const char* amvhip_kernel_name(int kernel) {
     switch (kernel) {
         case AMVHIP_K_HUFFMAN: return "amv_huffman_sync_kernel";

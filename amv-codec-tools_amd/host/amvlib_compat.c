@@ -330,3 +330,155 @@ int AmvAudioDecode(AMVDecoder *amv)
     }
     return rtn;
 }
+
+/* ---- export helpers: AMVDec.c:342-547, AmvJpeg.c:315-414,1289-1393 ---------------------- */
+
+void AmvJpegPutHeader(FILE *fp, unsigned short height, unsigned short width)
+{
+    unsigned char hdr[1024];
+    uint32_t n = amvhip_jpeg_header(height, width, hdr, sizeof hdr);
+    if (fp != NULL && n <= sizeof hdr) fwrite(hdr, n, 1, fp);
+}
+
+int AmvCreateJpegFileFromBuffer(AMVInfo *amvinfo, FRAMEBUFF *framebuf, const char *filename)
+{
+    FILE *fp;
+    if (amvinfo == NULL || framebuf == NULL || filename == NULL || framebuf->videobuff == NULL ||
+        framebuf->videobufflen < 2)
+        return -1;
+    fp = fopen(filename, "wb");                                   /* AMVDec.c:365-367 */
+    if (fp == NULL) return -1;
+    AmvJpegPutHeader(fp, (unsigned short)amvinfo->dwHeight, (unsigned short)amvinfo->dwWidth);
+    fwrite(framebuf->videobuff + 2, framebuf->videobufflen - 2, 1, fp);   /* :371 the chunk minus its SOI */
+    fclose(fp);
+    return 0;
+}
+
+int AmvCreateJpegFileFromFrameBuffer(AMVDecoder *amv, const char *dirname)
+{
+    char name[512];
+    if (amv == NULL || dirname == NULL) return -1;
+    snprintf(name, sizeof name, "%s-amvjpg_%06d_.jpg", dirname, amv->framebuf.framenum);   /* AMVDec.c:347 */
+    return AmvCreateJpegFileFromBuffer(&amv->amvinfo, &amv->framebuf, name);
+}
+
+static void wr16(unsigned char *p, unsigned v) { p[0] = (unsigned char)v; p[1] = (unsigned char)(v >> 8); }
+static void wr32(unsigned char *p, uint32_t v) { wr16(p, v & 0xffffu); wr16(p + 2, v >> 16); }
+
+int AmvConvertJpegFileToBmpFile(const char *jpgname, const char *bmpname)
+{
+    FILE *fp;
+    long size;
+    unsigned char *jpg = NULL, *bmp = NULL, want[1024];
+    uint32_t hdr, w, h, stride, img;
+    int rc = -1;
+
+    if (jpgname == NULL || bmpname == NULL) return -1;            /* AMVDec.c:378-379 */
+    fp = fopen(jpgname, "rb");
+    if (fp == NULL) return -1;
+    fseek(fp, 0, SEEK_END);
+    size = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    hdr = amvhip_jpeg_header(0, 0, NULL, 0);
+    if (size > (long)hdr + 2 && (jpg = (unsigned char *)malloc((size_t)size)) != NULL &&
+        fread(jpg, 1, (size_t)size, fp) == (size_t)size) {
+        /* SOF0 sits at a fixed place in the header this library (and amvlib) writes: SOI 2, APP0 18, DQT 2 x 69 */
+        const uint32_t sof = 2 + 18 + 2 * 69;
+        h = ((uint32_t)jpg[sof + 5] << 8) | jpg[sof + 6];
+        w = ((uint32_t)jpg[sof + 7] << 8) | jpg[sof + 8];
+        amvhip_jpeg_header((uint16_t)h, (uint16_t)w, want, sizeof want);
+        if (w && h && memcmp(jpg, want, hdr) == 0) {              /* amvlib's tables and 4:2:0, nothing else */
+            stride = amvhip_stride(w);                            /* WIDTHBYTES, AmvJpeg.c:1343 */
+            img = stride * h;
+            bmp = (unsigned char *)calloc(1, 54 + (size_t)img);
+            if (bmp != NULL) {
+                /* the scan behind the header is a chunk without its SOI: give it one in place */
+                unsigned char *chunk = jpg + hdr - 2;
+                chunk[0] = 0xff;
+                chunk[1] = 0xd8;
+                if (decode_amv_frame(chunk, (unsigned int)((uint32_t)size - hdr + 2), w, h, bmp + 54) == 0) {
+                    bmp[0] = 'B'; bmp[1] = 'M';                   /* BITMAPFILEHEADER :1346-1348 */
+                    wr32(bmp + 2, 54 + img);
+                    wr32(bmp + 10, 54);
+                    wr32(bmp + 14, 40);                           /* BITMAPINFOHEADER :1334-1341 */
+                    wr32(bmp + 18, w);
+                    wr32(bmp + 22, h);
+                    wr16(bmp + 26, 1);
+                    wr16(bmp + 28, 24);
+                    fclose(fp);
+                    fp = fopen(bmpname, "wb");                    /* :1374-1377 */
+                    if (fp != NULL && fwrite(bmp, 1, 54 + (size_t)img, fp) == 54 + (size_t)img) rc = 0;
+                }
+            }
+        }
+    }
+    if (fp != NULL) fclose(fp);
+    free(jpg);
+    free(bmp);
+    return rc;
+}
+
+int AmvCreateWavFileFromAmvFile(AMVDecoder *amv, int type, const char *wavfile)
+{
+    static const unsigned char adpcminfo[2] = {0xF9, 0x03};      /* AMVDec.c:386-390: wSamplesPerBlock 1017 */
+    unsigned char h[64], pre_index[4] = {0, 0, 0, 0};
+    long dataseekpos_save, fileseekpos_save;
+    uint32_t totlen = 0, n = 0;
+    int first = 0, adpcm;
+    AMVInfo *info;
+    FILE *fp;
+
+    if (amv == NULL || wavfile == NULL) return -1;                /* :409-414 */
+    if (!amv->opened) return -1;
+    if (!(type == AUDIO_FILE_TYPE_PCM || type == AUDIO_FILE_TYPE_ADPCM_IMA)) return -1;
+    adpcm = type == AUDIO_FILE_TYPE_ADPCM_IMA;
+    dataseekpos_save = amv->dataseekpos;                          /* :416-417 */
+    fileseekpos_save = amv->fileseekpos;
+    fp = fopen(wavfile, "wb");
+    if (fp == NULL) return -1;
+    info = &amv->amvinfo;
+
+    memcpy(h + n, "RIFF", 4); n += 4;                             /* :426-477 */
+    wr32(h + n, 38); n += 4;
+    memcpy(h + n, "WAVEfmt ", 8); n += 8;
+    wr32(h + n, adpcm ? 0x14 : 18); n += 4;
+    wr16(h + n, adpcm ? 0x11 : info->wFormatTag); n += 2;
+    wr16(h + n, info->nChannels); n += 2;
+    wr32(h + n, info->nSamplesPerSec); n += 4;
+    wr32(h + n, adpcm ? info->nAvgBytesPerSec / 4 : info->nAvgBytesPerSec); n += 4;
+    wr16(h + n, info->nBlockAlign); n += 2;
+    wr16(h + n, adpcm ? info->wBitsPerSample / 4 : info->wBitsPerSample); n += 2;
+    wr16(h + n, adpcm ? 2 : info->cbSize); n += 2;
+    if (adpcm) { memcpy(h + n, adpcminfo, 2); n += 2; }
+    memcpy(h + n, "data", 4); n += 4;
+    wr32(h + n, 0); n += 4;
+    if (adpcm) { wr32(h + n, 0); n += 4; }                        /* :486-490 room for the first chunk's predictor/index */
+    fwrite(h, 1, n, fp);
+
+    for (;;) {                                                    /* :492-529 */
+        FRAMEBUFF *fb = &amv->framebuf;
+        if (AmvReadNextFrame(amv) != 0) break;
+        if (fb->framenum == -1) break;
+        if (fb->audiobuff == NULL || fb->audiobufflen < 8) continue;
+        if (adpcm) {
+            if (!first) { memcpy(pre_index, fb->audiobuff, 4); first = 1; }
+            fwrite(fb->audiobuff + 8, 1, fb->audiobufflen - 8, fp);
+            totlen += fb->audiobufflen - 8;
+        } else if (AmvAudioDecode(amv) == 0) {
+            fwrite(amv->audiobuf.audiodata, 1, amv->audiobuf.len, fp);
+            totlen += amv->audiobuf.len;
+        }
+    }
+    if (adpcm && (totlen & 1u)) totlen -= 1;                      /* :533-535 */
+    fseek(fp, 4, SEEK_SET);
+    wr32(h, adpcm ? totlen + 0x28 : totlen + 38);                 /* :536-539 */
+    fwrite(h, 1, 4, fp);
+    fseek(fp, adpcm ? 0x2C : 42, SEEK_SET);                       /* :541-545 */
+    wr32(h, totlen);
+    fwrite(h, 1, 4, fp);
+    if (adpcm) fwrite(pre_index, 1, 4, fp);                       /* :547-550 */
+    fclose(fp);
+    amv->dataseekpos = dataseekpos_save;                          /* :554-555 */
+    amv->fileseekpos = fileseekpos_save;
+    return 0;
+}

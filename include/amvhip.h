@@ -125,6 +125,18 @@ int AmvRewindFrameStart(AMVDecoder *amv);
 int AmvVideoDecode(AMVDecoder *amv);
 int AmvAudioDecode(AMVDecoder *amv);
 
+/* AMVDec.h:102-107 and AmvJpeg.h:93-94 (AMVDec.c:342-547, AmvJpeg.c:315-414,1289-1393): the export
+ * helpers.  JPEG stills are the chunk's scan behind a standard JFIF header with amvlib's tables;
+ * AmvConvertJpegFileToBmpFile reads back exactly such files (the reference's is a general baseline
+ * JPEG reader; files with other tables or sampling factors return -1 here) and decodes on the GPU.
+ * AmvCreateWavFileFromAmvFile: type AUDIO_FILE_TYPE_PCM decodes every chunk (GPU), AUDIO_FILE_TYPE_ADPCM_IMA
+ * copies the nibbles.  0 on success, -1 on error, like the reference. */
+void AmvJpegPutHeader(FILE *fp, unsigned short height, unsigned short width);
+int AmvCreateJpegFileFromFrameBuffer(AMVDecoder *amv, const char *dirname);
+int AmvCreateJpegFileFromBuffer(AMVInfo *amvinfo, FRAMEBUFF *framebuf, const char *filename);
+int AmvConvertJpegFileToBmpFile(const char *jpgname, const char *bmpname);
+int AmvCreateWavFileFromAmvFile(AMVDecoder *amv, int type, const char *wavfile);
+
 /* the names BASELINE.json's north_star uses; thin aliases of the single-frame paths.
  * decode: chunk -> BGR24 (amvlib layout); encode: RGB24/BGR24 top-down -> chunk, returns length. */
 int decode_amv_frame(const unsigned char *chunk, unsigned int len, unsigned int width,
@@ -166,6 +178,9 @@ int amvhip_device(const amvhip_ctx *ctx);
 uint32_t amvhip_stride(uint32_t width);
 uint64_t amvhip_frame_bytes(uint32_t width, uint32_t height);
 uint32_t amvhip_encode_bound(uint32_t width, uint32_t height);
+/* the bytes AmvJpegPutHeader writes (SOI ... SOS) for a picture size; returns their number (623) and
+ * copies them to out when cap allows.  Host only. */
+uint32_t amvhip_jpeg_header(uint16_t height, uint16_t width, uint8_t *out, uint32_t cap);
 
 /*
  * Video decode, device-resident.  Replaces a loop of AmvVideoDecode/AmvJpegDecode calls

@@ -158,3 +158,54 @@ def test_container_writer_round_trip(pkg, amv1, tmp_path):
     lib.AmvClose(dec)
     assert lib.amvhip_mux_open(None, w, h, fps, 16000, 0, 0) is None
     assert lib.amvhip_mux_write_frame(None, None, 0, None, 0) == -1 and lib.amvhip_mux_close(None) == -1
+
+
+def test_jpeg_and_adpcm_wav_export_are_host_only(pkg, amv1, tmp_path):
+    """AmvJpegPutHeader / AmvCreateJpegFileFrom* (AmvJpeg.c:315-414, AMVDec.c:342-374) and the ADPCM flavour of
+    AmvCreateWavFileFromAmvFile (AMVDec.c:384-547) move bytes only"""
+    lib = pkg.load_library()
+    hdr = np.zeros(1024, np.uint8)
+    n = lib.amvhip_jpeg_header(96, 128, hdr.ctypes.data, hdr.size)
+    assert n == 623 and lib.amvhip_jpeg_header(96, 128, None, 0) == 623
+    h = hdr[:n].tobytes()
+    # walk the segments: SOI, APP0/JFIF, DQT 0, DQT 1, SOF0, DHT x4 (DC0, AC0, DC1, AC1), SOS
+    assert h[:2] == b"\xff\xd8"
+    pos, segs = 2, []
+    while pos < n:
+        assert h[pos] == 0xFF
+        ln = int.from_bytes(h[pos + 2:pos + 4], "big")
+        segs.append((h[pos + 1], h[pos + 4:pos + 2 + ln]))
+        pos += 2 + ln
+    assert pos == n and [m for m, _ in segs] == [0xE0, 0xDB, 0xDB, 0xC0, 0xC4, 0xC4, 0xC4, 0xC4, 0xDA]
+    assert segs[0][1] == b"JFIF\x00\x01\x01\x01\x00\x60\x00\x60\x00\x00"
+    assert segs[1][1][0] == 0 and segs[2][1][0] == 1 and len(segs[1][1]) == 65
+    assert segs[1][1][1:4] == bytes([8, 6, 6]) and segs[2][1][1:4] == bytes([9, 9, 9])     # AmvJpeg.c:30,52
+    assert segs[3][1] == bytes([8, 0, 96, 0, 128, 3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1])
+    assert [s[1][0] for s in segs[4:8]] == [0x00, 0x10, 0x01, 0x11] and [len(s[1]) + 2 for s in segs[4:8]] == [0x1F, 0xB5, 0x1F, 0xB5]
+    assert segs[8][1] == bytes([3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0])
+    # a still = that header + the chunk without its SOI
+    dec = lib.AmvOpen(amv1["path"].encode())
+    assert lib.AmvReadNextFrame(dec) == 0
+    base = str(tmp_path / "still")
+    assert lib.AmvCreateJpegFileFromFrameBuffer(dec, base.encode()) == 0
+    got = open(base + "-amvjpg_000001_.jpg", "rb").read()
+    assert got == h + amv1["video"][0][2:]
+    one = str(tmp_path / "one.jpg")
+    assert lib.AmvCreateJpegFileFromBuffer(ctypes.byref(dec.contents.amvinfo), ctypes.byref(dec.contents.framebuf), one.encode()) == 0
+    assert open(one, "rb").read() == got
+    assert lib.AmvCreateJpegFileFromBuffer(None, None, one.encode()) == -1
+    # ADPCM WAV: 0x14-byte fmt (tag 0x11, bits/4, byte rate/4, cbSize 2, 1017 samples per block), fact-less data
+    assert lib.AmvRewindFrameStart(dec) == 0
+    wav = str(tmp_path / "a.wav")
+    assert lib.AmvCreateWavFileFromAmvFile(dec, 1, wav.encode()) == 0
+    w = open(wav, "rb").read()
+    body = b"".join(a[8:] for a in amv1["audio"])
+    tot = len(body) - (len(body) & 1)
+    le = lambda o, k=4: int.from_bytes(w[o:o + k], "little")
+    assert w[:4] == b"RIFF" and le(4) == tot + 0x28 and w[8:16] == b"WAVEfmt " and le(16) == 0x14
+    assert (le(20, 2), le(22, 2), le(24), le(28), le(32, 2), le(34, 2), le(36, 2), le(38, 2)) == (0x11, 1, 16000, 8000, 2, 4, 2, 1017)
+    assert w[40:44] == b"data" and le(44) == tot
+    assert w[48:52] == amv1["audio"][0][:4] and w[52:] == body             # first chunk's predictor/index, then every nibble
+    assert dec.contents.fileseekpos == 316                                     # positions restored (:554-555)
+    assert lib.AmvCreateWavFileFromAmvFile(dec, 7, wav.encode()) == -1
+    lib.AmvClose(dec)

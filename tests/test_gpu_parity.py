@@ -575,3 +575,47 @@ def test_encode_fuzz_geometries(ctx, orc):
         for i in range(n):
             want = orc.encode_frame(np.ascontiguousarray(pix[i]), w, h, bgr=bool(bgr), qbias=qbias)
             assert int(lens[i]) == len(want) and blob[int(offs[i]):int(offs[i]) + len(want)].tobytes() == want, (w, h, i)
+
+
+def test_amvlib_export_helpers(ctx, pkg, orc, amv1, tmp_path):
+    """AmvCreateWavFileFromAmvFile (PCM: every chunk decoded on the GPU) and AmvConvertJpegFileToBmpFile
+    (a still written by AmvCreateJpegFileFromFrameBuffer comes back as the decoded frame in a 24-bit BMP)"""
+    lib = pkg.load_library()
+    dec = lib.AmvOpen(amv1["path"].encode())
+    assert dec
+    wav = str(tmp_path / "pcm.wav")
+    assert lib.AmvCreateWavFileFromAmvFile(dec, 0, wav.encode()) == 0
+    w = open(wav, "rb").read()
+    # what the reference's loop writes: audiobuf.len bytes of every AmvAudioDecode (AMVDec.c:512-519); each
+    # starts with the chunk's defined samples (the oracle's), cf. test_amvlib_player_loop
+    parts = []
+    assert lib.AmvRewindFrameStart(dec) == 0
+    for a in amv1["audio"]:
+        assert lib.AmvReadNextFrame(dec) == 0 and lib.AmvAudioDecode(dec) == 0
+        part = ctypes.string_at(dec.contents.audiobuf.audiodata, dec.contents.audiobuf.len)
+        want = orc.adpcm_decode_chunk(a)[0].astype("<i2").tobytes()
+        assert part[: len(want)] == want
+        parts.append(part)
+    pcm = b"".join(parts)
+    le = lambda o, k=4: int.from_bytes(w[o:o + k], "little")
+    assert w[:4] == b"RIFF" and le(4) == len(pcm) + 38 and w[8:16] == b"WAVEfmt " and le(16) == 18
+    assert (le(20, 2), le(22, 2), le(24), le(28), le(32, 2), le(34, 2)) == (1, 1, 16000, 32000, 2, 16)
+    assert w[38:42] == b"data" and le(42) == len(pcm) and w[46:] == pcm
+    # stills -> BMP
+    for k in (0, 100):
+        assert lib.AmvRewindFrameStart(dec) == 0
+        for _ in range(k + 1):
+            assert lib.AmvReadNextFrame(dec) == 0
+        base = str(tmp_path / ("f%d" % k))
+        assert lib.AmvCreateJpegFileFromFrameBuffer(dec, base.encode()) == 0
+        jpg = base + "-amvjpg_%06d_.jpg" % dec.contents.framebuf.framenum   # the counter runs on across rewinds (AMVDec.c:233,253)
+        bmp = base + ".bmp"
+        assert lib.AmvConvertJpegFileToBmpFile(jpg.encode(), bmp.encode()) == 0
+        b = open(bmp, "rb").read()
+        want, st, _ = orc.decode_frame(amv1["video"][k], 128, 96)
+        assert st == 0 and b[:2] == b"BM" and int.from_bytes(b[2:6], "little") == len(b) == 54 + want.size
+        assert int.from_bytes(b[10:14], "little") == 54 and int.from_bytes(b[14:18], "little") == 40
+        assert (int.from_bytes(b[18:22], "little"), int.from_bytes(b[22:26], "little"), b[26], b[28]) == (128, 96, 1, 24)
+        assert b[54:] == want.tobytes()
+    assert lib.AmvConvertJpegFileToBmpFile(amv1["path"].encode(), (str(tmp_path / "x.bmp")).encode()) == -1   # not such a JPEG
+    lib.AmvClose(dec)
