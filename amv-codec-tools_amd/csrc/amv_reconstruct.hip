@@ -32,6 +32,19 @@ constexpr int kSegMcus = 10;   // MCUs per wave: 60 of 64 lanes busy in the tran
 // 8-point inverse DCT of AmvJpeg.c: idctrow (:1082-1128) when kColumn == false, idctcol
 // (:1130-1175, without its final clamp) when true.  The reference's all-AC-zero shortcuts
 // (:1087-1092, :1134-1140) are exact special cases of this arithmetic and are not branched on.
+// The products are written per input (W1*a4 + W7*a5 instead of W7*(a4+a5) + (W1-W7)*a4): the same numbers
+// modulo 2^32, which is what the reference's int arithmetic computes, but every factor is an INPUT of the
+// pass and those always fit 24 bits -- a quantised coefficient times a step in the row pass, a value
+// shifted right by 8 in the column pass -- so each product is one full-rate 24-bit multiply-add instead
+// of a quarter-rate 32-bit multiply (a sum of two inputs can need 25 bits).  Only the two 181* products
+// take arbitrary 32-bit operands.
+// x * w + c with x and w inside 24 bits: one full-rate instruction, the low 32 bits of the exact result
+__device__ __forceinline__ int mad24(int x, int w, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(w), "v"(c));
+    return d;
+}
+
 template <bool kColumn>
 __device__ __forceinline__ void idct8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7) {
     constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565;
@@ -41,18 +54,16 @@ __device__ __forceinline__ void idct8(int& v0, int& v1, int& v2, int& v3, int& v
     constexpr int kDown = kColumn ? 3 : 0;
     constexpr int kOut = kColumn ? 14 : 8;
     int a0 = v0 * kUp + kBias, a1 = v4 * kUp;
-    int a2 = v6, a3 = v2, a4 = v1, a5 = v7, a6 = v5, a7 = v3, t;
-    t = W7 * (a4 + a5) + kRound;
-    a4 = (t + (W1 - W7) * a4) >> kDown;
-    a5 = (t - (W1 + W7) * a5) >> kDown;
-    t = W3 * (a6 + a7) + kRound;
-    a6 = (t - (W3 - W5) * a6) >> kDown;
-    a7 = (t - (W3 + W5) * a7) >> kDown;
+    const int i2 = v6, i3 = v2, i4 = v1, i5 = v7, i6 = v5, i7 = v3;
+    int t;
+    int a4 = mad24(i4, W1, mad24(i5, W7, kRound)) >> kDown;     // W7*(x4+x5) + (W1-W7)*x4
+    int a5 = mad24(i4, W7, mad24(i5, -W1, kRound)) >> kDown;    // W7*(x4+x5) - (W1+W7)*x5
+    int a6 = mad24(i6, W5, mad24(i7, W3, kRound)) >> kDown;     // W3*(x6+x7) - (W3-W5)*x6
+    int a7 = mad24(i6, W3, mad24(i7, -W5, kRound)) >> kDown;    // W3*(x6+x7) - (W3+W5)*x7
     t = a0 + a1;
     a0 -= a1;
-    a1 = W6 * (a3 + a2) + kRound;
-    a2 = (a1 - (W2 + W6) * a2) >> kDown;
-    a3 = (a1 + (W2 - W6) * a3) >> kDown;
+    int a2 = mad24(i3, W6, mad24(i2, -W2, kRound)) >> kDown;    // W6*(x3+x2) - (W2+W6)*x2
+    int a3 = mad24(i3, W2, mad24(i2, W6, kRound)) >> kDown;     // W6*(x3+x2) + (W2-W6)*x3
     a1 = a4 + a6;
     a4 -= a6;
     a6 = a5 + a7;
