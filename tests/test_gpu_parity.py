@@ -619,3 +619,17 @@ def test_amvlib_export_helpers(ctx, pkg, orc, amv1, tmp_path):
         assert b[54:] == want.tobytes()
     assert lib.AmvConvertJpegFileToBmpFile(amv1["path"].encode(), (str(tmp_path / "x.bmp")).encode()) == -1   # not such a JPEG
     lib.AmvClose(dec)
+
+
+@pytest.mark.parametrize("w,h,n", [(640, 480, 3), (1024, 768, 2)])
+def test_decode_large_frames(ctx, orc, w, h, n):
+    """640x480: long streams through the per-lane windows (hundreds of refills per lane); 1024x768: more blocks
+    than a record's block field holds, so the whole batch takes the lane-per-frame kernel"""
+    chunks = _synth_chunks(orc, n, w, h)
+    damaged = bytearray(chunks[-1])
+    damaged[len(damaged) // 2] ^= 0x10
+    chunks.append(bytes(damaged))
+    got, st = _gpu_decode(ctx, chunks, w, h)
+    want, wst = _oracle_decode(orc, chunks, w, h)
+    assert (st == wst).all() and (wst[:n] == 0).all()
+    assert (got == want).all()
