@@ -45,7 +45,7 @@
 //
 // Statuses equal the serial kernel's bit for bit (tests): the first error on the true path stops
 // the frame, nmcu_ok counts whole MCUs before it, TRUNCATED compares consumed with stored bits.
-// Chunks larger than the per-frame workspace window, or with a run of FF bytes longer than the 7-byte
+// Chunks larger than the per-frame workspace window, or with a run of FF bytes longer than the 8-byte
 // look-back of the unstuffer (never in a valid stream), are queued for amv_huffman_kernel.
 #include "amv_kernels.h"
 
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
     bool retry = len > 2u && (len - 2u) > cap_words * 4u;   // does not fit its window
     uint32_t total = 0;
     if (!retry) {
-        uint32_t prev_word = 0;
+        uint32_t carry = 0;   // FF flags of the eight bytes in front of the tile, nearest first
         for (uint32_t t0 = 0; t0 * 4u < end; t0 += kWave) {
             const uint32_t wi = t0 + lane;
             uint32_t w = 0;
@@ -119,22 +119,27 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
                 if (bo + 4u <= guard) w = *reinterpret_cast<const uint32_t*>(base + bo);
                 else for (uint32_t q = 0; q < 4u; ++q) if (bo + q < guard) w |= (uint32_t)base[bo + q] << (8u * q);
             }
-            uint32_t q = __shfl_up(w, 1);
-            if (lane == 0) q = prev_word;
-            prev_word = __shfl(w, kWave - 1);
-            const uint64_t both = ((uint64_t)w << 32) | q;   // byte j of w sits at bit 32 + 8j
+            // which of this lane's four bytes are FF (bytes in front of the data never count)
+            uint32_t ff = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j)
+                ff |= (wi * 4u + j >= first && ((w >> (8u * j)) & 0xffu) == 0xffu ? 1u : 0u) << j;
+            // the flags of the eight bytes in front of this word, NEAREST FIRST (bit i: the byte i + 1 places back)
+            const uint32_t rev = __brev(ff) >> 28;                       // this word's flags, last byte in bit 0
+            uint32_t prev = __shfl_up(rev, 1) | (__shfl_up(rev, 2) << 4);
+            if (lane == 0) prev = carry;                                  // the eight bytes in front of the tile
+            if (lane == 1) prev = (prev & 0xfu) | ((carry & 0xfu) << 4);
+            carry = __shfl(rev, kWave - 1) | (__shfl(rev, kWave - 2) << 4);
             uint32_t keep = 0, cnt = 0;
             bool deep = false;
 #pragma unroll
             for (uint32_t j = 0; j < 4u; ++j) {
                 const uint32_t pos = wi * 4u + j;
-                uint32_t run = 0;   // FF bytes immediately before pos, never counting bytes before `first`
-#pragma unroll
-                for (uint32_t back = 1; back <= 4u + j; ++back) {
-                    const bool ff = pos >= first + back && ((both >> (32u + 8u * j - 8u * back)) & 0xffu) == 0xffu;
-                    if (ff && run == back - 1u) run = back;
-                }
-                if (run == 4u + j && pos > first + run) deep = true;   // the run reaches past the look-back
+                // flags in front of byte j, nearest first: this word's bytes j-1 .. 0, then `prev`
+                const uint32_t own = j == 0u ? 0u : __brev(ff & ((1u << j) - 1u)) >> (32u - j);
+                const uint32_t seq = own | (prev << j);                  // 8 + j flags
+                const uint32_t run = (uint32_t)__builtin_ctz(~seq);      // FF bytes immediately in front of pos
+                deep = deep || run >= 8u + j;                             // the run may reach past the look-back
                 const bool kept = pos >= first && pos < end && !(run & 1u);   // dropped iff an odd run of FF precedes it
                 keep |= (kept ? 1u : 0u) << j;
                 cnt += kept ? 1u : 0u;
