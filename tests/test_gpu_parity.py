@@ -633,3 +633,23 @@ def test_decode_large_frames(ctx, orc, w, h, n):
     want, wst = _oracle_decode(orc, chunks, w, h)
     assert (st == wst).all() and (wst[:n] == 0).all()
     assert (got == want).all()
+
+
+def test_c_host_links_and_matches_amvlib(pkg, amv1, tmp_path):
+    """a plain C program in the shape of the reference's AmvLibTest.cpp, compiled with gcc against include/amvhip.h and
+    linked with libamvhip.so, decodes the reference clip to the very hash amvlib produced"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "amvlib_host")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "amvlib_host.c"),
+                    "-L", libdir, "-l:" + os.path.basename(pkg.LIB_PATH), "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    wav = str(tmp_path / "out.wav")
+    out = subprocess.run([exe, amv1["path"], wav], check=True, capture_output=True, text=True, timeout=300).stdout
+    fields = dict(line.split(": ", 1) for line in out.strip().splitlines())
+    assert fields["size"] == "128 x 96" and fields["speed"] == "12 frames/s" and fields["total frames"] == "252"
+    assert fields["decoded frames"] == "252" and fields["pcm bytes"] == "672504"        # the byte count the survey recorded
+    assert fields["video chunk bytes"] == str(sum(map(len, amv1["video"])))
+    assert int(fields["video fnv1a64"], 16) == AMVLIB_HASH
+    assert os.path.getsize(wav) == 52 + sum(len(a) - 8 for a in amv1["audio"])
