@@ -623,18 +623,23 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
 
 }  // namespace
 
-// Lanes per frame for a batch of n frames on a device with `cus` compute units.  More lanes per frame
-// mean shorter walks (a shorter launch when the chip is not full) but more speculative work per frame
-// (every lane needs ~4 400 bits to fall in step whatever its share of the frame).  Measured on MI355X at
-// 160x120 and 320x240: the fastest choice is the most lanes for which the batch is at most ~10 waves per
-// CU (10 000 frames: 16; 20 000: 8; 2 000: 64).  `wanted` (8, 16, 32 or 64) overrides.
-int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted) {
+// Lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units.
+// More lanes per frame mean shorter walks (a shorter launch when the chip is not full) but more
+// speculative work per frame: every lane needs ~4 400 bits to fall in step whatever its share of the
+// frame.  Measured on MI355X: when the chip is full the best share is about that long (160x120 at
+// ~1.5 bits per pixel: 8 lanes; 320x240: 16), and a small batch does best with the most lanes that keep
+// it at ~10 waves per CU (10 000 frames of 160x120: 16; 2 000 of 320x240: 64).  `wanted` (8, 16, 32 or
+// 64) overrides.
+int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     if (wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
+    int full = 8;                                  // chip full: a share of ~4 000 bits, i.e. ~4 096 pixels
+    while (full < 64 && (uint64_t)full * 2u * 4096u <= pixels) full *= 2;
     const uint64_t waves = (uint64_t)cus * 10u;
-    if (n <= waves) return 64;
-    if (n <= 2u * waves) return 32;
-    if (n <= 4u * waves) return 16;
-    return 8;
+    int fill = 8;                                  // small batch: as many lanes as keep every task resident
+    if (n <= waves) fill = 64;
+    else if (n <= 2u * waves) fill = 32;
+    else if (n <= 4u * waves) fill = 16;
+    return fill > full ? fill : full;
 }
 
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,

@@ -23,8 +23,8 @@ void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
                     uint32_t cap_words, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
                     hipStream_t s);
-// lanes per frame for a batch of n frames on a device with `cus` compute units (amv_decode_sync.hip)
-int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted);
+// lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units (amv_decode_sync.hip)
+int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels);
 // Where the entropy stage puts its result.  rec == nullptr: dense coefficient lines in coef
 // ([n][blocks][64] int16).  Otherwise the records form, per frame: rec[cap_rec] (one word per
 // non-zero AC coefficient: bits 0-5 index in block, 6-19 block, 20-31 value), dcv[blocks] predicted

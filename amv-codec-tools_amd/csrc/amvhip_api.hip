@@ -287,7 +287,7 @@ static int entropy_stage(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
         Timed t(c, AMVHIP_K_HUFFMAN, st);
         unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
         launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, cap_words,
-                            huffman_sync_lanes(n, c->cus, c->sync_lanes), c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1,
+                            huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height), c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1,
                             stats, c->cus, st);
     }
     if (int r = check_launch(c, "huffman_sync")) return r;
