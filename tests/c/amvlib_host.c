@@ -1,14 +1,16 @@
 /*
- * amvlib_host.c -- a C host of the amvlib call surface, in the shape of the reference's own test program
- * (C-AMVDecoder/AmvLibTest/AmvLibTest.cpp:11-85: AmvOpen, AmvCreateWavFileFromAmvFile, the header print-out,
- * the AmvReadNextFrame loop, AmvClose) plus the two decode calls its player makes per frame
- * (AMVDecoderDlg.cpp FillBuffer).  Built by tests/test_gpu_parity.py with plain gcc against include/amvhip.h and
- * linked with libamvhip.so: what a maintainer's program does when it swaps amvlib for this library.
+ * amvlib_host.c -- a plain C host of the amvlib call surface.
+ *
+ * It makes the calls the reference's console test makes (C-AMVDecoder/AmvLibTest/AmvLibTest.cpp:11-85: open,
+ * export the audio as an ADPCM WAV, print the header, walk the frames, close) and, per frame, the two decode
+ * calls of its player (AMVDecoderDlg.cpp FillBuffer).  tests/test_gpu_parity.py builds it with gcc against
+ * include/amvhip.h and links it with libamvhip.so: what a maintainer's program does when it swaps amvlib for
+ * this library.
  *
  *     amvlib_host <file.amv> <out.wav>
  *
- * prints the header fields, per-stream totals and the chained FNV-1a-64 of every decoded BGR frame (seeded as the
- * survey's harness was, so the figure can be compared with the one amvlib itself produced).
+ * Output: "key: value" lines -- header fields, per-stream totals, and the chained FNV-1a-64 of every decoded
+ * BGR frame, seeded as the survey's harness was so that it can be compared with the figure amvlib produced.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -16,52 +18,60 @@
 
 #include "amvhip.h"
 
+struct totals {
+    unsigned long frames, video_in, audio_in, pcm_out;
+    uint64_t fnv;
+};
+
+static void fold(struct totals *t, const unsigned char *p, unsigned int n)
+{
+    unsigned int i;
+    for (i = 0; i < n; ++i) t->fnv = (t->fnv ^ p[i]) * 1099511628211ull;
+}
+
+static int play(AMVDecoder *d, struct totals *t)
+{
+    while (AmvReadNextFrame(d) == 0 && d->framebuf.framenum != -1) {
+        t->video_in += d->framebuf.videobufflen;
+        t->audio_in += d->framebuf.audiobufflen;
+        if (AmvVideoDecode(d) != 0 || AmvAudioDecode(d) != 0) {
+            printf("error: decode failed at frame %d\n", d->framebuf.framenum);
+            return -1;
+        }
+        fold(t, d->videobuf.fbmpdat, d->videobuf.len);
+        t->pcm_out += 4ul * (d->framebuf.audiobufflen - 8);   /* the chunk's defined samples: two per byte */
+        t->frames++;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    AMVDecoder *amvdec;
-    AMVInfo *amvinfo;
-    FRAMEBUFF *fbuff;
-    uint64_t hash = 1469598103934665603ull;
-    unsigned long video_bytes = 0, audio_bytes = 0, pcm_bytes = 0, frames = 0;
-    unsigned int i;
+    struct totals t = {0, 0, 0, 0, 1469598103934665603ull};
+    const AMVInfo *hdr;
+    AMVDecoder *d;
 
     if (argc < 3) {
         printf("usage: amvlib_host file.amv out.wav\n");
         return 2;
     }
-    amvdec = AmvOpen(argv[1]);
-    if (amvdec == NULL) return 1;
-    amvinfo = &amvdec->amvinfo;
-    if (AmvCreateWavFileFromAmvFile(amvdec, AUDIO_FILE_TYPE_ADPCM_IMA, argv[2]) != 0) return 1;
-
-    printf("frame interval: %u us\n", amvinfo->dwMicroSecPerFrame);
-    printf("size: %u x %u\n", amvinfo->dwWidth, amvinfo->dwHeight);
-    printf("speed: %u frames/s\n", amvinfo->dwSpeed);
-    printf("duration: %u h %u min %u s\n", amvinfo->dwTimeHour, amvinfo->dwTimeMin, amvinfo->dwTimeSec);
-    printf("total frames: %u\n", amvdec->totalframe);
-    printf("audio: %u ch, %u Hz, %u bits, %u bytes/s\n", amvinfo->nChannels, amvinfo->nSamplesPerSec,
-           amvinfo->wBitsPerSample, amvinfo->nAvgBytesPerSec);
-
-    for (;;) {
-        if (AmvReadNextFrame(amvdec) != 0) break;
-        fbuff = &amvdec->framebuf;
-        if (fbuff->framenum == -1) break;
-        video_bytes += fbuff->videobufflen;
-        audio_bytes += fbuff->audiobufflen;
-        if (AmvVideoDecode(amvdec) != 0) { printf("video decode failed at frame %d\n", fbuff->framenum); return 1; }
-        for (i = 0; i < amvdec->videobuf.len; ++i) {
-            hash ^= amvdec->videobuf.fbmpdat[i];
-            hash *= 1099511628211ull;
-        }
-        if (AmvAudioDecode(amvdec) != 0) { printf("audio decode failed at frame %d\n", fbuff->framenum); return 1; }
-        pcm_bytes += 4ul * (fbuff->audiobufflen - 8);     /* the defined samples of the chunk: 2 per byte */
-        ++frames;
-    }
-    printf("decoded frames: %lu\n", frames);
-    printf("video chunk bytes: %lu\n", video_bytes);
-    printf("audio chunk bytes: %lu\n", audio_bytes);
-    printf("pcm bytes: %lu\n", pcm_bytes);
-    printf("video fnv1a64: %016llx\n", (unsigned long long)hash);
-    AmvClose(amvdec);
+    d = AmvOpen(argv[1]);
+    if (d == NULL) return 1;
+    if (AmvCreateWavFileFromAmvFile(d, AUDIO_FILE_TYPE_ADPCM_IMA, argv[2]) != 0) return 1;
+    hdr = &d->amvinfo;
+    printf("frame interval: %u us\n", hdr->dwMicroSecPerFrame);
+    printf("size: %u x %u\n", hdr->dwWidth, hdr->dwHeight);
+    printf("speed: %u frames/s\n", hdr->dwSpeed);
+    printf("duration: %u h %u min %u s\n", hdr->dwTimeHour, hdr->dwTimeMin, hdr->dwTimeSec);
+    printf("total frames: %u\n", d->totalframe);
+    printf("audio: %u ch, %u Hz, %u bits, %u bytes/s\n", hdr->nChannels, hdr->nSamplesPerSec, hdr->wBitsPerSample,
+           hdr->nAvgBytesPerSec);
+    if (play(d, &t) != 0) return 1;
+    printf("decoded frames: %lu\n", t.frames);
+    printf("video chunk bytes: %lu\n", t.video_in);
+    printf("audio chunk bytes: %lu\n", t.audio_in);
+    printf("pcm bytes: %lu\n", t.pcm_out);
+    printf("video fnv1a64: %016llx\n", (unsigned long long)t.fnv);
+    AmvClose(d);
     return 0;
 }
