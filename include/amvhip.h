@@ -192,7 +192,9 @@ uint32_t amvhip_jpeg_header(uint16_t height, uint16_t width, uint8_t *out, uint3
  *   d_status   : n int32, AMVHIP_ST_* bits
  *   stream     : hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue.
  * Workspace is owned by ctx and grown on demand (a hipMalloc on first use of a larger
- * batch; none in steady state).
+ * batch; none in steady state).  Calls on one context reuse that workspace, so they must be
+ * ordered on the device: keep a context on one stream at a time (the lock inside only orders the
+ * enqueueing) and create one context per stream for work that is meant to overlap.
  */
 int amvhip_decode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_bytes,
                             const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n,
