@@ -84,8 +84,9 @@ def timed(E, step, steps, warmup):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    E.ctx.prof_enable(True)
-    E.ctx.prof_reset()
+    for c in [E.ctx] + getattr(E, "extra_ctx", []):
+        c.prof_enable(True)
+        c.prof_reset()
     if E.world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -96,16 +97,18 @@ def timed(E, step, steps, warmup):
     if E.world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    E.ctx.prof_enable(False)
+    for c in [E.ctx] + getattr(E, "extra_ctx", []):
+        c.prof_enable(False)
     return E.sh.max_over_ranks(elapsed, E.dev)
 
 
-def kernel_times(E, ids):
+def kernel_times(E, ids, ctx=None):
+    ctx = ctx or E.ctx
     kern = {}
     for k in ids:
-        launches, ms = E.ctx.prof_read(k)
+        launches, ms = ctx.prof_read(k)
         if launches:
-            kern[E.ctx.kernel_name(k)] = {"launches": launches, "avg_ms": ms / launches}
+            kern[ctx.kernel_name(k)] = {"launches": launches, "avg_ms": ms / launches}
     return kern
 
 
@@ -350,10 +353,13 @@ def run_adpcm(E, args, with_video=False):
     torch.cuda.synchronize()                   # the sources were made on the main stream
     side = torch.cuda.Stream(device=dev) if with_video else None
     astream = side.cuda_stream if with_video else stream
+    actx = pkg.Context(dev.index) if with_video else ctx    # one context per stream that is meant to overlap
+    if with_video:
+        E.extra_ctx = [actx]
 
     def audio():
-        ctx.adpcm_encode_batch_dev(d_pcm, d_pcm_offs, d_nsamp, na, None, d_chunks, d_offs, astream)
-        ctx.adpcm_decode_batch_dev(d_chunks, na * clen, d_offs, d_lens, na, d_pcm2, d_pcm_offs, None, astream)
+        actx.adpcm_encode_batch_dev(d_pcm, d_pcm_offs, d_nsamp, na, None, d_chunks, d_offs, astream)
+        actx.adpcm_decode_batch_dev(d_chunks, na * clen, d_offs, d_lens, na, d_pcm2, d_pcm_offs, None, astream)
 
     def step():
         if with_video:
@@ -383,7 +389,7 @@ def run_adpcm(E, args, with_video=False):
     audio_bytes = na * (clen + 2 * spf)
     if with_video:
         kern = kernel_times(E, (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON))
-        audio_kern = kernel_times(E, (pkg.K_ADPCM_DEC, pkg.K_ADPCM_ENC))   # on the second stream, overlapped with the video kernels
+        audio_kern = kernel_times(E, (pkg.K_ADPCM_DEC, pkg.K_ADPCM_ENC), actx)   # on the second stream, overlapped with the video kernels
         result = base_result(E, args, "AMV frames/sec/GPU (%dx%d decode with co-resident IMA-ADPCM, bit-exact)" % (w, h),
                              "frames/s", n, elapsed)
         result["config"] = {"workload": "%dx%d AMV decode of %d frames per GPU on one HIP stream, IMA-ADPCM encode + decode of "
