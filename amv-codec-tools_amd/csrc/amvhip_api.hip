@@ -708,7 +708,7 @@ extern "C" const char* amvhip_kernel_name(int kernel) {
         case AMVHIP_K_PACK_SERIAL: return "amv_pack_kernel";
         case AMVHIP_K_COMPACT: return "amv_scan_kernel+amv_gather_kernel";
         case AMVHIP_K_ADPCM_DEC: return "amv_adpcm_decode_kernel";
-        case AMVHIP_K_ADPCM_ENC: return "amv_adpcm_encode_kernel";
+        case AMVHIP_K_ADPCM_ENC: return "amv_adpcm_map_kernel+amv_adpcm_chain_*+amv_adpcm_encode_kernel";
         case AMVHIP_K_SYNTH: return "amv_synth_frames_kernel";
         default: return "";
     }

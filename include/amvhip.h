@@ -322,7 +322,7 @@ int amvhip_mux_close(amvhip_muxer *m);
 #define AMVHIP_K_FDCT 2
 #define AMVHIP_K_PACK 3
 #define AMVHIP_K_ADPCM_DEC 4
-#define AMVHIP_K_ADPCM_ENC 5
+#define AMVHIP_K_ADPCM_ENC 5       /* map + chain + encode kernels, timed as one (the map dominates) */
 #define AMVHIP_K_SYNTH 6
 #define AMVHIP_K_HUFFMAN_SERIAL 7
 #define AMVHIP_K_UNSTUFF 8
