@@ -26,16 +26,32 @@ def shard_tables(offs, lens, rank, world):
     return lo, hi, int(offs[lo]), int(offs[hi - 1]) + int(lens[hi - 1])
 
 
+def _as_tensor(x, dtype):
+    """numpy array or torch tensor (host or device) -> torch tensor of `dtype`, no copy when possible"""
+    if isinstance(x, np.ndarray):
+        if x.dtype == np.uint64:
+            x = x.view(np.int64)
+        elif x.dtype == np.uint32:
+            x = x.view(np.int32)
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    return x if x.dtype == dtype else x.to(dtype)
+
+
 def scatter_stream(blob, offs, lens, device, src=0):
-    """rank `src` holds (blob uint8, offs uint64, lens uint32) as numpy; every rank returns its own
-    (blob tensor on `device`, offs int64 rebased to 0, lens int32, first_frame).  Other ranks pass None."""
+    """rank `src` holds the stream (blob uint8, offs, lens) as numpy arrays or as torch tensors (host or
+    already on `device`: then every move is device to device); every rank returns its own
+    (blob tensor on `device`, offs int64 rebased to 0, lens int32, first_frame).  Other ranks pass None.
+    One broadcast of the split table (4 numbers per rank), then one scatter each for bytes, offsets, lengths."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    meta = torch.zeros(2 + 4 * world, dtype=torch.int64, device=device)
+    meta = torch.zeros(2 + 4 * world, dtype=torch.int64)
     if rank == src:
-        n = len(lens)
-        rows = [shard_tables(offs, lens, r, world) for r in range(world)]
+        blob, offs, lens = _as_tensor(blob, torch.uint8), _as_tensor(offs, torch.int64), _as_tensor(lens, torch.int32)
+        n = int(lens.numel())
+        o_h, l_h = offs.cpu().numpy(), lens.cpu().numpy()          # the split table is made on the host
+        rows = [shard_tables(o_h, l_h, r, world) for r in range(world)]
         meta[0], meta[1] = n, max(1, max(b1 - b0 for _, _, b0, b1 in rows))
         meta[2:] = torch.tensor(rows, dtype=torch.int64).flatten()
+    meta = meta.to(device)
     dist.broadcast(meta, src)
     m = meta.cpu().tolist()
     n, maxb = m[0], m[1]
@@ -45,16 +61,17 @@ def scatter_stream(blob, offs, lens, device, src=0):
     my_offs = torch.zeros(maxf, dtype=torch.int64, device=device)
     my_lens = torch.zeros(maxf, dtype=torch.int32, device=device)
     if rank == src:
+        blob, offs, lens = blob.to(device), offs.to(device), lens.to(device)
         bl, ol, ll = [], [], []
         for r in range(world):
             rlo, rhi, rb0, rb1 = m[2 + 4 * r: 6 + 4 * r]
-            b = torch.zeros(maxb, dtype=torch.uint8)
-            b[: rb1 - rb0] = torch.from_numpy(np.ascontiguousarray(blob[rb0:rb1]))
-            o = torch.zeros(maxf, dtype=torch.int64)
-            o[: rhi - rlo] = torch.from_numpy((offs[rlo:rhi].astype(np.int64) - rb0))
-            ln = torch.zeros(maxf, dtype=torch.int32)
-            ln[: rhi - rlo] = torch.from_numpy(lens[rlo:rhi].astype(np.int32))
-            bl.append(b.to(device)); ol.append(o.to(device)); ll.append(ln.to(device))
+            b = torch.zeros(maxb, dtype=torch.uint8, device=device)
+            b[: rb1 - rb0] = blob[rb0:rb1]
+            o = torch.zeros(maxf, dtype=torch.int64, device=device)
+            o[: rhi - rlo] = offs[rlo:rhi] - rb0
+            ln = torch.zeros(maxf, dtype=torch.int32, device=device)
+            ln[: rhi - rlo] = lens[rlo:rhi]
+            bl.append(b); ol.append(o); ll.append(ln)
         dist.scatter(my_blob, bl, src)
         dist.scatter(my_offs, ol, src)
         dist.scatter(my_lens, ll, src)
@@ -96,3 +113,19 @@ def sum_over_ranks(value, device):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def strong_step(blob, offs, lens, n_total, device, decode, src=0, clock=None):
+    """BASELINE.json configs[3] as stated: ONE stream of n_total frames held by rank `src` is frame-sharded over the
+    ranks -- scatter-v of the compressed chunks, decode(my_blob, my_offs, my_lens, first_frame) -> [n_local, ...]
+    uint8 frames on `device`, gather of the frames back to `src`.  Returns (frames on src | None, seconds per phase)
+    with clock() read after each phase (pass a function that synchronises the device first when timing a GPU)."""
+    clock = clock or (lambda: 0.0)
+    t0 = clock()
+    my_blob, my_offs, my_lens, first = scatter_stream(blob, offs, lens, device, src)
+    t1 = clock()
+    local = decode(my_blob, my_offs, my_lens, first)
+    t2 = clock()
+    full = gather_frames(local, n_total, src)
+    t3 = clock()
+    return full, {"scatter": t1 - t0, "decode": t2 - t1, "gather": t3 - t2}

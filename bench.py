@@ -211,6 +211,12 @@ def run_decode(E, args):
         (lambda dom: profiled_traffic("", dom)) if (w, h, n) == (160, 120, DECODE_FRAMES) else None,
         {"entropy_sync_rounds": {"mean": sync["rounds"] / max(sync["frames"], 1), "max": sync["max_rounds"]}})
 
+    if E.dist:          # config 4 as BASELINE.json states it, beside the weak-scaling line above
+        result["config"]["scaling_modes"] = {"weak": "value / ms_per_step of this line: every GPU decodes its own %d frames" % n,
+                                             "strong": "config4_strong_10k"}
+        strong = run_strong(E, args, w, h)
+        result["config"]["config4_strong_10k"] = strong
+
     if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
         m = min(args.cpu_sample, n)
         blob_h = d_blob[: int(offs_h[m - 1]) + int(lens_h[m - 1]) + 16].cpu().numpy()
@@ -231,6 +237,71 @@ def run_decode(E, args):
                                             "frame-sharded over %d OpenMP threads, %d passes" % (m, cores, reps),
                                   "single_thread_value": m / t1}
     return result
+
+
+# ---------------------------------------------------------------------------------------------
+def run_strong(E, args, w, h, n_total=10000):
+    """BASELINE.json configs[3] as it is stated: ONE 10 000-frame 160x120 stream, held by rank 0 in HBM, frame-sharded
+    over the ranks: scatter-v of the chunks over RCCL, per-rank decode through the C ABI, gather of the BGR frames back
+    to rank 0 -- timed end to end ("scaling": "strong").  Runs next to the weak-scaling line, never instead of it."""
+    ctx, dev, stream, sh = E.ctx, E.dev, E.stream, E.sh
+    d_blob = d_offs = d_lens = None
+    if E.rank == 0:
+        d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, 0, n_total, w, h)
+    maxf = max(hi - lo for lo, hi in (sh.frame_range(n_total, r, E.world) for r in range(E.world)))
+    d_out = torch.empty((maxf, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
+    d_st = torch.empty(maxf, dtype=torch.int32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def decode(my_blob, my_offs, my_lens, first):
+        k = int(my_lens.numel())
+        ctx.decode_batch_dev(my_blob, int(my_blob.numel()), my_offs, my_lens, k, w, h, 0, d_out, d_st, stream)
+        bad.add_((d_st[:k] != 0).sum())
+        return d_out[:k]
+
+    def clock():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    # gate: the gathered frames equal one GPU decoding the whole stream by itself, and the oracle on a sample
+    full, _ = sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode)
+    torch.cuda.synchronize()
+    ok = 1
+    if E.rank == 0:
+        ref = torch.empty((n_total, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
+        st = torch.empty(n_total, dtype=torch.int32, device=dev)
+        ctx.decode_batch_dev(d_blob, cap, d_offs, d_lens, n_total, w, h, 0, ref, st, stream)
+        torch.cuda.synchronize()
+        ok = int(torch.equal(full, ref) and int((st != 0).sum().item()) == 0)
+        orc = entry.load_oracle()
+        offs_h, lens_h = d_offs.cpu().numpy(), d_lens.cpu().numpy()
+        for i in sorted({0, min(n_total // E.world, n_total - 1), n_total // 2, n_total - 1}):
+            ch = d_blob[int(offs_h[i]):int(offs_h[i]) + int(lens_h[i])].cpu().numpy().tobytes()
+            ok &= int((full[i].cpu().numpy() == orc.decode_frame(ch, w, h)[0]).all())
+        del ref
+    ok = int(sh.sum_over_ranks(float(ok), dev)) == E.world and int(sh.sum_over_ranks(float(bad.item()), dev)) == 0
+    if not ok:
+        raise SystemExit("strong-scaling leg: gathered frames differ from the single-GPU decode / the oracle")
+    del full
+
+    steps = max(3, min(args.steps, 10))
+    phases = {"scatter": 0.0, "decode": 0.0, "gather": 0.0}
+    for _ in range(2):
+        sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode)
+    dist.barrier()
+    t0 = clock()
+    for _ in range(steps):
+        _, ph = sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode, clock=clock)
+        for k in phases:
+            phases[k] += ph[k]
+    dist.barrier()
+    elapsed = sh.max_over_ranks(clock() - t0, dev)
+    phases = {k: sh.max_over_ranks(v, dev) / steps * 1e3 for k, v in phases.items()}
+    return {"scaling": "strong", "workload": "one %d-frame %dx%d stream on rank 0 -> scatter-v of chunks (RCCL) -> per-rank decode "
+                                            "-> gather of BGR frames to rank 0, end to end" % (n_total, w, h),
+            "frames": n_total, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "frames_per_s": n_total * steps / elapsed,
+            "phase_ms_max_over_ranks": phases, "backend": dist.get_backend(), "n_gpus": E.world,
+            "gathered_bytes_per_step": n_total * h * ctx.stride(w)}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -437,6 +508,9 @@ def main():
                          "encoder in tests/test_oracle_pin.py::test_encode_round_trip_quality (26.6 at 320x240, 25.4 below: "
                          "amvlib's colour matrix is not the inverse of the encoder's, which bounds the figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="decode: also run configs[3] as stated (one 10 000-frame stream scattered from rank 0, decoded, gathered "
+                         "back) and report it under config.config4_strong_10k; always on when WORLD_SIZE > 1")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="frames of the stream the CPU baseline decodes")
     args = ap.parse_args()
 
@@ -444,12 +518,15 @@ def main():
     E.world = int(os.environ.get("WORLD_SIZE", "1"))
     E.rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if E.world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=E.rank, world_size=E.world)   # RCCL over xGMI
+    E.dist = E.world > 1 or args.strong
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the codec path has no CPU fallback")
     torch.cuda.set_device(local)
+    if E.dist:          # --strong with one process: the same RCCL code path, world size 1 (a rehearsal on a one-GPU box)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=E.rank, world_size=E.world,    # RCCL over xGMI
+                                device_id=torch.device("cuda", local))
     E.dev = torch.device("cuda", local)
     E.pkg = entry.load_package()
     E.sh = entry._load(entry.PKG_NAME + ".sharding", os.path.join(entry.PKG_DIR, "sharding.py"))
@@ -467,7 +544,7 @@ def main():
     if E.rank == 0:
         print(json.dumps(result))
     E.ctx.close()
-    if E.world > 1:
+    if E.dist:
         dist.destroy_process_group()
 
 

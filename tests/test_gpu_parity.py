@@ -653,3 +653,53 @@ def test_c_host_links_and_matches_amvlib(pkg, amv1, tmp_path):
     assert fields["video chunk bytes"] == str(sum(map(len, amv1["video"])))
     assert int(fields["video fnv1a64"], 16) == AMVLIB_HASH
     assert os.path.getsize(wav) == 52 + sum(len(a) - 8 for a in amv1["audio"])
+
+
+def test_coresident_video_and_adpcm_streams(pkg, orc):
+    """BASELINE.json configs[4]: 320x240 video decode on HIP stream A while IMA-ADPCM encode (step index carried)
+    + decode of the frames' audio chunks run on stream B -- two contexts (one per stream, as include/amvhip.h
+    prescribes for work that overlaps), enqueued back to back with no synchronisation in between, twice over so
+    that the second round's kernels meet the first round's on the device.  EVERY frame, chunk and sample is
+    compared with the oracle."""
+    import torch
+    dev = "cuda:0"
+    w, h, n, spf = 320, 240, 192, 1378
+    vctx, actx = pkg.Context(0), pkg.Context(0)
+    blob, offs, lens = orc.synth_stream(SEED, 500, n, w, h, threads=8)
+    want_frames, want_st = orc.decode_batch(blob, offs, lens, w, h, 0, threads=8)
+    pcm = orc.synth_audio(SEED, 777, n * spf)
+    clen = 8 + spf // 2
+    want_chunks, idx = [], 0
+    for i in range(n):
+        c, idx = orc.adpcm_encode_chunk(pcm[i * spf:(i + 1) * spf], idx)
+        want_chunks.append(c)
+    want_pcm = np.concatenate([orc.adpcm_decode_chunk(c)[0][:spf] for c in want_chunks])
+
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    d_blob, d_offs, d_lens = _t(blob), _t(offs), _t(lens)
+    d_pcm = _t(pcm)
+    d_pcm_offs = torch.arange(n, dtype=torch.int64, device=dev) * spf
+    d_nsamp = torch.full((n,), spf, dtype=torch.int32, device=dev)
+    d_aoffs = torch.arange(n, dtype=torch.int64, device=dev) * clen
+    d_alens = torch.full((n,), clen, dtype=torch.int32, device=dev)
+    outs = []
+    torch.cuda.synchronize()
+    for rnd in range(2):
+        d_out = torch.full((n, h, vctx.stride(w)), 0x5A, dtype=torch.uint8, device=dev)
+        d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        d_chunks = torch.zeros(n * clen + 16, dtype=torch.uint8, device=dev)
+        d_pcm2 = torch.zeros(n * spf + 8, dtype=torch.int16, device=dev)
+        outs.append((d_out, d_st, d_chunks, d_pcm2))
+    torch.cuda.synchronize()
+    for d_out, d_st, d_chunks, d_pcm2 in outs:        # no host synchronisation inside this loop
+        vctx.decode_batch_dev(d_blob, blob.size, d_offs, d_lens, n, w, h, 0, d_out, d_st, sa.cuda_stream)
+        actx.adpcm_encode_batch_dev(d_pcm, d_pcm_offs, d_nsamp, n, None, d_chunks, d_aoffs, sb.cuda_stream)
+        actx.adpcm_decode_batch_dev(d_chunks, n * clen, d_aoffs, d_alens, n, d_pcm2, d_pcm_offs, None, sb.cuda_stream)
+    torch.cuda.synchronize()
+    for d_out, d_st, d_chunks, d_pcm2 in outs:
+        assert (d_st.cpu().numpy() == want_st).all() and (want_st == 0).all()
+        assert (d_out.cpu().numpy() == want_frames).all()
+        assert d_chunks[: n * clen].cpu().numpy().tobytes() == b"".join(want_chunks)
+        assert (d_pcm2[: n * spf].cpu().numpy() == want_pcm).all()
+    vctx.close()
+    actx.close()

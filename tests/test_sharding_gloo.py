@@ -36,17 +36,29 @@ def _worker(rank, world, port, q):
         blob = offs = lens = None
         if rank == 0:
             blob, offs, lens = orc.synth_stream(SEED, 0, N, W, H)
-        my_blob, my_offs, my_lens, first = sh.scatter_stream(blob, offs, lens, dev)
         lo, hi = sh.frame_range(N, rank, world)
-        assert first == lo and my_lens.numel() == hi - lo
-        b = my_blob.numpy()
-        frames = np.zeros((hi - lo, H, orc.stride(W)), np.uint8)
-        for i in range(hi - lo):
-            o, ln = int(my_offs[i]), int(my_lens[i])
-            out, st, _ = orc.decode_frame(b[o:o + ln].tobytes(), W, H)
-            assert st == 0
-            frames[i] = out
-        full = sh.gather_frames(torch.from_numpy(frames), N)
+
+        def decode(my_blob, my_offs, my_lens, first):
+            assert first == lo and my_lens.numel() == hi - lo
+            b = my_blob.numpy()
+            frames = np.zeros((hi - lo, H, orc.stride(W)), np.uint8)
+            for i in range(hi - lo):
+                o, ln = int(my_offs[i]), int(my_lens[i])
+                out, st, _ = orc.decode_frame(b[o:o + ln].tobytes(), W, H)
+                assert st == 0
+                frames[i] = out
+            return torch.from_numpy(frames)
+
+        # the move bench.py times for BASELINE configs[3]: scatter-v -> per-rank decode -> gather; the stream is handed
+        # over as numpy arrays the first time and as torch tensors (what bench.py holds) the second
+        full, phases = sh.strong_step(blob, offs, lens, N, dev, decode)
+        assert set(phases) == {"scatter", "decode", "gather"}
+        if rank == 0:
+            tb, to, tl = torch.from_numpy(blob), torch.from_numpy(offs.view(np.int64)), torch.from_numpy(lens.view(np.int32))
+            full2, _ = sh.strong_step(tb, to, tl, N, dev, decode)
+            assert torch.equal(full, full2)
+        else:
+            sh.strong_step(None, None, None, N, dev, decode)
         slow = sh.max_over_ranks(float(rank + 1), dev)
         total = sh.sum_over_ranks(float(hi - lo), dev)
         assert slow == float(world) and total == float(N)
