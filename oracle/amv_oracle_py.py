@@ -12,6 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libamvoracle.so")
 REF = os.path.join(HERE, "_ref", "libamvref.so")
+AVCREF = os.path.join(HERE, "_ref", "libavcref.so")
 
 ST_FORMAT, ST_OVERRUN, ST_TRUNCATED = 1, 2, 4
 FLAG_ZIGZAG_FIXED = 1
@@ -28,7 +29,9 @@ def build(force=False):
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(
             os.path.getmtime(os.path.join(HERE, f)) for f in ("amv_oracle.c", "amv_oracle.h", "Makefile")):
         subprocess.run(["make", "-C", HERE, "-s", "libamvoracle.so"], check=True)
-    if os.path.isdir("/root/reference") and (force or not os.path.exists(REF)):
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(REF) or not os.path.exists(AVCREF)
+                                             or os.path.getmtime(AVCREF) < max(os.path.getmtime(os.path.join(HERE, f))
+                                                                               for f in ("ref_harness.c", "Makefile"))):
         subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
 
 
@@ -87,6 +90,43 @@ def ref():
         R.ff_jpeg_fdct_islow.argtypes = [_vp]
         _ref = R
     return _ref
+
+
+_avcref = None
+
+
+def avcref():
+    """oracle/_ref/libavcref.so: the reference's own mjpegenc.c / mjpeg.c / simple_idct.c / sp5x.h behind
+    ref_harness.c, or None when not built"""
+    global _avcref
+    if _avcref is None and os.path.exists(AVCREF):
+        R = ctypes.CDLL(AVCREF)
+        R.amvref_mjpeg_encode_scan.restype = _int
+        R.amvref_mjpeg_encode_scan.argtypes = [_vp, _int, _vp, _int]
+        R.amvref_simple_idct.restype = None
+        R.amvref_simple_idct.argtypes = [_vp, _int]
+        R.amvref_sp5x_quant.restype = None
+        R.amvref_sp5x_quant.argtypes = [_int, _vp]
+        R.amvref_sp5x_segment.restype = _int
+        R.amvref_sp5x_segment.argtypes = [_int, _vp, _int]
+        R.amvref_mjpeg_huffman_spec.restype = _int
+        R.amvref_mjpeg_huffman_spec.argtypes = [_int, _vp, _vp]
+        R.amvref_mjpeg_huffman_codes.restype = None
+        R.amvref_mjpeg_huffman_codes.argtypes = [_int, _vp, _vp]
+        _avcref = R
+    return _avcref
+
+
+def ref_mjpeg_encode_scan(coef):
+    """coef [nmcu*6, 64] int16 (zig-zag order, not predicted) -> the bytes the REFERENCE's entropy coder +
+    picture trailer write (scan, padding, FF escaping, EOI)"""
+    coef = np.ascontiguousarray(coef, np.int16)
+    nm = coef.shape[0] // 6
+    buf = np.zeros(nm * 6 * 64 * 8 + 64, np.uint8)
+    n = avcref().amvref_mjpeg_encode_scan(coef.ctypes.data, nm, buf.ctypes.data, buf.size)
+    if n < 0:
+        raise RuntimeError("reference entropy coder failed")
+    return bytes(buf[:n])
 
 
 class RefADPCMChannelStatus(ctypes.Structure):  # reference AdpcmIma.h:11-18

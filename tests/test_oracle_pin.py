@@ -4,6 +4,12 @@ these pass:
                      produced (SURVEY.md section 8c / Appendix A step 5), quirk on and off;
   * audio decode, amvlib's WAV encoder, forward DCT -- bit-equal to oracle/_ref/libamvref.so,
                      which is compiled from the reference's AdpcmIma.c and jfdctint.c;
+  * entropy coder -- oracle/_ref/libavcref.so holds the reference's OWN mjpegenc.c / mjpeg.c (ff_mjpeg_encode_mb,
+                     stuffing, escape_FF, trailer) behind oracle/ref_harness.c: (i) re-coding the coefficients the
+                     oracle's decoder recovers from every chunk of the real AMV1.amv with the reference's coder gives
+                     the device-made chunk back byte for byte -- the oracle's Huffman DECODER is the inverse of the
+                     reference's coder; (ii) the oracle's ENCODER writes the bytes the reference's coder writes for the
+                     same coefficients;
   * committed golden vectors of the synthetic clips (tests/golden/synth_golden.json).
 """
 import ctypes
@@ -190,3 +196,63 @@ def test_synthetic_golden_vectors(orc):
     chunk, idx = orc.adpcm_encode_chunk(pcm, a["step_in"])
     assert "%016x" % orc.fnv1a64(orc.FNV_BASIS, pcm) == a["pcm_fnv"] and idx == a["step_out"]
     assert "%016x" % orc.fnv1a64(orc.FNV_BASIS, np.frombuffer(chunk, np.uint8)) == a["chunk_fnv"]
+
+
+def _need_avcref(orc):
+    R = orc.avcref()
+    if R is None:
+        pytest.skip("oracle/_ref/libavcref.so is built only where /root/reference exists")
+    return R
+
+
+def test_entropy_decoder_inverts_reference_coder_on_amv1(orc, amv1):
+    """All 252 device-made chunks of the reference's fixture: decode with the oracle (coefficients, DC already
+    accumulated = what encode_block takes with its predictors at 0), re-code with the reference's own
+    ff_mjpeg_encode_mb + ff_mjpeg_encode_picture_trailer (mjpegenc.c:437-450,345-355): byte-identical."""
+    _need_avcref(orc)
+    for i, chunk in enumerate(amv1["video"]):
+        _, st, ok, coef = orc.decode_frame(chunk, 128, 96, want_coef=True)
+        assert st == 0 and ok == 48
+        assert chunk[:2] == b"\xff\xd8" and orc.ref_mjpeg_encode_scan(coef) == chunk[2:], i
+
+
+def test_entropy_coder_matches_reference_build(orc):
+    """rows a20 / a21: the oracle encoder's scan bytes == the reference's entropy coder on the oracle's own
+    quantised blocks -- synthetic clips at both sizes and biases, partial MCUs, noise (many FF bytes, ZRL runs,
+    11-bit magnitudes), flat and saturated frames"""
+    _need_avcref(orc)
+    rng = np.random.default_rng(77)
+    cases = []
+    for w, h, n in ((160, 120, 6), (320, 240, 3), (176, 144, 2), (130, 98, 2), (16, 16, 2)):
+        cases += [(orc.synth_frame(SEED, 31 * t, w, h), w, h) for t in range(n)]
+    for w, h in ((160, 120), (48, 32)):
+        cases.append((rng.integers(0, 256, (h, w, 3), dtype=np.uint8), w, h))                       # noise
+        cases.append((np.full((h, w, 3), 255, np.uint8), w, h))                                      # white
+        cases.append((np.zeros((h, w, 3), np.uint8), w, h))                                          # black
+        chk = ((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.uint8)               # 1-pixel checker
+        cases.append((np.repeat(chk[:, :, None], 3, 2), w, h))
+    escaped = 0
+    for src, w, h in cases:
+        for qbias in (0, 128):
+            chunk, coef = orc.encode_frame(src, w, h, qbias=qbias, want_coef=True)
+            assert chunk[:2] == b"\xff\xd8" and chunk[-2:] == b"\xff\xd9"
+            assert orc.ref_mjpeg_encode_scan(coef) == chunk[2:], (w, h, qbias)
+            escaped += chunk.count(b"\xff\x00")
+    assert escaped > 50
+
+
+def test_huffman_tables_match_reference_build(orc):
+    """the K.3 specifications compiled into the oracle decode what mjpeg.c:62-127 specifies, and the canonical
+    code assignment equals ff_mjpeg_build_huffman_codes (mjpeg.c:129-147): checked by coding single symbols"""
+    R = _need_avcref(orc)
+    for t in range(4):
+        bits = np.zeros(17, np.uint8)
+        vals = np.zeros(256, np.uint8)
+        n = R.amvref_mjpeg_huffman_spec(t, bits.ctypes.data, vals.ctypes.data)
+        assert n == (12 if t < 2 else 162) and int(bits[1:].sum()) == n
+        size = np.zeros(256, np.uint8)
+        code = np.zeros(256, np.uint16)
+        R.amvref_mjpeg_huffman_codes(t, size.ctypes.data, code.ctypes.data)
+        assert int((size > 0).sum()) == n and size.max() <= 16
+        # Kraft sum of a complete-but-one prefix code (JPEG reserves the all-ones code)
+        assert sum(2.0 ** -int(s) for s in size if s) == 1.0 - 2.0 ** -int(size.max())
