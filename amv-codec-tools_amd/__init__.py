@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("AMVHIP_LIB") or os.path.join(_HERE, "libamvhip.so")  
 OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_SPACE = 0, -1, -2, -3, -4
 ST_FORMAT, ST_OVERRUN, ST_TRUNCATED = 1, 2, 4
 FLAG_ZIGZAG_FIXED = 1
+FLAG_FFMPEG = 2
 QBIAS_AMV, QBIAS_MJPEG = 0, 128
 K_HUFFMAN, K_RECON, K_FDCT, K_PACK, K_ADPCM_DEC, K_ADPCM_ENC, K_SYNTH, K_HUFFMAN_SERIAL, K_UNSTUFF, K_PACK_SERIAL, K_COMPACT = range(11)
 ENTROPY_AUTO, ENTROPY_SERIAL = 0, 1
@@ -86,6 +87,7 @@ SYMBOLS = {
     "amvhip_device": (_int, [_vp]),
     "amvhip_stride": (_u32, [_u32]),
     "amvhip_frame_bytes": (_u64, [_u32, _u32]),
+    "amvhip_yuv420_frame_bytes": (_u64, [_u32, _u32]),
     "amvhip_encode_bound": (_u32, [_u32, _u32]),
     "amvhip_jpeg_header": (_u32, [ctypes.c_ushort, ctypes.c_ushort, _vp, _u32]),
     "amvhip_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
@@ -188,6 +190,9 @@ class Context:
 
     def frame_bytes(self, w, h):
         return self.lib.amvhip_frame_bytes(w, h)
+
+    def yuv420_frame_bytes(self, w, h):
+        return self.lib.amvhip_yuv420_frame_bytes(w, h)
 
     def encode_bound(self, w, h):
         return self.lib.amvhip_encode_bound(w, h)

@@ -1,0 +1,62 @@
+// amv_block_load.h -- stage A of the reconstruction kernels: one 8x8 block of quantised coefficients per lane.
+//
+// A wave owns an MCU-row segment of `cnt` MCUs (<= 10, i.e. <= 60 blocks).  Lane b ends up with block b's 64
+// coefficients (scan order, int16 pairs in 32 dwords): from its dense 128-byte line, or -- records form -- after
+// the wave has scattered the segment's (block, index, value) records and DC values into a zeroed LDS image of the
+// blocks (16-byte granules XOR-swizzled by block so that the per-lane 128-byte reads do not collide on banks).
+#pragma once
+#include "amv_kernels.h"
+
+namespace amv {
+
+// s_img: >= cnt * 6 * 128 bytes of LDS, 16-byte aligned; the caller may reuse it after a __syncthreads().
+// Returns true when this lane holds a block (lane < cnt * 6).
+__device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_t f, const FrameGeom& g, uint32_t mcu0,
+                                                    uint32_t cnt, uint32_t ok, uint32_t lane, uint8_t* s_img,
+                                                    uint32_t (&c)[32]) {
+    constexpr uint32_t kWave = 64;
+    const uint32_t nb = cnt * 6u;
+    const bool records = in.rec != nullptr && in.rec_count[f] != 0xffffffffu;
+    if (records) {   // records -> dense image of the segment's blocks in LDS
+        uint4* img16 = reinterpret_cast<uint4*>(s_img);
+        for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
+        const uint32_t* ms = in.mcu_start + (uint64_t)f * (g.mcus + 1u);
+        const uint32_t r0 = ms[mcu0], r1 = ms[mcu0 + cnt_ok];
+        const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec;
+        int16_t* img = reinterpret_cast<int16_t*>(s_img);
+        for (uint32_t r = r0 + lane; r < r1; r += kWave) {
+            const uint32_t w = rec[r];
+            const uint32_t b = ((w >> 6) & 0x3fffu) - mcu0 * 6u, k = w & 63u;
+            if (b < cnt_ok * 6u) img[b * 64u + ((((k >> 3) ^ b) & 7u) << 3) + (k & 7u)] = (int16_t)((int)w >> 20);
+        }
+        if (lane < cnt_ok * 6u)
+            img[lane * 64u + ((lane & 7u) << 3)] = in.dcv[(uint64_t)f * g.blocks + mcu0 * 6u + lane];   // k = 0: granule 0 ^ b
+        __syncthreads();
+    }
+    if (lane >= nb) return false;
+    if (records) {
+        const uint4* src = reinterpret_cast<const uint4*>(s_img) + lane * 8u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 q = src[(uint32_t)i ^ (lane & 7u)];
+            c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+        }
+    } else {
+        const uint4* src = reinterpret_cast<const uint4*>(in.coef + (((uint64_t)f * g.mcus + mcu0) * 6u + lane) * 64u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 q = src[i];
+            c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+        }
+    }
+    return true;
+}
+
+// int16 number `i` of a block held as 32 dwords
+__device__ __forceinline__ int coef_at(const uint32_t (&c)[32], int i) {
+    return (i & 1) ? ((int)c[i >> 1] >> 16) : (int)(int16_t)(c[i >> 1] & 0xffffu);
+}
+
+}  // namespace amv

@@ -8,7 +8,7 @@ namespace amv {
 
 // status bits, same values as AMVHIP_ST_* in include/amvhip.h
 enum : uint32_t { kStFormat = 1u, kStOverrun = 2u, kStTruncated = 4u };
-enum : uint32_t { kFlagZigzagFixed = 1u };
+enum : uint32_t { kFlagZigzagFixed = 1u, kFlagFfmpeg = 2u };
 
 // ---- decode -------------------------------------------------------------------------------
 // entropy stage: one lane per frame, coefficients staged per block in LDS and written out as
@@ -49,6 +49,13 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
 // sinks.rec == nullptr: every frame is dense in sinks.coef; otherwise per frame as rec_count says
 void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n,
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s);
+
+// FFmpeg-compat back half (amv_reconstruct_ff.hip): Q60 dequantisation, simple_idct_put, YUVJ420P planes
+// (Y, Cb, Cr; tight rows) flipped as mjpegdec.c:672-677 does.  yuv_store_covers_planes: false when that formula
+// leaves plane rows unwritten (the caller clears the output first).
+void launch_reconstruct_yuv(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameGeom& g,
+                            uint64_t yuv_frame_bytes, uint8_t* out, hipStream_t s);
+bool yuv_store_covers_planes(const FrameGeom& g);
 
 // ---- encode -------------------------------------------------------------------------------
 // colour conversion + level shift + forward DCT + quantise: coef [n][blocks][64] int16 scan order

@@ -20,6 +20,17 @@ static constexpr uint8_t kQuantChroma[64] = {
     50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50,
     50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50};
 
+// the "Q60" tables the patched FFmpeg's AMV decoder dequantises with (libavcodec/sp5x.h:187-194 =
+// sp5x_quant_table[10], [11], selected by sp5xdec.c:40,60-61), bitstream order: AMVHIP_FLAG_FFMPEG only
+static constexpr uint8_t kQ60Luma[64] = {
+    13, 9,  10, 11, 10, 8,  13, 11, 10, 11, 14, 14, 13, 15, 19, 32, 21, 19, 18, 18, 19, 39,
+    28, 30, 23, 32, 46, 41, 49, 48, 46, 41, 45, 44, 51, 58, 74, 62, 51, 54, 70, 55, 44, 45,
+    64, 87, 65, 70, 76, 78, 82, 83, 82, 50, 62, 90, 97, 90, 80, 96, 74, 81, 82, 79};
+static constexpr uint8_t kQ60Chroma[64] = {
+    14, 14, 14, 19, 17, 19, 38, 21, 21, 38, 79, 53, 45, 53, 79, 79, 79, 79, 79, 79, 79, 79,
+    79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79,
+    79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79};
+
 // scan position of each natural (row-major) coefficient position
 static constexpr uint8_t kScanOfNatural[64] = {
     0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,

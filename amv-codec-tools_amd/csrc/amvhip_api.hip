@@ -243,6 +243,9 @@ extern "C" int amvhip_device(const amvhip_ctx* c) { return c ? c->device : -1; }
 
 extern "C" uint32_t amvhip_stride(uint32_t w) { return (w * 24 + 31) / 32 * 4; }
 extern "C" uint64_t amvhip_frame_bytes(uint32_t w, uint32_t h) { return (uint64_t)amvhip_stride(w) * h; }
+extern "C" uint64_t amvhip_yuv420_frame_bytes(uint32_t w, uint32_t h) {
+    return (uint64_t)w * h + 2ull * ((w + 1) / 2) * ((h + 1) / 2);
+}
 extern "C" uint32_t amvhip_encode_bound(uint32_t w, uint32_t h) {
     // per coefficient at most a 16-bit code + 11 magnitude bits (< 4 bytes), doubled by FF escaping
     return 4 + ((w + 15) / 16) * ((h + 15) / 16) * 6 * 64 * 4 * 2;
@@ -316,6 +319,16 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
 
 static int reconstruct_stage(amvhip_ctx* c, const SyncSinks& sinks, const uint32_t* d_nmcu_ok, uint32_t n,
                              const FrameGeom& g, uint32_t flags, uint8_t* d_out, hipStream_t st) {
+    if (flags & AMVHIP_FLAG_FFMPEG) {   // the patched FFmpeg's amv_decoder: YUVJ420P planes
+        const uint64_t fb = amvhip_yuv420_frame_bytes(g.width, g.height);
+        if (!yuv_store_covers_planes(g))  // mjpegdec.c:672-677 leaves rows of such heights unwritten: they read as zero
+            HIP_TRY(c, hipMemsetAsync(d_out, 0, fb * n, st));
+        {
+            Timed t(c, AMVHIP_K_RECON, st);
+            launch_reconstruct_yuv(sinks, d_nmcu_ok, n, g, fb, d_out, st);
+        }
+        return check_launch(c, "reconstruct_yuv");
+    }
     if (g.stride != g.width * 3)  // row padding bytes stay zero as in AMVDec.c:283
         HIP_TRY(c, hipMemsetAsync(d_out, 0, g.frame_bytes * n, st));
     {
@@ -373,7 +386,7 @@ extern "C" int amvhip_decode_batch(amvhip_ctx* c, const uint8_t* blob, uint64_t 
     if (!size_ok(w, h) || (n && (!blob || !offs || !lens || !out))) return fail(c, AMVHIP_ERR_ARG, "decode: bad argument");
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
-    const uint64_t fb = amvhip_frame_bytes(w, h);
+    const uint64_t fb = (flags & AMVHIP_FLAG_FFMPEG) ? amvhip_yuv420_frame_bytes(w, h) : amvhip_frame_bytes(w, h);
     if (int r = ensure(c, c->h_in, blob_bytes + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;

@@ -163,6 +163,13 @@ typedef struct amvhip_ctx amvhip_ctx;
 
 /* decode flags */
 #define AMVHIP_FLAG_ZIGZAG_FIXED 1u /* standard zig-zag instead of amvlib's table (AmvJpeg.c:138) */
+/* FFmpeg-compat mode: the output of the patched FFmpeg's amv_decoder instead of amvlib's -- sp5x "Q60" quantiser
+ * tables (libavcodec/sp5xdec.c:40,60-61, sp5x.h:187-194), standard zig-zag (dsputil.c:50-59), last_dc = 1024 on
+ * dequantised DC (mjpegdec.c:805,388-390), simple_idct_put (simple_idct.c:390-398) and planar YUVJ420P output
+ * flipped with the formula of mjpegdec.c:672-677.  d_out then holds n * amvhip_yuv420_frame_bytes(w,h) bytes:
+ * per frame the Y plane (w*h), then Cb and Cr ((w+1)/2 x (h+1)/2 each), rows tight.  The two reference decoders
+ * do NOT agree with each other; amvlib's output is the default and the headline target. */
+#define AMVHIP_FLAG_FFMPEG 2u
 
 /* encode quantiser bias in 1/256 of a step: 0 = the reference's AMV setting
  * (mpegvideo_enc.c:492-496), 128 = its MJPEG setting (round to nearest, :488-490). */
@@ -177,6 +184,7 @@ int amvhip_device(const amvhip_ctx *ctx);
 /* geometry helpers (AmvJpeg.c:420,1524: stride; :1276-1284: MCU grid) */
 uint32_t amvhip_stride(uint32_t width);
 uint64_t amvhip_frame_bytes(uint32_t width, uint32_t height);
+uint64_t amvhip_yuv420_frame_bytes(uint32_t width, uint32_t height);   /* YUVJ420P frame, tight planes (mjpegdec.c:312) */
 uint32_t amvhip_encode_bound(uint32_t width, uint32_t height);
 /* the bytes AmvJpegPutHeader writes (SOI ... SOS) for a picture size; returns their number (623) and
  * copies them to out when cap allows.  Host only. */

@@ -372,6 +372,194 @@ int amvo_decode_frame(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h
 }
 
 /* ------------------------------------------------------------------------------------
+ * FFmpeg-compat decode: what the patched FFmpeg's amv_decoder produces (sp5xdec.c:33-93 ->
+ * ff_mjpeg_decode_frame -> mjpeg_decode_scan mjpegdec.c:660-736 -> decode_block :376-430 ->
+ * simple_idct_put simple_idct.c:390-408).  Same bitstream and Huffman tables as above; different
+ * quantiser tables ("Q60", sp5x.h:187-195 via sp5xdec.c:40,60-61), the standard zig-zag
+ * (dsputil.c:50-59), DC kept in dequantised units from 1024 (mjpegdec.c:805,388-390), DCTELEM = int16
+ * everywhere, FFmpeg's simple_idct, planar YUVJ420P output flipped with the formula of :672-677.
+ * ---------------------------------------------------------------------------------- */
+static const uint8_t k_q60_luma[64] = { /* zig-zag order, sp5x.h:187-190 = sp5x_quant_table[10] */
+    13,  9, 10, 11, 10,  8, 13, 11, 10, 11, 14, 14, 13, 15, 19, 32,
+    21, 19, 18, 18, 19, 39, 28, 30, 23, 32, 46, 41, 49, 48, 46, 41,
+    45, 44, 51, 58, 74, 62, 51, 54, 70, 55, 44, 45, 64, 87, 65, 70,
+    76, 78, 82, 83, 82, 50, 62, 90, 97, 90, 80, 96, 74, 81, 82, 79 };
+static const uint8_t k_q60_chroma[64] = { /* sp5x.h:191-194 = sp5x_quant_table[11] */
+    14, 14, 14, 19, 17, 19, 38, 21, 21, 38, 79, 53, 45, 53, 79, 79,
+    79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79,
+    79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79,
+    79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79, 79 };
+
+void amvo_q60_table(int chroma, uint8_t out[64]) { memcpy(out, chroma ? k_q60_chroma : k_q60_luma, 64); }
+
+#define SW1 22725 /* simple_idct.c:47-55 */
+#define SW2 21407
+#define SW3 19266
+#define SW4 16383
+#define SW5 12873
+#define SW6 8867
+#define SW7 4520
+#define SROW_SHIFT 11
+#define SCOL_SHIFT 20
+
+/* idctRowCondDC simple_idct.c:78-181 (results stored back into int16) */
+static void sidct_row(int16_t *row)
+{
+    int a0, a1, a2, a3, b0, b1, b2, b3;
+    if (!(row[1] | row[2] | row[3] | row[4] | row[5] | row[6] | row[7])) {   /* :107-117: NOT the general formula */
+        int16_t v = (int16_t)((row[0] << 3) & 0xffff);
+        for (int i = 0; i < 8; i++) row[i] = v;
+        return;
+    }
+    a0 = SW4 * row[0] + (1 << (SROW_SHIFT - 1));
+    a1 = a0; a2 = a0; a3 = a0;
+    a0 += SW2 * row[2]; a1 += SW6 * row[2]; a2 -= SW6 * row[2]; a3 -= SW2 * row[2];
+    b0 = SW1 * row[1] + SW3 * row[3];
+    b1 = SW3 * row[1] - SW7 * row[3];
+    b2 = SW5 * row[1] - SW1 * row[3];
+    b3 = SW7 * row[1] - SW5 * row[3];
+    /* :152-171, the guard only skips additions of zero */
+    a0 += SW4 * row[4] + SW6 * row[6];
+    a1 += -SW4 * row[4] - SW2 * row[6];
+    a2 += -SW4 * row[4] + SW2 * row[6];
+    a3 += SW4 * row[4] - SW6 * row[6];
+    b0 += SW5 * row[5] + SW7 * row[7];
+    b1 += -SW1 * row[5] - SW5 * row[7];
+    b2 += SW7 * row[5] + SW3 * row[7];
+    b3 += SW3 * row[5] - SW1 * row[7];
+    row[0] = (int16_t)((a0 + b0) >> SROW_SHIFT);
+    row[7] = (int16_t)((a0 - b0) >> SROW_SHIFT);
+    row[1] = (int16_t)((a1 + b1) >> SROW_SHIFT);
+    row[6] = (int16_t)((a1 - b1) >> SROW_SHIFT);
+    row[2] = (int16_t)((a2 + b2) >> SROW_SHIFT);
+    row[5] = (int16_t)((a2 - b2) >> SROW_SHIFT);
+    row[3] = (int16_t)((a3 + b3) >> SROW_SHIFT);
+    row[4] = (int16_t)((a3 - b3) >> SROW_SHIFT);
+}
+
+/* idctSparseCol / idctSparseColPut simple_idct.c:183-247,320-388: the eight sums before the clip */
+static void sidct_col(const int16_t *col, int out[8])
+{
+    int a0, a1, a2, a3, b0, b1, b2, b3;
+    a0 = SW4 * (col[8 * 0] + ((1 << (SCOL_SHIFT - 1)) / SW4));                /* :190 */
+    a1 = a0; a2 = a0; a3 = a0;
+    a0 += SW2 * col[8 * 2]; a1 += SW6 * col[8 * 2]; a2 -= SW6 * col[8 * 2]; a3 -= SW2 * col[8 * 2];
+    b0 = SW1 * col[8 * 1] + SW3 * col[8 * 3];
+    b1 = SW3 * col[8 * 1] - SW7 * col[8 * 3];
+    b2 = SW5 * col[8 * 1] - SW1 * col[8 * 3];
+    b3 = SW7 * col[8 * 1] - SW5 * col[8 * 3];
+    a0 += SW4 * col[8 * 4]; a1 -= SW4 * col[8 * 4]; a2 -= SW4 * col[8 * 4]; a3 += SW4 * col[8 * 4];
+    b0 += SW5 * col[8 * 5]; b1 -= SW1 * col[8 * 5]; b2 += SW7 * col[8 * 5]; b3 += SW3 * col[8 * 5];
+    a0 += SW6 * col[8 * 6]; a1 -= SW2 * col[8 * 6]; a2 += SW2 * col[8 * 6]; a3 -= SW6 * col[8 * 6];
+    b0 += SW7 * col[8 * 7]; b1 -= SW5 * col[8 * 7]; b2 += SW3 * col[8 * 7]; b3 -= SW1 * col[8 * 7];
+    out[0] = (a0 + b0) >> SCOL_SHIFT; out[1] = (a1 + b1) >> SCOL_SHIFT;
+    out[2] = (a2 + b2) >> SCOL_SHIFT; out[3] = (a3 + b3) >> SCOL_SHIFT;
+    out[4] = (a3 - b3) >> SCOL_SHIFT; out[5] = (a2 - b2) >> SCOL_SHIFT;
+    out[6] = (a1 - b1) >> SCOL_SHIFT; out[7] = (a0 - b0) >> SCOL_SHIFT;
+}
+
+/* simple_idct simple_idct.c:410-419: in place, no clip */
+void amvo_simple_idct(int16_t blk[64])
+{
+    int t[8];
+    for (int i = 0; i < 8; i++) sidct_row(blk + 8 * i);
+    for (int i = 0; i < 8; i++) {
+        sidct_col(blk + i, t);
+        for (int r = 0; r < 8; r++) blk[8 * r + i] = (int16_t)t[r];
+    }
+}
+
+/* simple_idct_put :390-398.  ff_cropTbl covers -1024..1279 (dsputil.h MAX_NEG_CROP); beyond it the reference
+ * reads out of bounds, defined here as saturation */
+void amvo_simple_idct_put(uint8_t *dest, int line_size, int16_t blk[64])
+{
+    int t[8];
+    for (int i = 0; i < 8; i++) sidct_row(blk + 8 * i);
+    for (int i = 0; i < 8; i++) {
+        sidct_col(blk + i, t);
+        for (int r = 0; r < 8; r++) dest[r * line_size + i] = (uint8_t)(t[r] < 0 ? 0 : (t[r] > 255 ? 255 : t[r]));
+    }
+}
+
+/* decode_block's dequantisation mjpegdec.c:388-390,417,424 from a block of quantised coefficients in scan
+ * order whose DC is already the running sum of the differences (amvo_decode_frame's coef_out): FFmpeg keeps
+ * last_dc = 1024 + q0 * (that sum), and every store goes through DCTELEM = int16 */
+void amvo_ffmpeg_dequant_block(const int16_t coef[64], int comp, int16_t out[64])
+{
+    const uint8_t *qt = comp == 0 ? k_q60_luma : k_q60_chroma;
+    for (int nat = 0; nat < 64; nat++) {
+        int scan = k_zigzag_std[nat];
+        int v = (int)coef[scan] * (int)qt[scan];
+        if (scan == 0) v += 1024;                                             /* :805 */
+        out[nat] = (int16_t)v;
+    }
+}
+
+uint32_t amvo_yuv420_frame_bytes(uint32_t w, uint32_t h) { return w * h + 2 * ((w + 1) / 2) * ((h + 1) / 2); }
+
+/* Decode one chunk the way FFmpeg's amv_decoder does.  out: Y plane w*h, then Cb, then Cr, each
+ * ((w+1)/2) x ((h+1)/2), rows tight (linesize = width), zero-filled first.  Plane row p of a component with
+ * vertical factor v (2 luma, 1 chroma) receives scan row v*(8*mcu_rows - ((h/2)&7)) - 1 - p (mjpegdec.c:672-677;
+ * rows the formula sends outside the plane fall into FFmpeg's edge area and are dropped here; columns beyond
+ * the plane width likewise).  Errors, statuses and nmcu_ok are defined as in amvo_decode_frame: MCUs before the
+ * first error are stored, the rest stays zero (FFmpeg logs the error and keeps whatever the buffer held). */
+int amvo_decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
+                             uint8_t *out, uint32_t *nmcu_ok, uint32_t *status)
+{
+    hufbounds hb[4];
+    bitrd b;
+    const uint32_t mcw = amvo_mcus_per_row(w), mch = amvo_mcu_rows(h);
+    const uint32_t cw = (w + 1) / 2, chh = (h + 1) / 2;
+    uint8_t *plane[3] = { out, out + (size_t)w * h, out + (size_t)w * h + (size_t)cw * chh };
+    const uint32_t pw[3] = { w, cw, cw }, ph[3] = { h, chh, chh };
+    int16_t pred[3] = { 0, 0, 0 };
+    uint32_t st = 0, mcu = 0;
+    static const int comp_of[6] = { 0, 0, 0, 0, 1, 2 };
+
+    for (int t = 0; t < 4; t++) build_bounds(&hb[t], k_bits[t]);
+    memset(out, 0, amvo_yuv420_frame_bytes(w, h));
+    memset(&b, 0, sizeof b);
+    b.buf = chunk; b.len = len; b.pos = 2;                                    /* sp5xdec.c:75-77 copies [2, n-2) */
+
+    for (uint32_t my = 0; my < mch && !st; my++) {
+        for (uint32_t mx = 0; mx < mcw; mx++) {
+            int16_t mcub[6][64];
+            for (int k = 0; k < 6 && !st; k++) {
+                int c = comp_of[k];
+                int r = huf_block(&b, hb, c ? 1 : 0, c ? 3 : 2, mcub[k]);
+                if (r) { st |= (uint32_t)r; break; }
+                mcub[k][0] = (int16_t)(mcub[k][0] + pred[c]);
+                pred[c] = mcub[k][0];
+            }
+            if (st) break;
+            for (int k = 0; k < 6; k++) {
+                int c = comp_of[k];
+                int v = c == 0 ? 2 : 1;
+                int16_t blk[64];
+                uint8_t px[64];
+                amvo_ffmpeg_dequant_block(mcub[k], c, blk);
+                amvo_simple_idct_put(px, 8, blk);
+                /* block origin in scan coordinates (mjpegdec.c:708-710) */
+                int32_t sy = (int32_t)((c == 0 ? 2 * my + (uint32_t)(k >> 1) : my) * 8);
+                uint32_t sx = (c == 0 ? 2 * mx + (uint32_t)(k & 1) : mx) * 8;
+                int32_t start = v * (int32_t)(8 * mch - ((h / 2) & 7)) - 1;   /* :675 */
+                for (int i = 0; i < 8; i++) {
+                    int32_t p = start - (sy + i);
+                    if (p < 0 || p >= (int32_t)ph[c]) continue;
+                    for (uint32_t j = 0; j < 8; j++)
+                        if (sx + j < pw[c]) plane[c][(size_t)p * pw[c] + sx + j] = px[8 * i + j];
+                }
+            }
+            mcu++;
+        }
+    }
+    if (b.consumed > b.valid) st |= AMVO_ST_TRUNCATED;
+    if (nmcu_ok) *nmcu_ok = mcu;
+    if (status) *status = st;
+    return st ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * IMA ADPCM
  * ---------------------------------------------------------------------------------- */
 static const int8_t k_index_table[16] = { -1, -1, -1, -1, 2, 4, 6, 8, -1, -1, -1, -1, 2, 4, 6, 8 }; /* AdpcmIma.c:20-23 */

@@ -70,6 +70,21 @@ void amvo_idct_block(int32_t blk[64]);
 /* StoreBuffer's per-pixel conversion (AmvJpeg.c:805-831); bgr[0..2] = B,G,R */
 void amvo_yuv_to_bgr(int32_t y, int32_t u, int32_t v, uint8_t bgr[3]);
 
+/* ---- FFmpeg-compat video decode (the patched FFmpeg's amv_decoder) ------ */
+/* sp5x "Q60" tables in zig-zag order (sp5x.h:187-194 = sp5x_quant_table[10], [11]; sp5xdec.c:40,60-61) */
+void amvo_q60_table(int chroma, uint8_t out[64]);
+/* simple_idct (simple_idct.c:410-419) in place on 64 int16; pinned against the reference's own object */
+void amvo_simple_idct(int16_t blk[64]);
+/* simple_idct_put (:390-398): rows in place, columns clipped to 0..255 into dest */
+void amvo_simple_idct_put(uint8_t *dest, int line_size, int16_t blk[64]);
+/* decode_block's dequantisation (mjpegdec.c:388-390,417,424; last_dc = 1024 :805) of a scan-order block whose
+ * DC is the running sum of differences; out in natural order, int16 like DCTELEM.  comp 0 = luma table */
+void amvo_ffmpeg_dequant_block(const int16_t coef[64], int comp, int16_t out[64]);
+uint32_t amvo_yuv420_frame_bytes(uint32_t w, uint32_t h);
+/* whole frame: YUVJ420P planes (Y, Cb, Cr; tight rows), flipped per mjpegdec.c:672-677 */
+int amvo_decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
+                             uint8_t *out, uint32_t *nmcu_ok, uint32_t *status);
+
 /* ---- IMA ADPCM (AMV layout) ------------------------------------------------------ */
 /* AmvAudioDecode header parse (AMVDec.c:312-320) + AdpcmImaDecodeFrame (AdpcmIma.c:206-242)
  * with AdpcmImaExpandNibble (:170-204).  Writes 2*(len-8) samples (the defined part,

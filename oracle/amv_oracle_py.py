@@ -51,6 +51,12 @@ def lib():
             "amvo_dequant_idct_block": (None, [_vp, _int, _u32, _vp]),
             "amvo_idct_block": (None, [_vp]),
             "amvo_yuv_to_bgr": (None, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]),
+            "amvo_q60_table": (None, [_int, _vp]),
+            "amvo_simple_idct": (None, [_vp]),
+            "amvo_simple_idct_put": (None, [_vp, _int, _vp]),
+            "amvo_ffmpeg_dequant_block": (None, [_vp, _int, _vp]),
+            "amvo_yuv420_frame_bytes": (_u32, [_u32, _u32]),
+            "amvo_decode_frame_ffmpeg": (_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
             "amvo_adpcm_decode_chunk": (_int, [_vp, _u32, _vp, _vp]),
             "amvo_adpcm_encode_chunk": (_int, [_vp, _u32, ctypes.POINTER(_int), _vp]),
             "amvo_adpcm_wav_encode_frame": (_int, [_vp, _int, _vp, _vp]),
@@ -158,6 +164,23 @@ def decode_frame(chunk, w, h, flags=0, want_coef=False):
     L.amvo_decode_frame(chunk, len(chunk), w, h, flags, out.ctypes.data, coef.ctypes.data if want_coef else None,
                         ctypes.byref(ok), ctypes.byref(st))
     return (out, st.value, ok.value, coef) if want_coef else (out, st.value, ok.value)
+
+
+def decode_frame_ffmpeg(chunk, w, h):
+    """FFmpeg-compat mode -> (yuvj420p bytes [w*h + 2*cw*ch] uint8, status, nmcu_ok)"""
+    L = lib()
+    chunk = bytes(chunk)
+    out = np.zeros(L.amvo_yuv420_frame_bytes(w, h), np.uint8)
+    ok, st = _u32(), _u32()
+    L.amvo_decode_frame_ffmpeg(chunk, len(chunk), w, h, out.ctypes.data, ctypes.byref(ok), ctypes.byref(st))
+    return out, st.value, ok.value
+
+
+def yuv_planes(buf, w, h):
+    """split a YUVJ420P frame buffer -> (Y [h, w], Cb [ch, cw], Cr [ch, cw])"""
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    return (buf[: w * h].reshape(h, w), buf[w * h: w * h + cw * ch].reshape(ch, cw),
+            buf[w * h + cw * ch: w * h + 2 * cw * ch].reshape(ch, cw))
 
 
 def encode_frame(pix, w, h, bgr=False, qbias=0, want_coef=False):

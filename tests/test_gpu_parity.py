@@ -703,3 +703,113 @@ def test_coresident_video_and_adpcm_streams(pkg, orc):
         assert (d_pcm2[: n * spf].cpu().numpy() == want_pcm).all()
     vctx.close()
     actx.close()
+
+
+# ---------------------------------------------------------------------------------- FFmpeg-compat mode
+
+def _gpu_decode_ffmpeg(ctx, pkg, chunks, w, h, pad_front=0):
+    import torch
+    blob, offs, lens, nbytes = _blob_of(chunks, pad_front)
+    n = len(chunks)
+    fb = ctx.yuv420_frame_bytes(w, h)
+    d_out = torch.full((n, fb), 0x5A, dtype=torch.uint8, device="cuda:0")
+    d_st = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+    ctx.decode_batch_dev(_t(blob), nbytes, _t(offs), _t(lens), n, w, h, pkg.FLAG_FFMPEG, d_out, d_st,
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy(), d_st.cpu().numpy()
+
+
+def _oracle_decode_ffmpeg(orc, chunks, w, h):
+    outs, sts = [], []
+    for c in chunks:
+        o, st, _ = orc.decode_frame_ffmpeg(c, w, h)
+        outs.append(o)
+        sts.append(st)
+    return np.stack(outs), np.array(sts, np.int32)
+
+
+def test_ffmpeg_compat_decode_amv1(ctx, pkg, orc, amv1):
+    """rows a14/a15: AMVHIP_FLAG_FFMPEG on all 252 chunks of the reference's fixture == the oracle's restatement
+    of the patched FFmpeg's amv_decoder (whose IDCT and tables are pinned by the reference's own objects)"""
+    got, st = _gpu_decode_ffmpeg(ctx, pkg, amv1["video"], 128, 96, pad_front=1)
+    want, want_st = _oracle_decode_ffmpeg(orc, amv1["video"], 128, 96)
+    assert (st == 0).all() and (want_st == 0).all()
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("w,h,n", [(160, 120, 40), (320, 240, 6), (176, 144, 3), (130, 98, 3), (16, 16, 2), (336, 32, 2),
+                                   (46, 30, 3), (33, 31, 3), (640, 480, 2)])
+def test_ffmpeg_compat_decode_matches_oracle(ctx, pkg, orc, w, h, n):
+    """synthetic clips incl. partial MCUs, heights the flip formula of mjpegdec.c:672-677 shifts (98) or leaves
+    partly unwritten (30, 31), odd sizes (chroma planes of (w+1)/2 x (h+1)/2), several segments per MCU row"""
+    ew, eh = w + (w & 1), h + (h & 1)           # the oracle's encoder wants even sizes; decode the same scan as w x h
+    chunks = [orc.encode_frame(orc.synth_frame(SEED, 3 + t, ew, eh), ew, eh) for t in range(n)]
+    rng = np.random.default_rng(w * h)
+    noise = rng.integers(0, 256, (eh, ew, 3), dtype=np.uint8)
+    chunks.append(orc.encode_frame(noise, ew, eh))
+    if (ew + 15) // 16 != (w + 15) // 16 or (eh + 15) // 16 != (h + 15) // 16:
+        pytest.skip("geometry changes the MCU grid")
+    got, st = _gpu_decode_ffmpeg(ctx, pkg, chunks, w, h)
+    want, want_st = _oracle_decode_ffmpeg(orc, chunks, w, h)
+    assert (st == want_st).all() and (want_st == 0).all()
+    assert (got == want).all()
+
+
+def test_ffmpeg_compat_errors_saturation_and_kernels(ctx, pkg, orc, amv1):
+    """damaged chunks (statuses and the zeroed remainder as in the amvlib mode), coefficients that wrap the int16
+    stores of the reference's DCTELEM blocks, both entropy kernels, the host-buffer entry point"""
+    import torch
+    w, h = 160, 120
+    good = [orc.encode_frame(orc.synth_frame(SEED, t, w, h), w, h) for t in range(6)]
+    rng = np.random.default_rng(11)
+    chunks = list(good)
+    for c in good[:4]:
+        b = bytearray(c)
+        for _ in range(3):
+            b[int(rng.integers(2, len(b) - 2))] ^= 1 << int(rng.integers(0, 8))
+        chunks.append(bytes(b))
+    chunks += [good[0][: len(good[0]) // 2], good[1][:40], b"\xff\xd8\xff\xd9", b"\xff\xd8" + b"\xff\x00" * 400 + b"\xff\xd9",
+               b"\xff\xd8" + bytes(rng.integers(0, 255, 3000, dtype=np.uint8)) + b"\xff\xd9"]
+    want, want_st = _oracle_decode_ffmpeg(orc, chunks, w, h)
+    assert (want_st != 0).sum() >= 4
+    for mode in (pkg.ENTROPY_AUTO, pkg.ENTROPY_SERIAL):
+        ctx.set_entropy_mode(mode)
+        try:
+            got, st = _gpu_decode_ffmpeg(ctx, pkg, chunks, w, h, pad_front=3)
+        finally:
+            ctx.set_entropy_mode(pkg.ENTROPY_AUTO)
+        assert (st == want_st).all()
+        assert (got == want).all()
+    # host buffers
+    blob, offs, lens, nbytes = _blob_of(chunks)
+    out = np.zeros((len(chunks), ctx.yuv420_frame_bytes(w, h)), np.uint8)
+    st = np.zeros(len(chunks), np.int32)
+    ctx.decode_batch(blob, nbytes, offs, lens, len(chunks), w, h, pkg.FLAG_FFMPEG, out, st)
+    assert (out == want).all() and (st == want_st).all()
+    # stage access with hand-made coefficients: extremes wrap exactly as the reference's int16 blocks do
+    nm = 80
+    coef = rng.integers(-2047, 2048, (3, nm * 6, 64)).astype(np.int16)
+    coef[1] = (coef[1] * (rng.random(coef[1].shape) < 0.05)).astype(np.int16)     # sparse: DC-only rows take the shortcut
+    coef[2, :, 1:] = 0                                                            # DC only
+    d_out = torch.zeros((3, ctx.yuv420_frame_bytes(w, h)), dtype=torch.uint8, device="cuda:0")
+    ctx.reconstruct_dev(_t(coef), _t(np.full(3, nm, np.uint32)), 3, w, h, pkg.FLAG_FFMPEG, d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    L = orc.lib()
+    for f in range(3):
+        Y, Cb, Cr = orc.yuv_planes(got[f], w, h)
+        for m in (0, 7, 33, 79):
+            my, mx = divmod(m, 10)
+            for k in range(6):
+                blk = np.zeros(64, np.int16)
+                px = np.zeros(64, np.uint8)
+                L.amvo_ffmpeg_dequant_block(coef[f, m * 6 + k].ctypes.data, 0 if k < 4 else k - 3, blk.ctypes.data)
+                L.amvo_simple_idct_put(px.ctypes.data, 8, blk.ctypes.data)
+                plane, v = (Y, 2) if k < 4 else ((Cb, 1) if k == 4 else (Cr, 1))
+                by, bx = (2 * my + (k >> 1), 2 * mx + (k & 1)) if k < 4 else (my, mx)
+                start = v * (8 * 8 - ((h // 2) & 7)) - 1
+                for i in range(8):
+                    p = start - (8 * by + i)
+                    if 0 <= p < plane.shape[0]:
+                        assert (plane[p, 8 * bx: 8 * bx + 8] == px[8 * i: 8 * i + 8]).all(), (f, m, k, i)

@@ -256,3 +256,89 @@ def test_huffman_tables_match_reference_build(orc):
         assert int((size > 0).sum()) == n and size.max() <= 16
         # Kraft sum of a complete-but-one prefix code (JPEG reserves the all-ones code)
         assert sum(2.0 ** -int(s) for s in size if s) == 1.0 - 2.0 ** -int(size.max())
+
+
+def test_simple_idct_matches_reference_build(orc):
+    """row a15: the oracle's simple_idct restatement against the reference's own simple_idct.c object --
+    random dense blocks, sparse blocks (the DC-only row shortcut of idctRowCondDC is NOT the general formula),
+    dequantised AMV coefficients, and full-range int16 values where the int16 stores between the passes wrap"""
+    R = _need_avcref(orc)
+    L = orc.lib()
+    rng = np.random.default_rng(3)
+    blocks = [rng.integers(-2048, 2048, 64), rng.integers(-32768, 32768, 64), np.zeros(64, np.int64)]
+    for mag in (8, 64, 512, 2048, 6000, 16384, 32767):              # dense: row results beyond int16 wrap in the stores
+        blocks += [rng.integers(-mag, mag + 1, 64) for _ in range(60)]
+    for _ in range(300):
+        b = np.zeros(64, np.int64)
+        k = int(rng.integers(1, 12))
+        b[rng.integers(0, 64, k)] = rng.integers(-1500, 1500, k)
+        blocks.append(b)
+    for dc in (-32768, -4096, -1, 0, 1, 1023, 1024, 2047, 2048, 4095, 32767):      # DC only: every row takes the shortcut
+        b = np.zeros(64, np.int64)
+        b[0] = dc
+        blocks.append(b)
+        b = b.copy()
+        b[8] = 7                                                                   # row 1 has only its first value
+        blocks.append(b)
+    for _ in range(200):
+        blocks.append(rng.integers(-300, 300, 64) * (rng.random(64) < 0.3))
+    arr = np.array(blocks, np.int16)
+    want = arr.copy()
+    R.amvref_simple_idct(want.ctypes.data, len(want))
+    got = arr.copy()
+    for i in range(len(got)):
+        L.amvo_simple_idct(got[i].ctypes.data)
+    assert (got == want).all()
+    # the put form = the same sums clipped to 0..255
+    for i in range(0, len(arr), 7):
+        blk = arr[i].copy()
+        px = np.zeros(64, np.uint8)
+        L.amvo_simple_idct_put(px.ctypes.data, 8, blk.ctypes.data)
+        assert (px == np.clip(want[i], 0, 255)).all()
+
+
+def test_q60_tables_match_reference_header(orc):
+    """the quantiser tables sp5xdec.c:60-61 puts in front of an AMV scan (sp5x_quant_table[10], [11])"""
+    R = _need_avcref(orc)
+    for chroma in (0, 1):
+        a, b = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+        orc.lib().amvo_q60_table(chroma, a.ctypes.data)
+        R.amvref_sp5x_quant(chroma, b.ctypes.data)
+        assert (a == b).all()
+    # the wrapper's frame header says 4:2:0 with component ids 1,2,3, DC/AC tables 0 for Y and 1 for C (sp5x.h:27-51)
+    seg = np.zeros(64, np.uint8)
+    n = R.amvref_sp5x_segment(1, seg.ctypes.data, 64)
+    assert bytes(seg[:n])[:5] == b"\xff\xc0\x00\x11\x08" and bytes(seg[9:n]) == bytes([3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1])
+    n = R.amvref_sp5x_segment(2, seg.ctypes.data, 64)
+    assert bytes(seg[:n]) == bytes([0xff, 0xda, 0, 12, 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0])
+
+
+def test_ffmpeg_compat_decode_properties(orc, amv1):
+    """whole-frame FFmpeg-compat decode (not buildable from the reference here: mjpegdec.c needs configure's
+    ENABLE_* switches), checked through its parts and its geometry: every block of a frame equals
+    reference simple_idct (clipped) of the dequantised coefficients, placed where mjpegdec.c:672-677 puts it."""
+    R = _need_avcref(orc)
+    L = orc.lib()
+    for chunk, w, h in [(amv1["video"][0], 128, 96), (amv1["video"][200], 128, 96),
+                        (orc.encode_frame(orc.synth_frame(SEED, 9, 160, 120), 160, 120), 160, 120),
+                        (orc.encode_frame(orc.synth_frame(SEED, 4, 130, 98), 130, 98), 130, 98)]:
+        buf, st, ok = orc.decode_frame_ffmpeg(chunk, w, h)
+        _, st2, ok2, coef = orc.decode_frame(chunk, w, h, want_coef=True)
+        assert st == st2 == 0 and ok == ok2
+        Y, Cb, Cr = orc.yuv_planes(buf, w, h)
+        mcw, mch = (w + 15) // 16, (h + 15) // 16
+        for plane, v, comp in ((Y, 2, 0), (Cb, 1, 1), (Cr, 1, 2)):
+            full = np.zeros((8 * mch * v, 8 * mcw * v), np.uint8)               # the padded, unflipped component
+            for m in range(mcw * mch):
+                my, mx = divmod(m, mcw)
+                for k in ((0, 1, 2, 3) if comp == 0 else (3 + comp,)):
+                    blk = np.zeros(64, np.int16)
+                    L.amvo_ffmpeg_dequant_block(coef[m * 6 + k].ctypes.data, comp, blk.ctypes.data)
+                    R.amvref_simple_idct(blk.ctypes.data, 1)
+                    by, bx = (2 * my + (k >> 1), 2 * mx + (k & 1)) if comp == 0 else (my, mx)
+                    full[8 * by: 8 * by + 8, 8 * bx: 8 * bx + 8] = np.clip(blk, 0, 255).reshape(8, 8)
+            start = v * (8 * mch - ((h // 2) & 7)) - 1
+            for p in range(plane.shape[0]):
+                r = start - p
+                want = full[r, : plane.shape[1]] if 0 <= r < full.shape[0] else np.zeros(plane.shape[1], np.uint8)
+                assert (plane[p] == want).all(), (w, h, comp, p)
