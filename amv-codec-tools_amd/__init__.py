@@ -96,11 +96,16 @@ SYMBOLS = {
     "amvhip_reconstruct_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_encode_batch_dev": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "amvhip_encode_batch": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp]),
+    "amvhip_encode_yuv420_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
+    "amvhip_encode_yuv420_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp]),
     "amvhip_encode_coefs_dev": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_adpcm_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "amvhip_adpcm_encode_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "amvhip_adpcm_decode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _u64, _vp, _vp]),
     "amvhip_adpcm_encode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),
+    "amvhip_adpcm_encode_frame": (_int, [_vp, _vp, _u32, ctypes.POINTER(_i32), _vp, _u32]),
+    "amvhip_amv_audio_pairs": (_u32, [_u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),
+    "amvhip_amv_audio_frame_size": (_u32, [_u32, _u32, _u32]),
     "amvhip_adpcm_wav_encode_frame": (_int, [_vp, _vp, _int, _vp, _vp, _int]),
     "amvhip_synth_frames_dev": (_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_synth_audio_dev": (_int, [_vp, _u32, _u64, _u64, _vp, _vp]),
@@ -148,7 +153,9 @@ class AmvHipError(RuntimeError):
 
 
 def _ptr(x):
-    """device/host address of a torch tensor, numpy array, bytes-like or int; None -> NULL"""
+    """device/host address of a torch tensor, numpy array, bytes object or int; None -> NULL.  The caller keeps x alive
+    for the duration of the call; other buffer types (bytearray, memoryview ...) are refused: wrap them in numpy
+    (np.frombuffer) so that the address is that of the caller's own memory, never of a temporary copy."""
     if x is None:
         return None
     if isinstance(x, int):
@@ -157,7 +164,9 @@ def _ptr(x):
         return x.data_ptr()
     if hasattr(x, "ctypes"):
         return x.ctypes.data
-    return ctypes.cast(ctypes.c_char_p(bytes(x)), ctypes.c_void_p).value
+    if isinstance(x, bytes):      # immutable, owned by the caller: input arguments only
+        return ctypes.cast(ctypes.c_char_p(x), ctypes.c_void_p).value
+    raise TypeError("pass a torch tensor, numpy array, bytes or int address, not %s" % type(x).__name__)
 
 
 class Context:
@@ -215,6 +224,17 @@ class Context:
         return self._check(self.lib.amvhip_encode_batch_dev(self.h, _ptr(pix), pix_stride, is_bgr, n, w, h, qbias,
                                                             _ptr(blob), blob_cap, _ptr(offs), _ptr(lens), stream),
                            "encode_batch_dev")
+
+    def encode_yuv420_batch_dev(self, y, cb, cr, y_stride, c_stride, y_frame, c_frame, n, w, h, qbias, blob, blob_cap, offs,
+                                lens, stream=None):
+        return self._check(self.lib.amvhip_encode_yuv420_batch_dev(self.h, _ptr(y), _ptr(cb), _ptr(cr), y_stride, c_stride,
+                                                                   y_frame, c_frame, n, w, h, qbias, _ptr(blob), blob_cap,
+                                                                   _ptr(offs), _ptr(lens), stream), "encode_yuv420_batch_dev")
+
+    def encode_yuv420_batch(self, y, cb, cr, y_stride, c_stride, y_frame, c_frame, n, w, h, qbias, blob, blob_cap, offs, lens):
+        return self._check(self.lib.amvhip_encode_yuv420_batch(self.h, _ptr(y), _ptr(cb), _ptr(cr), y_stride, c_stride,
+                                                               y_frame, c_frame, n, w, h, qbias, _ptr(blob), blob_cap,
+                                                               _ptr(offs), _ptr(lens)), "encode_yuv420_batch")
 
     def encode_coefs_dev(self, pix, pix_stride, is_bgr, n, w, h, qbias, coef, stream=None):
         return self._check(self.lib.amvhip_encode_coefs_dev(self.h, _ptr(pix), pix_stride, is_bgr, n, w, h, qbias,

@@ -1,4 +1,7 @@
-"""Build libamvhip.so (HIP kernels + C ABI + amvlib call surface) in-tree for gfx950.
+"""Build libamvhip.so (HIP kernels + C ABI + amvlib call surface) in-tree for gfx950, and -- where the reference
+tree is present -- libamvhip_lavc.so, the FFmpeg `AVCodec` plugin surface (host/amvhip_lavc.c), which is compiled
+against the reference's own libavcodec/avcodec.h where it lies (the binding a maintainer adds to the patched FFmpeg;
+on the GPU box, which has no /root/reference, the prebuilt library that travelled with the snapshot is used).
 
     python amv-codec-tools_amd/build.py [--force]
 
@@ -14,6 +17,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 OUT = os.path.join(HERE, "libamvhip.so")
+LAVC_OUT = os.path.join(HERE, "libamvhip_lavc.so")
+LAVC_HOST = os.path.join(ROOT, "tests", "c", "_bin", "lavc_host")     # the C program of tests/c/lavc_host.c
+REF_FFMPEG = "/root/reference/AMVmuxer/ffmpeg"
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
@@ -71,7 +77,26 @@ def build(force=False, verbose=False):
                     sys.stderr.write(warn)
     if jobs or force or _stale(OUT, objs):
         _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs + ["-lpthread"])
+    build_lavc(force)
     return OUT
+
+
+def build_lavc(force=False):
+    """the AVCodec plugin + the C host that drives it, against the reference's avcodec.h (only where it exists)"""
+    if not os.path.isdir(REF_FFMPEG):
+        return None
+    inc = ["-I" + os.path.join(REF_FFMPEG, "libavcodec"), "-I" + os.path.join(REF_FFMPEG, "libavutil")]
+    src = os.path.join(HERE, "host", "amvhip_lavc.c")
+    hdr = os.path.join(ROOT, "include", "amvhip.h")
+    if force or _stale(LAVC_OUT, [src, hdr, OUT, os.path.abspath(__file__)]):
+        _run(["gcc", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-std=gnu11", "-shared"] + inc +
+             [src, "-o", LAVC_OUT, "-L" + HERE, "-l:libamvhip.so", "-Wl,-rpath,$ORIGIN", "-Wl,-z,defs"])
+    host_src = os.path.join(ROOT, "tests", "c", "lavc_host.c")
+    if force or _stale(LAVC_HOST, [host_src, hdr, LAVC_OUT]):
+        os.makedirs(os.path.dirname(LAVC_HOST), exist_ok=True)
+        _run(["gcc", "-O2", "-Wall", "-std=gnu11"] + inc + ["-I" + os.path.join(ROOT, "include"), host_src, "-o", LAVC_HOST,
+              "-L" + HERE, "-l:libamvhip_lavc.so", "-l:libamvhip.so", "-Wl,-rpath,$ORIGIN/../../../amv-codec-tools_amd"])
+    return LAVC_OUT
 
 
 if __name__ == "__main__":

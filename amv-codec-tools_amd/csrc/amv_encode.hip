@@ -99,8 +99,12 @@ __device__ __forceinline__ void unpack12(const Px12& v, int (&b)[12]) {
 //     (mjpegenc.c:462-467); rows and columns outside the picture repeat the nearest edge sample.
 //  2. one lane per 8x8 block, the block in registers: 8 row passes, DCTELEM truncation, 8 column
 //     passes, dct_quantize_c, scan order (a compile-time permutation), one 128-byte line out.
+// kYuv: the source is planar YUVJ420P, what amv_encoder itself takes (mjpegenc.c:493) -- stage 1 only copies
+// samples (level shift 128) instead of converting; everything else, edge repetition included, is the same, so
+// that rgb24_to_yuvj420p followed by this form equals the RGB form bit for bit.
+template <bool kYuv>
 __global__ __launch_bounds__(kWave) void amv_forward_kernel(
-    const uint8_t* __restrict__ pix, uint32_t pix_stride, int is_bgr, uint32_t n, FrameGeom g,
+    const uint8_t* __restrict__ pix, uint32_t pix_stride, int is_bgr, YuvSource yuv, uint32_t n, FrameGeom g,
     uint32_t nseg, uint32_t per_seg, uint32_t qbias, int16_t* __restrict__ coef) {
     __shared__ __attribute__((aligned(16))) int16_t s_y[16 * kPitchY];
     __shared__ __attribute__((aligned(16))) int16_t s_cb[8 * kPitchC];
@@ -130,7 +134,23 @@ __global__ __launch_bounds__(kWave) void amv_forward_kernel(
         const uint8_t* pa = src + (uint64_t)row_a * pix_stride;
         const uint8_t* pb = src + (uint64_t)row_b * pix_stride;
         int ya[4], yb[4], u[2], v[2];
-        if (c + 3u < w) {
+        if (kYuv) {
+            const uint8_t* ya_p = yuv.y + (uint64_t)f * yuv.y_frame + (uint64_t)row_a * yuv.y_stride;
+            const uint8_t* yb_p = yuv.y + (uint64_t)f * yuv.y_frame + (uint64_t)row_b * yuv.y_stride;
+            const uint64_t co = (uint64_t)f * yuv.c_frame + (uint64_t)(row_b >> 1) * yuv.c_stride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = min(c + (uint32_t)q, w - 1u);
+                ya[q] = (int)ya_p[x] - 128;
+                yb[q] = (int)yb_p[x] - 128;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t x = min((c >> 1) + (uint32_t)e, cw - 1u);
+                u[e] = (int)yuv.cb[co + x] - 128;
+                v[e] = (int)yuv.cr[co + x] - 128;
+            }
+        } else if (c + 3u < w) {
             int a[12], b[12];
             unpack12(*reinterpret_cast<const Px12*>(pa + c * 3u), a);
             unpack12(*reinterpret_cast<const Px12*>(pb + c * 3u), b);
@@ -237,8 +257,17 @@ void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
     const uint32_t per_seg = (g.mcu_cols + nseg - 1) / nseg;      // balanced: 11 columns -> 6 + 5
     const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
-    hipLaunchKernelGGL(amv_forward_kernel, dim3((uint32_t)grid), dim3(kWave), 0, s, pix, pix_stride,
-                       is_bgr, n, g, nseg, per_seg, qbias, coef);
+    hipLaunchKernelGGL(amv_forward_kernel<false>, dim3((uint32_t)grid), dim3(kWave), 0, s, pix, pix_stride,
+                       is_bgr, YuvSource{}, n, g, nseg, per_seg, qbias, coef);
+}
+
+void launch_forward_yuv(const YuvSource& src, uint32_t n, const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
+    const uint32_t per_seg = (g.mcu_cols + nseg - 1) / nseg;
+    const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
+    hipLaunchKernelGGL(amv_forward_kernel<true>, dim3((uint32_t)grid), dim3(kWave), 0, s, (const uint8_t*)nullptr, 0u,
+                       0, src, n, g, nseg, per_seg, qbias, coef);
 }
 
 // ============================================================================================
@@ -391,18 +420,21 @@ __global__ __launch_bounds__(1024) void amv_scan_kernel(const uint32_t* __restri
 }
 
 __global__ __launch_bounds__(256) void amv_gather_kernel(const uint8_t* __restrict__ tmp, uint32_t bound,
-                                                         const uint32_t* __restrict__ lens,
+                                                         uint32_t* __restrict__ lens,
                                                          const uint64_t* __restrict__ offs,
                                                          uint8_t* __restrict__ blob, uint64_t cap) {
     const uint32_t i = blockIdx.x;
     const uint32_t len = lens[i];
     const uint64_t off = offs[i];
-    if (off + len > cap) return;
+    if (off + len > cap) {   // does not fit the caller's blob: not written, and its length says so
+        if (threadIdx.x == 0) lens[i] = 0;
+        return;
+    }
     const uint8_t* src = tmp + (uint64_t)i * bound;
     for (uint32_t k = threadIdx.x; k < len; k += 256) blob[off + k] = src[k];
 }
 
-void launch_compact(const uint8_t* tmp, uint32_t bound, const uint32_t* lens, uint32_t n,
+void launch_compact(const uint8_t* tmp, uint32_t bound, uint32_t* lens, uint32_t n,
                     uint64_t* offs, uint8_t* blob, uint64_t blob_cap, int32_t* overflow, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(amv_scan_kernel, dim3(1), dim3(1024), 0, s, lens, n, offs, blob_cap, overflow);

@@ -61,6 +61,16 @@ bool yuv_store_covers_planes(const FrameGeom& g);
 // colour conversion + level shift + forward DCT + quantise: coef [n][blocks][64] int16 scan order
 void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n,
                     const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s);
+// the same from planar YUVJ420P (what the reference's amv_encoder takes, mjpegenc.c:493): frame i's planes at
+// y + i*y_frame, cb/cr + i*c_frame (bytes); rows y_stride / c_stride apart
+struct YuvSource {
+    const uint8_t* y;
+    const uint8_t* cb;
+    const uint8_t* cr;
+    uint32_t y_stride, c_stride;
+    uint64_t y_frame, c_frame;
+};
+void launch_forward_yuv(const YuvSource& src, uint32_t n, const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s);
 // entropy coder: one lane per frame, writes FFD8 + escaped scan + FFD9 into tmp[i*bound..]
 void launch_pack(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img,
                  uint8_t* tmp, uint32_t bound, uint32_t* lens, const uint32_t* list, const uint32_t* list_count,
@@ -69,8 +79,9 @@ void launch_pack(const int16_t* coef, uint32_t n, const FrameGeom& g, const Huff
 // window are appended to retry_list for launch_pack(list).  false: geometry too large, use launch_pack.
 bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img, uint8_t* tmp,
                       uint32_t bound, uint32_t* lens, uint32_t* retry_list, uint32_t* retry_count, hipStream_t s);
-// exclusive scan of lens -> offs (single workgroup), then gather tmp -> blob
-void launch_compact(const uint8_t* tmp, uint32_t bound, const uint32_t* lens, uint32_t n,
+// exclusive scan of lens -> offs (single workgroup), then gather tmp -> blob.  A chunk that would end past
+// blob_cap is not copied and its lens entry becomes 0; *overflow = 1 when the total exceeds blob_cap.
+void launch_compact(const uint8_t* tmp, uint32_t bound, uint32_t* lens, uint32_t n,
                     uint64_t* offs, uint8_t* blob, uint64_t blob_cap, int32_t* overflow, hipStream_t s);
 
 // ---- ADPCM --------------------------------------------------------------------------------

@@ -425,6 +425,32 @@ extern "C" int amvhip_encode_coefs_dev(amvhip_ctx* c, const uint8_t* d_pix, uint
     return check_launch(c, "forward");
 }
 
+// entropy coding + compaction of the n frames whose coefficient lines are in c->coef (the context is locked)
+static int encode_tail(amvhip_ctx* c, uint32_t n, const FrameGeom& g, uint32_t bound, uint8_t* d_blob, uint64_t blob_cap,
+                       uint64_t* d_offs, uint32_t* d_lens, hipStream_t stream) {
+    if (int r = ensure(c, c->retry, ((size_t)n + 4) * 8)) return r;
+    uint32_t* retry_count = (uint32_t*)c->retry.p;
+    uint32_t* retry_list = retry_count + 8;
+    HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, stream));
+    bool par = false;
+    if (c->entropy_mode != AMVHIP_ENTROPY_SERIAL) {
+        Timed t(c, AMVHIP_K_PACK, stream);
+        par = launch_pack_wave((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens, retry_list,
+                               retry_count, stream);
+    }
+    {   // the one-lane-per-frame coder: everything, or the frames handed back (usually none)
+        Timed t(c, AMVHIP_K_PACK_SERIAL, stream);
+        launch_pack((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens,
+                    par ? retry_list : nullptr, par ? retry_count : nullptr, stream);
+    }
+    if (int r = check_launch(c, "pack")) return r;
+    {
+        Timed t(c, AMVHIP_K_COMPACT, stream);
+        launch_compact((const uint8_t*)c->tmp.p, bound, d_lens, n, d_offs, d_blob, blob_cap, (int32_t*)c->flag.p, stream);
+    }
+    return check_launch(c, "compact");
+}
+
 extern "C" int amvhip_encode_batch_dev(amvhip_ctx* c, const uint8_t* d_pix, uint32_t pix_stride, int is_bgr,
                                        uint32_t n, uint32_t w, uint32_t h, uint32_t qbias, uint8_t* d_blob,
                                        uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens, void* stream) {
@@ -439,28 +465,47 @@ extern "C" int amvhip_encode_batch_dev(amvhip_ctx* c, const uint8_t* d_pix, uint
     if (int r = ensure(c, c->tmp, (size_t)n * bound)) return r;
     if (int r = ensure(c, c->flag, 16)) return r;
     if (int r = amvhip_encode_coefs_dev(c, d_pix, pix_stride, is_bgr, n, w, h, qbias, (int16_t*)c->coef.p, stream)) return r;
-    if (int r = ensure(c, c->retry, ((size_t)n + 4) * 8)) return r;
-    uint32_t* retry_count = (uint32_t*)c->retry.p;
-    uint32_t* retry_list = retry_count + 8;
-    HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, (hipStream_t)stream));
-    bool par = false;
-    if (c->entropy_mode != AMVHIP_ENTROPY_SERIAL) {
-        Timed t(c, AMVHIP_K_PACK, (hipStream_t)stream);
-        par = launch_pack_wave((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens, retry_list,
-                               retry_count, (hipStream_t)stream);
-    }
-    {   // the one-lane-per-frame coder: everything, or the frames handed back (usually none)
-        Timed t(c, AMVHIP_K_PACK_SERIAL, (hipStream_t)stream);
-        launch_pack((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens,
-                    par ? retry_list : nullptr, par ? retry_count : nullptr, (hipStream_t)stream);
-    }
-    if (int r = check_launch(c, "pack")) return r;
+    return encode_tail(c, n, g, bound, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
+}
+
+extern "C" int amvhip_encode_yuv420_batch_dev(amvhip_ctx* c, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
+                                              uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                              uint64_t c_frame_stride, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
+                                              uint8_t* d_blob, uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens,
+                                              void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (w & 1) || (h & 1) || y_stride < w || c_stride < w / 2 || qbias > 255 ||
+        (n && (!d_y || !d_cb || !d_cr || !d_blob || !d_offs || !d_lens)))
+        return fail(c, AMVHIP_ERR_ARG, "encode_yuv420: bad argument (width/height must be even)");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    const FrameGeom g = make_geom(w, h);
+    const uint32_t bound = amvhip_encode_bound(w, h);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int r = ensure(c, c->coef, (size_t)n * g.blocks * 128)) return r;
+    if (int r = ensure(c, c->tmp, (size_t)n * bound)) return r;
+    if (int r = ensure(c, c->flag, 16)) return r;
     {
-        Timed t(c, AMVHIP_K_COMPACT, (hipStream_t)stream);
-        launch_compact((const uint8_t*)c->tmp.p, bound, d_lens, n, d_offs, d_blob, blob_cap, (int32_t*)c->flag.p,
-                       (hipStream_t)stream);
+        Timed t(c, AMVHIP_K_FDCT, (hipStream_t)stream);
+        launch_forward_yuv(YuvSource{d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride}, n, g, qbias,
+                           (int16_t*)c->coef.p, (hipStream_t)stream);
     }
-    return check_launch(c, "compact");
+    if (int r = check_launch(c, "forward_yuv")) return r;
+    return encode_tail(c, n, g, bound, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
+}
+
+// the device-to-host half of the host-buffer encoders: offs/lens, then the chunks
+static int encode_fetch(amvhip_ctx* c, uint32_t n, uint8_t* blob, uint64_t blob_cap, uint64_t* offs, uint32_t* lens) {
+    int32_t overflow = 0;
+    HIP_TRY(c, hipMemcpyAsync(offs, c->h_offs.p, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipMemcpyAsync(lens, c->h_lens.p, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipMemcpyAsync(&overflow, c->flag.p, 4, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipStreamSynchronize(0));
+    const uint64_t total = offs[n - 1] + lens[n - 1];
+    if (overflow || total > blob_cap)
+        return fail(c, AMVHIP_ERR_SPACE, "encode: the chunks need more than the %llu bytes of blob", (unsigned long long)blob_cap);
+    HIP_TRY(c, hipMemcpy(blob, c->h_out.p, total, hipMemcpyDeviceToHost));
+    return AMVHIP_OK;
 }
 
 extern "C" int amvhip_encode_batch(amvhip_ctx* c, const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n,
@@ -471,23 +516,45 @@ extern "C" int amvhip_encode_batch(amvhip_ctx* c, const uint8_t* pix, uint32_t p
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
     const size_t in_bytes = (size_t)pix_stride * h * n;
-    const uint64_t dev_cap = (uint64_t)amvhip_encode_bound(w, h) * n;
     if (int r = ensure(c, c->h_in, in_bytes)) return r;
-    if (int r = ensure(c, c->h_out, dev_cap)) return r;
+    if (int r = ensure(c, c->h_out, blob_cap + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
     HIP_TRY(c, hipMemcpyAsync(c->h_in.p, pix, in_bytes, hipMemcpyHostToDevice, 0));
     if (int r = amvhip_encode_batch_dev(c, (const uint8_t*)c->h_in.p, pix_stride, is_bgr, n, w, h, qbias,
-                                        (uint8_t*)c->h_out.p, dev_cap, (uint64_t*)c->h_offs.p,
+                                        (uint8_t*)c->h_out.p, blob_cap, (uint64_t*)c->h_offs.p,
                                         (uint32_t*)c->h_lens.p, nullptr))
         return r;
-    HIP_TRY(c, hipMemcpyAsync(offs, c->h_offs.p, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipMemcpyAsync(lens, c->h_lens.p, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipStreamSynchronize(0));
-    const uint64_t total = offs[n - 1] + lens[n - 1];
-    if (total > blob_cap) return fail(c, AMVHIP_ERR_SPACE, "encode: need %llu bytes, have %llu", (unsigned long long)total, (unsigned long long)blob_cap);
-    HIP_TRY(c, hipMemcpy(blob, c->h_out.p, total, hipMemcpyDeviceToHost));
-    return AMVHIP_OK;
+    return encode_fetch(c, n, blob, blob_cap, offs, lens);
+}
+
+extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
+                                          uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                          uint64_t c_frame_stride, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
+                                          uint8_t* blob, uint64_t blob_cap, uint64_t* offs, uint32_t* lens) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (w & 1) || (h & 1) || y_stride < w || c_stride < w / 2 || (n && (!y || !cb || !cr || !blob || !offs || !lens)))
+        return fail(c, AMVHIP_ERR_ARG, "encode_yuv420: bad argument");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    // staged tight: Y w*h, Cb, Cr (w/2 x h/2) per frame
+    const uint32_t cw = w / 2, chh = h / 2;
+    const uint64_t fb = (uint64_t)w * h + 2ull * cw * chh;
+    if (int r = ensure(c, c->h_in, fb * n)) return r;
+    if (int r = ensure(c, c->h_out, blob_cap + 16)) return r;
+    if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
+    if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
+    uint8_t* d = (uint8_t*)c->h_in.p;
+    for (uint32_t i = 0; i < n; ++i) {
+        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb, w, y + i * y_frame_stride, y_stride, w, h, hipMemcpyHostToDevice, 0));
+        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb + (uint64_t)w * h, cw, cb + i * c_frame_stride, c_stride, cw, chh, hipMemcpyHostToDevice, 0));
+        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb + (uint64_t)w * h + (uint64_t)cw * chh, cw, cr + i * c_frame_stride, c_stride, cw, chh, hipMemcpyHostToDevice, 0));
+    }
+    if (int r = amvhip_encode_yuv420_batch_dev(c, d, d + (uint64_t)w * h, d + (uint64_t)w * h + (uint64_t)cw * chh, w, cw, fb, fb, n, w, h,
+                                               qbias, (uint8_t*)c->h_out.p, blob_cap, (uint64_t*)c->h_offs.p,
+                                               (uint32_t*)c->h_lens.p, nullptr))
+        return r;
+    return encode_fetch(c, n, blob, blob_cap, offs, lens);
 }
 
 // =============================================================================================
@@ -590,6 +657,64 @@ extern "C" int amvhip_adpcm_encode_batch(amvhip_ctx* c, const int16_t* pcm, uint
     HIP_TRY(c, hipMemcpyAsync(blob, c->h_out.p, blob_bytes, hipMemcpyDeviceToHost, 0));
     HIP_TRY(c, hipStreamSynchronize(0));
     return AMVHIP_OK;
+}
+
+// One AMV audio chunk with the step index handed in and out: what adpcm_encode_frame (adpcm.c:461-498) does per
+// call with the index it keeps in its context.  The end index is read off a decode of the fresh chunk (the decoder
+// walks the same index chain), one synchronisation for both kernels.
+extern "C" int amvhip_adpcm_encode_frame(amvhip_ctx* c, const int16_t* samples, uint32_t nsamp, int32_t* step_index,
+                                         uint8_t* chunk, uint32_t cap) {
+    if (!c) return AMVHIP_ERR_ARG;
+    const uint32_t len = 8u + (nsamp >> 1);
+    if (!samples || !step_index || !chunk || (nsamp & 1u) || nsamp == 0 || *step_index < 0 || *step_index > 88)
+        return fail(c, AMVHIP_ERR_ARG, "adpcm_encode_frame: bad argument (even, non-zero sample count; index 0..88)");
+    if (cap < len) return fail(c, AMVHIP_ERR_SPACE, "adpcm_encode_frame: chunk needs %u bytes", len);
+    if (int r = use_device(c)) return r;
+    // staging: [pcm | chunk | scratch pcm] + small tables {pcm_off, chunk_off, nsamp, len, step, final[2]}
+    if (int r = ensure(c, c->h_in, (size_t)nsamp * 2 + 16)) return r;
+    if (int r = ensure(c, c->h_out, (size_t)len + 16 + (size_t)nsamp * 2 + 16)) return r;
+    if (int r = ensure(c, c->h_aux, 64)) return r;
+    struct { uint64_t pcm_off, chunk_off; uint32_t nsamp, len; int32_t step; int32_t final_state[2]; } tab = {0, 0, nsamp, len, *step_index, {0, 0}};
+    uint8_t* aux = (uint8_t*)c->h_aux.p;
+    uint8_t* d_chunk = (uint8_t*)c->h_out.p;
+    int16_t* d_scratch = (int16_t*)(d_chunk + ((len + 15u) & ~15u));
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, samples, (size_t)nsamp * 2, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(aux, &tab, sizeof tab, hipMemcpyHostToDevice, 0));
+    if (int r = amvhip_adpcm_encode_batch_dev(c, (const int16_t*)c->h_in.p, (const uint64_t*)aux, (const uint32_t*)(aux + 16), 1,
+                                              (const int32_t*)(aux + 24), d_chunk, (const uint64_t*)(aux + 8), nullptr))
+        return r;
+    if (int r = amvhip_adpcm_decode_batch_dev(c, d_chunk, len, (const uint64_t*)(aux + 8), (const uint32_t*)(aux + 20), 1, d_scratch,
+                                              (const uint64_t*)aux, (int32_t*)(aux + 28), nullptr))
+        return r;
+    int32_t fin[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(chunk, d_chunk, len, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipMemcpyAsync(fin, aux + 28, 8, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(c, hipStreamSynchronize(0));
+    *step_index = fin[1];
+    return (int)len;
+}
+
+// AMV audio framing of the reference's encoder (adpcm.c:469-477): sample PAIRS of the next chunk for a nominal
+// frame_size -- an odd frame_size puts its extra sample into every second chunk, and a chunk that would straddle a
+// whole second of audio is stretched to end on it.  extra / samples_written are the caller's stream state.
+extern "C" uint32_t amvhip_amv_audio_pairs(uint32_t frame_size, uint32_t sample_rate, uint32_t* extra, uint64_t* samples_written) {
+    uint32_t n = frame_size >> 1;                           // :469
+    *extra += frame_size & 1u;                              // :470
+    n += *extra >> 1;                                       // :471
+    *extra &= 1u;                                           // :472
+    if (sample_rate) {
+        const uint32_t i = (uint32_t)((*samples_written + 2ull * n) % sample_rate);   // :474
+        if (i && i + frame_size > sample_rate) n += (sample_rate - i) >> 1;           // :476-477
+    }
+    *samples_written += 2ull * n;                           // :497
+    return n;
+}
+
+// frame_size the AMV muxer imposes on the audio encoder: sample_rate * time_base (amvenc.c:276-281, av_rescale
+// rounds to nearest)
+extern "C" uint32_t amvhip_amv_audio_frame_size(uint32_t sample_rate, uint32_t tb_num, uint32_t tb_den) {
+    if (!tb_den) return 0;
+    return (uint32_t)(((uint64_t)sample_rate * tb_num + tb_den / 2) / tb_den);
 }
 
 extern "C" int amvhip_adpcm_wav_encode_frame(amvhip_ctx* c, const int16_t* samples, int frame_size,

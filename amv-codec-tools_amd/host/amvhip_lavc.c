@@ -1,0 +1,321 @@
+/*
+ * amvhip_lavc.c -- the FFmpeg `AVCodec` plugin surface of the patched FFmpeg (AMVmuxer/ffmpeg) over libamvhip.
+ *
+ * Exports the four codec tables libavcodec/allcodecs.c registers for AMV (REGISTER_ENCDEC(AMV, amv) :64,
+ * REGISTER_ENCDEC(ADPCM_IMA_AMV, adpcm_ima_amv) :255) with the callback signatures of the reference's own
+ * `struct AVCodec` (libavcodec/avcodec.h:2149-2170), so that linking this object instead of
+ *     libavcodec/sp5xdec.c:203-212  amv_decoder   (sp5x_decode_frame -> ff_mjpeg_decode_frame, YUVJ420P out)
+ *     libavcodec/mjpegenc.c:485-494 amv_encoder   (amv_encode_picture -> MPV_encode_picture, YUVJ420P in)
+ *     libavcodec/adpcm.c:1535       adpcm_ima_amv_decoder / adpcm_ima_amv_encoder
+ * makes `ffmpeg -f amv ...` (AMVmuxer/Makefile:15-17) run its AMV codec work on the GPU.  It is compiled against
+ * the reference's avcodec.h WHERE IT LIES (amv-codec-tools_amd/build.py, -I only): AVCodecContext and AVFrame are
+ * the 2007 layouts of that header, nothing is copied or re-declared here.
+ *
+ * Host C only; every codec result comes from libamvhip.so (no CPU fallback: init fails without a HIP device).
+ * One frame per call, synchronous, as the callback contract demands -- the batch entry points of
+ * include/amvhip.h are where throughput lives.
+ *
+ *   decode (video)  AMVHIP_FLAG_FFMPEG: FFmpeg's own AMV arithmetic (Q60 tables, simple_idct, flipped planes),
+ *                   so a transcode through this plugin shows the pictures the reference's decoder shows.
+ *   encode (video)  planar YUVJ420P in, as pix_fmts declares.  Differences from the reference's encoder are the
+ *                   documented ones of DESIGN.md section 2 (amvlib's quantiser tables, true level shift): the
+ *                   reference's own output does not survive any AMV decoder.
+ *   audio           chunk layout, step index carried from call to call, odd-sample carry and 1 Hz resync of
+ *                   adpcm.c:461-498; `-trellis` is not implemented (the option is ignored).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "avcodec.h"
+
+#include "../../include/amvhip.h"
+
+typedef struct AmvHipVideo {
+    amvhip_ctx *ctx;
+    AVFrame picture;        /* decoder: the buffer handed out last (mjpegdec.c keeps s->picture the same way) */
+    uint8_t *own[3];        /* planes of our own when the caller installed no get_buffer */
+    uint8_t *staging;       /* tight YUVJ420P frame from the library */
+    size_t staging_size;
+    uint8_t *chunk;         /* encoder: one chunk */
+    uint32_t chunk_cap;
+} AmvHipVideo;
+
+typedef struct AmvHipAudio {
+    amvhip_ctx *ctx;
+    int32_t step_index;     /* adpcm.c: c->status[0].step_index, zero at open */
+    uint32_t extra;         /* c->extra_amv_samples */
+    uint64_t samples_written;
+} AmvHipAudio;
+
+static int device_index(void)
+{
+    const char *e = getenv("AMVHIP_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+static AVFrame *new_coded_frame(void)   /* avcodec_alloc_frame's essentials (utils.c:747-766) */
+{
+    AVFrame *f = calloc(1, sizeof *f);
+    if (f) {
+        f->pts = AV_NOPTS_VALUE;
+        f->key_frame = 1;
+        f->pict_type = FF_I_TYPE;
+    }
+    return f;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * amv_decoder  (sp5xdec.c:33-93 + mjpegdec.c)
+ * ------------------------------------------------------------------------------------------- */
+static int amvhip_video_decode_init(AVCodecContext *avctx)
+{
+    AmvHipVideo *s = avctx->priv_data;
+    memset(s, 0, sizeof *s);
+    avctx->pix_fmt = PIX_FMT_YUVJ420P;                       /* mjpegdec.c:312 */
+    return amvhip_create(&s->ctx, device_index()) == AMVHIP_OK ? 0 : -1;
+}
+
+static void release_picture(AVCodecContext *avctx, AmvHipVideo *s)
+{
+    if (s->picture.data[0] && !s->own[0] && avctx->release_buffer)
+        avctx->release_buffer(avctx, &s->picture);           /* mjpegdec.c:327-328 */
+    s->picture.data[0] = NULL;
+}
+
+static int amvhip_video_decode_end(AVCodecContext *avctx)
+{
+    AmvHipVideo *s = avctx->priv_data;
+    int i;
+    release_picture(avctx, s);
+    for (i = 0; i < 3; i++) free(s->own[i]);
+    free(s->staging);
+    amvhip_destroy(s->ctx);
+    memset(s, 0, sizeof *s);
+    return 0;
+}
+
+static int amvhip_video_decode_frame(AVCodecContext *avctx, void *data, int *data_size, uint8_t *buf, int buf_size)
+{
+    AmvHipVideo *s = avctx->priv_data;
+    const int w = avctx->width, h = avctx->height;
+    const int cw = (w + 1) / 2, ch = (h + 1) / 2;
+    uint64_t off = 0;
+    uint32_t len = (uint32_t)buf_size;
+    int32_t status = 0;
+    size_t need;
+    int i, y;
+
+    *data_size = 0;
+    if (!w || !h || buf_size < 4)                            /* sp5xdec.c:46-47 */
+        return -1;
+    need = (size_t)amvhip_yuv420_frame_bytes(w, h);
+    if (need > s->staging_size) {
+        free(s->staging);
+        s->staging = malloc(need);
+        s->staging_size = s->staging ? need : 0;
+        if (!s->staging) return -1;
+    }
+    if (amvhip_decode_batch(s->ctx, buf, len, &off, &len, 1, w, h, AMVHIP_FLAG_FFMPEG, s->staging, &status) != AMVHIP_OK)
+        return -1;
+    /* a damaged chunk: FFmpeg logs ("error dc" / "error count", mjpegdec.c:384,420) and shows what it has */
+
+    release_picture(avctx, s);
+    if (avctx->get_buffer) {                                 /* mjpegdec.c:330-334 */
+        s->picture.reference = 0;
+        if (avctx->get_buffer(avctx, &s->picture) < 0)
+            return -1;
+    } else {
+        const int pw[3] = {w, cw, cw}, ph[3] = {h, ch, ch};
+        for (i = 0; i < 3; i++) {
+            if (!s->own[i] && !(s->own[i] = malloc((size_t)pw[i] * ph[i]))) return -1;
+            s->picture.data[i] = s->own[i];
+            s->picture.linesize[i] = pw[i];
+        }
+    }
+    s->picture.pict_type = FF_I_TYPE;
+    s->picture.key_frame = 1;
+    {
+        const uint8_t *src = s->staging;
+        const int pw[3] = {w, cw, cw}, ph[3] = {h, ch, ch};
+        for (i = 0; i < 3; i++) {
+            for (y = 0; y < ph[i]; y++)
+                memcpy(s->picture.data[i] + (ptrdiff_t)y * s->picture.linesize[i], src + (size_t)y * pw[i], pw[i]);
+            src += (size_t)pw[i] * ph[i];
+        }
+    }
+    *(AVFrame *)data = s->picture;                           /* mjpegdec.c:1266-1268 */
+    *data_size = sizeof(AVFrame);
+    return buf_size;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * amv_encoder  (mjpegenc.c:454-494)
+ * ------------------------------------------------------------------------------------------- */
+static int amvhip_video_encode_init(AVCodecContext *avctx)
+{
+    AmvHipVideo *s = avctx->priv_data;
+    memset(s, 0, sizeof *s);
+    if (avctx->pix_fmt != PIX_FMT_YUVJ420P)                  /* mpegvideo_enc.c:251-256 (422 is not built) */
+        return -1;
+    if ((avctx->width & 1) || (avctx->height & 1) || avctx->width <= 0 || avctx->height <= 0)
+        return -1;
+    if (amvhip_create(&s->ctx, device_index()) != AMVHIP_OK)
+        return -1;
+    s->chunk_cap = amvhip_encode_bound(avctx->width, avctx->height);
+    s->chunk = malloc(s->chunk_cap);
+    avctx->coded_frame = new_coded_frame();
+    if (!s->chunk || !avctx->coded_frame)
+        return -1;
+    return 0;
+}
+
+static int amvhip_video_encode_end(AVCodecContext *avctx)
+{
+    AmvHipVideo *s = avctx->priv_data;
+    free(s->chunk);
+    free(avctx->coded_frame);
+    avctx->coded_frame = NULL;
+    amvhip_destroy(s->ctx);
+    memset(s, 0, sizeof *s);
+    return 0;
+}
+
+static int amvhip_video_encode_frame(AVCodecContext *avctx, unsigned char *buf, int buf_size, void *data)
+{
+    AmvHipVideo *s = avctx->priv_data;
+    AVFrame *pic = data;
+    uint64_t off = 0;
+    uint32_t len = 0;
+
+    if (avctx->flags & CODEC_FLAG_EMU_EDGE)                  /* mjpegenc.c:462-464 */
+        return -1;
+    if (!pic || !pic->data[0] || pic->linesize[0] < avctx->width || pic->linesize[1] < avctx->width / 2 ||
+        pic->linesize[1] != pic->linesize[2])
+        return -1;
+    /* the flip of mjpegenc.c:466-470 happens inside the kernel (bitstream row k = picture row h-1-k) */
+    if (amvhip_encode_yuv420_batch(s->ctx, pic->data[0], pic->data[1], pic->data[2], pic->linesize[0], pic->linesize[1], 0, 0, 1,
+                                   avctx->width, avctx->height, AMVHIP_QBIAS_AMV, s->chunk, s->chunk_cap, &off, &len) != AMVHIP_OK)
+        return -1;
+    if ((int)len > buf_size)
+        return -1;
+    memcpy(buf, s->chunk, len);
+    avctx->coded_frame->pict_type = FF_I_TYPE;
+    avctx->coded_frame->key_frame = 1;
+    return (int)len;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * adpcm_ima_amv  (adpcm.c:155-211, 445-498, 1268-1290)
+ * ------------------------------------------------------------------------------------------- */
+static int amvhip_audio_init(AVCodecContext *avctx, int encoder)
+{
+    AmvHipAudio *s = avctx->priv_data;
+    memset(s, 0, sizeof *s);
+    if (encoder) {
+        if (avctx->channels != 1 || avctx->sample_rate != 22050)   /* adpcm.c:190-199 */
+            return -1;
+        if (!(avctx->coded_frame = new_coded_frame()))              /* :206-207 */
+            return -1;
+    } else if (avctx->channels > 2) {                               /* :1148-1149 */
+        return -1;
+    }
+    return amvhip_create(&s->ctx, device_index()) == AMVHIP_OK ? 0 : -1;
+}
+
+static int amvhip_audio_encode_init(AVCodecContext *avctx) { return amvhip_audio_init(avctx, 1); }
+static int amvhip_audio_decode_init(AVCodecContext *avctx) { return amvhip_audio_init(avctx, 0); }
+
+static int amvhip_audio_close(AVCodecContext *avctx)
+{
+    AmvHipAudio *s = avctx->priv_data;
+    free(avctx->coded_frame);                                       /* adpcm.c:214 */
+    avctx->coded_frame = NULL;
+    amvhip_destroy(s->ctx);
+    memset(s, 0, sizeof *s);
+    return 0;
+}
+
+static int amvhip_audio_encode_frame(AVCodecContext *avctx, unsigned char *frame, int buf_size, void *data)
+{
+    AmvHipAudio *s = avctx->priv_data;
+    uint32_t n;
+    int r;
+
+    if (avctx->frame_size <= 0 || !data)
+        return -1;
+    avctx->coded_frame->pts = (int64_t)s->samples_written;          /* adpcm.c:463 */
+    n = amvhip_amv_audio_pairs((uint32_t)avctx->frame_size, (uint32_t)avctx->sample_rate, &s->extra, &s->samples_written);
+    if (n == 0 || (int)(8 + n) > buf_size)
+        return -1;
+    /* reads 2n samples like the reference does -- up to frame_size + 1, or more at a second's end (:476-477) */
+    r = amvhip_adpcm_encode_frame(s->ctx, (const int16_t *)data, 2 * n, &s->step_index, frame, (uint32_t)buf_size);
+    return r < 0 ? -1 : r;
+}
+
+static int amvhip_audio_decode_frame(AVCodecContext *avctx, void *data, int *data_size, uint8_t *buf, int buf_size)
+{
+    AmvHipAudio *s = avctx->priv_data;
+    uint64_t off = 0, pcm_off = 0;
+    uint32_t len = (uint32_t)buf_size;
+
+    *data_size = 0;
+    if (!buf_size)                                                  /* adpcm.c:812-813 */
+        return 0;
+    if (buf_size <= 8)
+        return buf_size;
+    /* every payload byte is decoded, whatever the header's count says (:1276-1288) */
+    if (amvhip_adpcm_decode_batch(s->ctx, buf, len, &off, &len, 1, (int16_t *)data, 2ull * (len - 8), &pcm_off, NULL) != AMVHIP_OK)
+        return -1;
+    *data_size = (int)(4 * (len - 8));
+    return buf_size;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * the tables, field for field as the reference declares them
+ * ------------------------------------------------------------------------------------------- */
+static const enum PixelFormat amvhip_pix_fmts[] = {PIX_FMT_YUVJ420P, -1};   /* mjpegenc.c:493 lists 422 too; it is not built */
+
+AVCodec amv_decoder = {                                             /* sp5xdec.c:203-212 */
+    "amv",
+    CODEC_TYPE_VIDEO,
+    CODEC_ID_AMV,
+    sizeof(AmvHipVideo),
+    amvhip_video_decode_init,
+    NULL,
+    amvhip_video_decode_end,
+    amvhip_video_decode_frame,
+};
+
+AVCodec amv_encoder = {                                             /* mjpegenc.c:485-494 */
+    "amv",
+    CODEC_TYPE_VIDEO,
+    CODEC_ID_AMV,
+    sizeof(AmvHipVideo),
+    amvhip_video_encode_init,
+    amvhip_video_encode_frame,
+    amvhip_video_encode_end,
+    .pix_fmts = amvhip_pix_fmts,
+};
+
+AVCodec adpcm_ima_amv_encoder = {                                   /* adpcm.c:1498-1508,1535 */
+    "adpcm_ima_amv",
+    CODEC_TYPE_AUDIO,
+    CODEC_ID_ADPCM_IMA_AMV,
+    sizeof(AmvHipAudio),
+    amvhip_audio_encode_init,
+    amvhip_audio_encode_frame,
+    amvhip_audio_close,
+    NULL,
+};
+
+AVCodec adpcm_ima_amv_decoder = {                                   /* adpcm.c:1514-1524,1535 */
+    "adpcm_ima_amv",
+    CODEC_TYPE_AUDIO,
+    CODEC_ID_ADPCM_IMA_AMV,
+    sizeof(AmvHipAudio),
+    amvhip_audio_decode_init,
+    NULL,
+    amvhip_audio_close,
+    amvhip_audio_decode_frame,
+};

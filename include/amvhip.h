@@ -248,8 +248,11 @@ int amvhip_reconstruct_dev(amvhip_ctx *ctx, const int16_t *d_coef, const uint32_
  * :282-355) over n frames.
  *   d_pix      : n frames, RGB24 (is_bgr=0) or BGR24 (is_bgr=1), top-down, pix_stride bytes/row,
  *                frame i at d_pix + i*pix_stride*height; width and height must be even
- *   d_blob     : output, n * amvhip_encode_bound(w,h) bytes capacity required (blob_cap);
- *                chunks are written back to back in frame order
+ *   d_blob     : output of blob_cap bytes; chunks are written back to back in frame order.
+ *                n * amvhip_encode_bound(w,h) always suffices (real streams run at ~0.2 byte per pixel).
+ *                A chunk that would end past blob_cap is NOT written and its d_lens entry is 0 (d_offs still
+ *                says where it would have started): a consumer checks d_lens[i] != 0.  The host-buffer forms
+ *                return AMVHIP_ERR_SPACE instead.
  *   d_offs/d_lens : n entries written
  */
 int amvhip_encode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_pix, uint32_t pix_stride, int is_bgr,
@@ -259,6 +262,22 @@ int amvhip_encode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_pix, uint32_t pix_
 int amvhip_encode_batch(amvhip_ctx *ctx, const uint8_t *pix, uint32_t pix_stride, int is_bgr,
                         uint32_t n, uint32_t width, uint32_t height, uint32_t qbias,
                         uint8_t *blob, uint64_t blob_cap, uint64_t *offs, uint32_t *lens);
+/*
+ * The same from planar YUVJ420P, the pixel format the reference's amv_encoder declares and takes
+ * (mjpegenc.c:485-494 pix_fmts; amv_encode_picture :454-472 flips it by negative linesize; get_pixels
+ * mpegvideo_enc.c:1539-1549): no colour conversion, otherwise the path above.  Frame i's planes start at
+ * d_y + i*y_frame_stride and d_cb/d_cr + i*c_frame_stride (bytes), rows y_stride / c_stride apart; chroma planes
+ * are (w/2) x (h/2).  rgb24_to_yuvj420p followed by this entry equals amvhip_encode_batch_dev bit for bit.
+ */
+int amvhip_encode_yuv420_batch_dev(amvhip_ctx *ctx, const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr,
+                                   uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                   uint64_t c_frame_stride, uint32_t n, uint32_t width, uint32_t height,
+                                   uint32_t qbias, uint8_t *d_blob, uint64_t blob_cap, uint64_t *d_offs,
+                                   uint32_t *d_lens, void *stream);
+int amvhip_encode_yuv420_batch(amvhip_ctx *ctx, const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
+                               uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                               uint64_t c_frame_stride, uint32_t n, uint32_t width, uint32_t height,
+                               uint32_t qbias, uint8_t *blob, uint64_t blob_cap, uint64_t *offs, uint32_t *lens);
 /* Stage access: quantised coefficients (zig-zag order, not predicted), n*nmcu*6*64 int16 */
 int amvhip_encode_coefs_dev(amvhip_ctx *ctx, const uint8_t *d_pix, uint32_t pix_stride, int is_bgr,
                             uint32_t n, uint32_t width, uint32_t height, uint32_t qbias,
@@ -292,6 +311,17 @@ int amvhip_adpcm_encode_batch(amvhip_ctx *ctx, const int16_t *pcm, uint64_t pcm_
                               const uint64_t *pcm_offs, const uint32_t *nsamp, uint32_t n,
                               const int32_t *step_in, uint8_t *blob, uint64_t blob_bytes,
                               const uint64_t *offs);
+/* One AMV audio chunk, host buffers, the step index handed in and out (what adpcm_encode_frame keeps in its
+ * context between calls, adpcm.c:461-498).  nsamp even and > 0; writes 8 + nsamp/2 bytes, returns that count. */
+int amvhip_adpcm_encode_frame(amvhip_ctx *ctx, const int16_t *samples, uint32_t nsamp, int32_t *step_index,
+                              uint8_t *chunk, uint32_t cap);
+/* The framing the reference's AMV audio encoder and muxer apply around the kernel (host arithmetic only):
+ * amvhip_amv_audio_pairs      adpcm.c:469-477,497: sample pairs of the next chunk for a nominal frame_size (odd sizes
+ *                             alternate, a chunk that would straddle a whole second is stretched to end on it);
+ *                             *extra (0/1) and *samples_written are the stream state, both start at 0.
+ * amvhip_amv_audio_frame_size amvenc.c:276-281: frame_size = sample_rate * time_base (22050/16 -> 1378). */
+uint32_t amvhip_amv_audio_pairs(uint32_t frame_size, uint32_t sample_rate, uint32_t *extra, uint64_t *samples_written);
+uint32_t amvhip_amv_audio_frame_size(uint32_t sample_rate, uint32_t tb_num, uint32_t tb_den);
 /* amvlib's IMA-WAV-layout encoder (AdpcmIma.c:43-160), one mono frame, host buffers; backs
  * AdpcmImaEncodeFrame.  state = {prev_sample (out), step_index (in/out)}; returns bytes written. */
 int amvhip_adpcm_wav_encode_frame(amvhip_ctx *ctx, const int16_t *samples, int frame_size,

@@ -209,3 +209,29 @@ def test_jpeg_and_adpcm_wav_export_are_host_only(pkg, amv1, tmp_path):
     assert dec.contents.fileseekpos == 316                                     # positions restored (:554-555)
     assert lib.AmvCreateWavFileFromAmvFile(dec, 7, wav.encode()) == -1
     lib.AmvClose(dec)
+
+
+def test_avcodec_plugin_tables(pkg):
+    """libamvhip_lavc.so (built where the reference's avcodec.h exists) exports the four tables allcodecs.c registers,
+    laid out as `struct AVCodec` (avcodec.h:2149-2170): name, type, id, priv_data_size, init, encode, close, decode"""
+    import ctypes
+    path = os.path.join(os.path.dirname(pkg.LIB_PATH), "libamvhip_lavc.so")
+    if not os.path.exists(path):
+        pytest.skip("the plugin is compiled against /root/reference's avcodec.h; not built here")
+    pkg.load_library()
+    lib = ctypes.CDLL(path)
+
+    class AVCodecHead(ctypes.Structure):
+        _fields_ = [("name", ctypes.c_char_p), ("type", ctypes.c_int), ("id", ctypes.c_int), ("priv_data_size", ctypes.c_int),
+                    ("init", ctypes.c_void_p), ("encode", ctypes.c_void_p), ("close", ctypes.c_void_p), ("decode", ctypes.c_void_p)]
+
+    want = {"amv_decoder": (b"amv", 0, False, True), "amv_encoder": (b"amv", 0, True, False),
+            "adpcm_ima_amv_decoder": (b"adpcm_ima_amv", 1, False, True), "adpcm_ima_amv_encoder": (b"adpcm_ima_amv", 1, True, False)}
+    ids = {}
+    for sym, (name, typ, enc, dec) in want.items():
+        t = AVCodecHead.in_dll(lib, sym)
+        assert t.name == name and t.type == typ and t.priv_data_size > 0 and t.init
+        assert bool(t.encode) == enc and bool(t.decode) == dec and t.close
+        ids[sym] = t.id
+    assert ids["amv_decoder"] == ids["amv_encoder"] and ids["adpcm_ima_amv_decoder"] == ids["adpcm_ima_amv_encoder"]
+    assert ids["amv_decoder"] != ids["adpcm_ima_amv_decoder"]

@@ -813,3 +813,144 @@ def test_ffmpeg_compat_errors_saturation_and_kernels(ctx, pkg, orc, amv1):
                     p = start - (8 * by + i)
                     if 0 <= p < plane.shape[0]:
                         assert (plane[p, 8 * bx: 8 * bx + 8] == px[8 * i: 8 * i + 8]).all(), (f, m, k, i)
+
+
+# ---------------------------------------------------------------------------------- FFmpeg AVCodec plugin surface
+
+def test_encode_yuv420_entry_matches_rgb_path(ctx, orc):
+    """the YUVJ420P-input encode entry (what amv_encoder takes, mjpegenc.c:493): the oracle's rgb24_to_yuvj420p of a
+    source followed by this entry gives the oracle encoder's chunk of the RGB source, byte for byte -- sizes with
+    partial MCUs, padded plane strides, device and host forms"""
+    import torch
+    L = orc.lib()
+    for w, h, n in ((160, 120, 5), (320, 240, 3), (130, 98, 3), (16, 16, 2)):
+        cw, ch = w // 2, h // 2
+        ys, cs = w + 24, cw + 8                                    # padded rows
+        Y = np.full((n, h, ys), 0xEE, np.uint8)
+        Cb = np.full((n, ch, cs), 0xEE, np.uint8)
+        Cr = np.full((n, ch, cs), 0xEE, np.uint8)
+        want = []
+        for t in range(n):
+            src = orc.synth_frame(SEED, 40 + t, w, h)
+            y, cb, cr = np.zeros((h, w), np.uint8), np.zeros((ch, cw), np.uint8), np.zeros((ch, cw), np.uint8)
+            L.amvo_rgb24_to_yuvj420p(src.ctypes.data, w * 3, w, h, 0, y.ctypes.data, cb.ctypes.data, cr.ctypes.data)
+            Y[t, :, :w], Cb[t, :, :cw], Cr[t, :, :cw] = y, cb, cr
+            want.append(orc.encode_frame(src, w, h))
+        cap = ctx.encode_bound(w, h) * n
+        d_blob = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+        d_offs = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+        d_lens = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        ctx.encode_yuv420_batch_dev(_t(Y), _t(Cb), _t(Cr), ys, cs, h * ys, ch * cs, n, w, h, 0, d_blob, cap, d_offs, d_lens)
+        torch.cuda.synchronize()
+        blob, offs, lens = d_blob.cpu().numpy(), d_offs.cpu().numpy(), d_lens.cpu().numpy()
+        for t in range(n):
+            assert blob[int(offs[t]):int(offs[t]) + int(lens[t])].tobytes() == want[t], (w, h, t)
+        blob2, offs2, lens2 = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+        ctx.encode_yuv420_batch(Y, Cb, Cr, ys, cs, h * ys, ch * cs, n, w, h, 0, blob2, cap, offs2, lens2)
+        assert (lens2 == lens.astype(np.uint32)).all() and blob2[: int(offs2[-1] + lens2[-1])].tobytes() == b"".join(want)
+
+
+def test_encode_reports_blob_overflow(ctx, pkg, orc):
+    """a blob smaller than the chunks need: the device form marks the chunks it could not write with length 0,
+    the host form returns AMVHIP_ERR_SPACE"""
+    import torch
+    w, h, n = 160, 120, 6
+    src = np.stack([orc.synth_frame(SEED, t, w, h) for t in range(n)])
+    want = [orc.encode_frame(src[t], w, h) for t in range(n)]
+    cap = len(want[0]) + len(want[1]) + len(want[2]) + 10        # room for three chunks and a bit
+    d_blob = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+    d_offs = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+    d_lens = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    ctx.encode_batch_dev(_t(src), w * 3, 0, n, w, h, 0, d_blob, cap, d_offs, d_lens)
+    torch.cuda.synchronize()
+    lens, offs, blob = d_lens.cpu().numpy(), d_offs.cpu().numpy(), d_blob.cpu().numpy()
+    assert [int(x) for x in lens] == [len(want[0]), len(want[1]), len(want[2]), 0, 0, 0]
+    assert [int(x) for x in offs] == list(np.cumsum([0] + [len(c) for c in want[:-1]]))
+    assert blob[: sum(map(len, want[:3]))].tobytes() == b"".join(want[:3])
+    with pytest.raises(pkg.AmvHipError, match="-4"):
+        ctx.encode_batch(src, w * 3, 0, n, w, h, 0, np.zeros(cap, np.uint8), cap, np.zeros(n, np.uint64), np.zeros(n, np.uint32))
+
+
+def test_audio_framing_helpers_and_single_chunk_encoder(ctx, pkg, orc):
+    """adpcm.c:469-477 framing and amvenc.c:276-281 frame_size in the product == the oracle's restatement; the
+    one-chunk encoder hands the step index in and out exactly as the sequential reference does"""
+    lib = pkg.load_library()
+    assert lib.amvhip_amv_audio_frame_size(22050, 1, 16) == 1378 and lib.amvhip_amv_audio_frame_size(16000, 1, 12) == 1333
+    L = orc.lib()
+    for fs, rate in ((1378, 22050), (1471, 22050), (1333, 16000), (735, 22050)):
+        e1, w1, e2, w2 = ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint32(0), ctypes.c_uint64(0)
+        for _ in range(200):
+            assert lib.amvhip_amv_audio_pairs(fs, rate, ctypes.byref(e1), ctypes.byref(w1)) == \
+                L.amvo_adpcm_amv_pairs(fs, rate, ctypes.byref(e2), ctypes.byref(w2))
+            assert (e1.value, w1.value) == (e2.value, w2.value)
+    pcm = orc.synth_audio(SEED, 5000, 30 * 1378)
+    idx, want_idx = ctypes.c_int32(0), 0
+    for i in range(30):
+        seg = np.ascontiguousarray(pcm[i * 1378:(i + 1) * 1378])
+        out = np.zeros(8 + 689, np.uint8)
+        n = lib.amvhip_adpcm_encode_frame(ctx.h, seg.ctypes.data, 1378, ctypes.byref(idx), out.ctypes.data, out.size)
+        want, want_idx = orc.adpcm_encode_chunk(seg, want_idx)
+        assert n == len(want) and out.tobytes() == want and idx.value == want_idx, i
+
+
+def test_avcodec_plugin_through_the_struct(ctx, pkg, orc, amv1, tmp_path):
+    """rows b2 / f2: a C program (tests/c/lavc_host.c, compiled against the reference's avcodec.h) calls
+    amv_decoder, amv_encoder, adpcm_ima_amv_decoder and adpcm_ima_amv_encoder of libamvhip_lavc.so through
+    `struct AVCodec` and must reproduce the batch ABI's and the oracle's bytes"""
+    import os
+    import struct
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "c", "_bin", "lavc_host")
+    plugin = os.path.join(os.path.dirname(pkg.LIB_PATH), "libamvhip_lavc.so")
+    assert os.path.exists(exe) and os.path.exists(plugin), "built by amv-codec-tools_amd/build.py where /root/reference exists"
+    out = subprocess.run([exe, amv1["path"], str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    f = dict(line.split(": ", 1) for line in out.stdout.strip().splitlines() if ": " in line)
+    assert f["decoded frames"] == "252" and f["pix_fmt is yuvj420p"] == "1" and f["emu_edge rejected"] == "1"
+    assert f["get_buffer calls"] == "252" and f["release_buffer calls"] == "252" and f["11025 Hz rejected"] == "1"
+    rd = lambda name: open(os.path.join(str(tmp_path), name), "rb").read()
+    # decode leg: video == FFmpeg-compat batch decode == oracle; audio == oracle
+    got_v = np.frombuffer(rd("dec_video.yuv"), np.uint8).reshape(252, -1)
+    batch, st = _gpu_decode_ffmpeg(ctx, pkg, amv1["video"], 128, 96)
+    assert (st == 0).all() and (got_v == batch).all()
+    assert (got_v[::25] == _oracle_decode_ffmpeg(orc, amv1["video"][::25], 128, 96)[0]).all()
+    want_a = np.concatenate([orc.adpcm_decode_chunk(a)[0] for a in amv1["audio"]])
+    assert (np.frombuffer(rd("dec_audio.pcm"), np.int16) == want_a).all()
+    # video encode leg: == batch ABI on the same planes; every chunk decodes clean on the amvlib-pinned oracle
+    w, h, n = 160, 120, 24
+    src = np.frombuffer(rd("enc_src.yuv"), np.uint8).reshape(n, -1)
+    Y = np.ascontiguousarray(src[:, : w * h]).reshape(n, h, w)
+    Cb = np.ascontiguousarray(src[:, w * h: w * h + w * h // 4]).reshape(n, h // 2, w // 2)
+    Cr = np.ascontiguousarray(src[:, w * h + w * h // 4:]).reshape(n, h // 2, w // 2)
+    cap = ctx.encode_bound(w, h) * n
+    blob, offs, lens = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    ctx.encode_yuv420_batch(Y, Cb, Cr, w, w // 2, w * h, w * h // 4, n, w, h, 0, blob, cap, offs, lens)
+    raw, pos = rd("enc_video.bin"), 0
+    for t in range(n):
+        (ln,) = struct.unpack_from("<I", raw, pos)
+        chunk = raw[pos + 4: pos + 4 + ln]
+        pos += 4 + ln
+        assert chunk == blob[int(offs[t]):int(offs[t]) + int(lens[t])].tobytes(), t
+        dec, dst, _ = orc.decode_frame(chunk, w, h)
+        assert dst == 0
+        if t == 0:   # luma of the decoded picture is close to the source plane (different colour matrices: loose bound)
+            yy = (dec[:, : w * 3].reshape(h, w, 3).astype(np.int32) * np.array([117, 601, 306])).sum(2) >> 10
+            assert np.abs(yy - Y[0].astype(np.int32)).mean() < 12
+    assert pos == len(raw)
+    # audio encode leg: both passes == the oracle's sequential encoder fed by the oracle's framing
+    pcm = np.frombuffer(rd("enc_pcm.raw"), np.int16)
+    raw, pos = rd("enc_audio.bin"), 0
+    L = orc.lib()
+    for fs in (1378, 1471):
+        e, wr, p, idx, sizes = ctypes.c_uint32(0), ctypes.c_uint64(0), 0, 0, set()
+        for i in range(40):
+            npairs = L.amvo_adpcm_amv_pairs(fs, 22050, ctypes.byref(e), ctypes.byref(wr))
+            want, idx = orc.adpcm_encode_chunk(np.ascontiguousarray(pcm[p:p + 2 * npairs]), idx)
+            (ln,) = struct.unpack_from("<I", raw, pos)
+            assert raw[pos + 4: pos + 4 + ln] == want, (fs, i)
+            pos += 4 + ln
+            p += 2 * npairs
+            sizes.add(npairs)
+        assert len(sizes) >= 2          # the odd-sample carry / the 1 Hz resync really changed chunk sizes
+    assert pos == len(raw)
