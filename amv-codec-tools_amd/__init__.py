@@ -92,6 +92,10 @@ SYMBOLS = {
     "amvhip_jpeg_header": (_u32, [ctypes.c_ushort, ctypes.c_ushort, _vp, _u32]),
     "amvhip_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "amvhip_decode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "amvhip_decode_batch_async": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "amvhip_sync": (_int, [_vp]),
+    "amvhip_host_alloc": (_int, [_vp, ctypes.POINTER(_vp), ctypes.c_size_t]),
+    "amvhip_host_free": (None, [_vp, _vp]),
     "amvhip_huffman_decode_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "amvhip_reconstruct_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_encode_batch_dev": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
@@ -102,6 +106,7 @@ SYMBOLS = {
     "amvhip_adpcm_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "amvhip_adpcm_encode_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "amvhip_adpcm_decode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _u64, _vp, _vp]),
+    "amvhip_adpcm_decode_batch_async": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _u64, _vp, _vp]),
     "amvhip_adpcm_encode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),
     "amvhip_adpcm_encode_frame": (_int, [_vp, _vp, _u32, ctypes.POINTER(_i32), _vp, _u32]),
     "amvhip_amv_audio_pairs": (_u32, [_u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),

@@ -45,8 +45,9 @@ struct amvhip_ctx {
     uint32_t cus = 256;   // compute units of the device
     bool want_stats = false;
     int entropy_mode = AMVHIP_ENTROPY_AUTO;
-    // host-pointer staging
-    DevBuf h_in, h_offs, h_lens, h_out, h_status, h_aux;
+    // host-pointer staging (one in-order stream of the context's own carries every host-buffer entry point)
+    DevBuf h_in, h_offs, h_lens, h_out, h_status, h_aux, a_in, a_tab, a_out;
+    hipStream_t hstream = nullptr;
     // timing
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -190,6 +191,14 @@ int use_device(amvhip_ctx* c) {
     return AMVHIP_OK;
 }
 
+// the stream of the host-buffer entry points: created on first use, non-blocking (it does not order itself against
+// the caller's other streams)
+int host_stream(amvhip_ctx* c, hipStream_t* out) {
+    if (!c->hstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking));
+    *out = c->hstream;
+    return AMVHIP_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -230,8 +239,9 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     (void)hipSetDevice(c->device);
     drain(c);
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
+    if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->dcv, &c->mcu_start, &c->rec_count, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux})
+                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->dcv, &c->mcu_start, &c->rec_count, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -379,30 +389,60 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     return reconstruct_stage(c, sinks, (const uint32_t*)c->nmcu.p, n, g, flags, d_out, (hipStream_t)stream);
 }
 
-extern "C" int amvhip_decode_batch(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
-                                   const uint64_t* offs, const uint32_t* lens, uint32_t n, uint32_t w,
-                                   uint32_t h, uint32_t flags, uint8_t* out, int32_t* status) {
+extern "C" int amvhip_decode_batch_async(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
+                                         const uint64_t* offs, const uint32_t* lens, uint32_t n, uint32_t w,
+                                         uint32_t h, uint32_t flags, uint8_t* out, int32_t* status) {
     if (!c) return AMVHIP_ERR_ARG;
     if (!size_ok(w, h) || (n && (!blob || !offs || !lens || !out))) return fail(c, AMVHIP_ERR_ARG, "decode: bad argument");
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
+    hipStream_t st;
+    if (int r = host_stream(c, &st)) return r;
     const uint64_t fb = (flags & AMVHIP_FLAG_FFMPEG) ? amvhip_yuv420_frame_bytes(w, h) : amvhip_frame_bytes(w, h);
     if (int r = ensure(c, c->h_in, blob_bytes + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
     if (int r = ensure(c, c->h_out, fb * n)) return r;
     if (int r = ensure(c, c->h_status, (size_t)n * 4)) return r;
-    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, blob, blob_bytes, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, st));
     if (int r = amvhip_decode_batch_dev(c, (const uint8_t*)c->h_in.p, blob_bytes, (const uint64_t*)c->h_offs.p,
                                         (const uint32_t*)c->h_lens.p, n, w, h, flags, (uint8_t*)c->h_out.p,
-                                        (int32_t*)c->h_status.p, nullptr))
+                                        (int32_t*)c->h_status.p, st))
         return r;
-    HIP_TRY(c, hipMemcpyAsync(out, c->h_out.p, fb * n, hipMemcpyDeviceToHost, 0));
-    if (status) HIP_TRY(c, hipMemcpyAsync(status, c->h_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipStreamSynchronize(0));
+    HIP_TRY(c, hipMemcpyAsync(out, c->h_out.p, fb * n, hipMemcpyDeviceToHost, st));
+    if (status) HIP_TRY(c, hipMemcpyAsync(status, c->h_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     return AMVHIP_OK;
+}
+
+extern "C" int amvhip_sync(amvhip_ctx* c) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (int r = use_device(c)) return r;
+    if (c->hstream) HIP_TRY(c, hipStreamSynchronize(c->hstream));
+    return AMVHIP_OK;
+}
+
+extern "C" int amvhip_decode_batch(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
+                                   const uint64_t* offs, const uint32_t* lens, uint32_t n, uint32_t w,
+                                   uint32_t h, uint32_t flags, uint8_t* out, int32_t* status) {
+    if (int r = amvhip_decode_batch_async(c, blob, blob_bytes, offs, lens, n, w, h, flags, out, status)) return r;
+    return amvhip_sync(c);
+}
+
+// page-locked host memory for the *_async entry points (pageable buffers work too, but their copies block)
+extern "C" int amvhip_host_alloc(amvhip_ctx* c, void** p, size_t bytes) {
+    if (!c || !p) return AMVHIP_ERR_ARG;
+    *p = nullptr;
+    if (int r = use_device(c)) return r;
+    HIP_TRY(c, hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+    return AMVHIP_OK;
+}
+
+extern "C" void amvhip_host_free(amvhip_ctx* c, void* p) {
+    if (!c || !p) return;
+    (void)hipSetDevice(c->device);
+    (void)hipHostFree(p);
 }
 
 // =============================================================================================
@@ -495,16 +535,17 @@ extern "C" int amvhip_encode_yuv420_batch_dev(amvhip_ctx* c, const uint8_t* d_y,
 }
 
 // the device-to-host half of the host-buffer encoders: offs/lens, then the chunks
-static int encode_fetch(amvhip_ctx* c, uint32_t n, uint8_t* blob, uint64_t blob_cap, uint64_t* offs, uint32_t* lens) {
+static int encode_fetch(amvhip_ctx* c, hipStream_t hs, uint32_t n, uint8_t* blob, uint64_t blob_cap, uint64_t* offs, uint32_t* lens) {
     int32_t overflow = 0;
-    HIP_TRY(c, hipMemcpyAsync(offs, c->h_offs.p, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipMemcpyAsync(lens, c->h_lens.p, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipMemcpyAsync(&overflow, c->flag.p, 4, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipStreamSynchronize(0));
+    HIP_TRY(c, hipMemcpyAsync(offs, c->h_offs.p, (size_t)n * 8, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipMemcpyAsync(lens, c->h_lens.p, (size_t)n * 4, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipMemcpyAsync(&overflow, c->flag.p, 4, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipStreamSynchronize(hs));
     const uint64_t total = offs[n - 1] + lens[n - 1];
     if (overflow || total > blob_cap)
         return fail(c, AMVHIP_ERR_SPACE, "encode: the chunks need more than the %llu bytes of blob", (unsigned long long)blob_cap);
-    HIP_TRY(c, hipMemcpy(blob, c->h_out.p, total, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(blob, c->h_out.p, total, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipStreamSynchronize(hs));
     return AMVHIP_OK;
 }
 
@@ -515,17 +556,19 @@ extern "C" int amvhip_encode_batch(amvhip_ctx* c, const uint8_t* pix, uint32_t p
     if (n && (!pix || !blob || !offs || !lens)) return fail(c, AMVHIP_ERR_ARG, "encode: null argument");
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
+    hipStream_t hs;
+    if (int r = host_stream(c, &hs)) return r;
     const size_t in_bytes = (size_t)pix_stride * h * n;
     if (int r = ensure(c, c->h_in, in_bytes)) return r;
     if (int r = ensure(c, c->h_out, blob_cap + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
-    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, pix, in_bytes, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, pix, in_bytes, hipMemcpyHostToDevice, hs));
     if (int r = amvhip_encode_batch_dev(c, (const uint8_t*)c->h_in.p, pix_stride, is_bgr, n, w, h, qbias,
                                         (uint8_t*)c->h_out.p, blob_cap, (uint64_t*)c->h_offs.p,
-                                        (uint32_t*)c->h_lens.p, nullptr))
+                                        (uint32_t*)c->h_lens.p, hs))
         return r;
-    return encode_fetch(c, n, blob, blob_cap, offs, lens);
+    return encode_fetch(c, hs, n, blob, blob_cap, offs, lens);
 }
 
 extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
@@ -537,6 +580,8 @@ extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const
         return fail(c, AMVHIP_ERR_ARG, "encode_yuv420: bad argument");
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
+    hipStream_t hs;
+    if (int r = host_stream(c, &hs)) return r;
     // staged tight: Y w*h, Cb, Cr (w/2 x h/2) per frame
     const uint32_t cw = w / 2, chh = h / 2;
     const uint64_t fb = (uint64_t)w * h + 2ull * cw * chh;
@@ -546,15 +591,15 @@ extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
     uint8_t* d = (uint8_t*)c->h_in.p;
     for (uint32_t i = 0; i < n; ++i) {
-        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb, w, y + i * y_frame_stride, y_stride, w, h, hipMemcpyHostToDevice, 0));
-        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb + (uint64_t)w * h, cw, cb + i * c_frame_stride, c_stride, cw, chh, hipMemcpyHostToDevice, 0));
-        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb + (uint64_t)w * h + (uint64_t)cw * chh, cw, cr + i * c_frame_stride, c_stride, cw, chh, hipMemcpyHostToDevice, 0));
+        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb, w, y + i * y_frame_stride, y_stride, w, h, hipMemcpyHostToDevice, hs));
+        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb + (uint64_t)w * h, cw, cb + i * c_frame_stride, c_stride, cw, chh, hipMemcpyHostToDevice, hs));
+        HIP_TRY(c, hipMemcpy2DAsync(d + i * fb + (uint64_t)w * h + (uint64_t)cw * chh, cw, cr + i * c_frame_stride, c_stride, cw, chh, hipMemcpyHostToDevice, hs));
     }
     if (int r = amvhip_encode_yuv420_batch_dev(c, d, d + (uint64_t)w * h, d + (uint64_t)w * h + (uint64_t)cw * chh, w, cw, fb, fb, n, w, h,
                                                qbias, (uint8_t*)c->h_out.p, blob_cap, (uint64_t*)c->h_offs.p,
-                                               (uint32_t*)c->h_lens.p, nullptr))
+                                               (uint32_t*)c->h_lens.p, hs))
         return r;
-    return encode_fetch(c, n, blob, blob_cap, offs, lens);
+    return encode_fetch(c, hs, n, blob, blob_cap, offs, lens);
 }
 
 // =============================================================================================
@@ -595,34 +640,45 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
     return check_launch(c, "adpcm_encode");
 }
 
-extern "C" int amvhip_adpcm_decode_batch(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
-                                         const uint64_t* offs, const uint32_t* lens, uint32_t n, int16_t* pcm,
-                                         uint64_t pcm_samples, const uint64_t* pcm_offs, int32_t* final_state) {
+extern "C" int amvhip_adpcm_decode_batch_async(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
+                                               const uint64_t* offs, const uint32_t* lens, uint32_t n, int16_t* pcm,
+                                               uint64_t pcm_samples, const uint64_t* pcm_offs, int32_t* final_state) {
     if (!c) return AMVHIP_ERR_ARG;
     if (n && (!blob || !offs || !lens || !pcm || !pcm_offs)) return fail(c, AMVHIP_ERR_ARG, "adpcm_decode: null argument");
     if (n == 0) return AMVHIP_OK;
     for (uint32_t i = 0; i < n; ++i)
         if (lens[i] > 8 && pcm_offs[i] + 2ull * (lens[i] - 8) > pcm_samples) return fail(c, AMVHIP_ERR_SPACE, "adpcm_decode: pcm too small for chunk %u", i);
     if (int r = use_device(c)) return r;
-    if (int r = ensure(c, c->h_in, blob_bytes + 16)) return r;
-    if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
-    if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
-    if (int r = ensure(c, c->h_out, pcm_samples * 2)) return r;
-    if (int r = ensure(c, c->h_aux, (size_t)n * 8)) return r;
-    if (int r = ensure(c, c->h_status, (size_t)n * 8)) return r;
-    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, blob, blob_bytes, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_aux.p, pcm_offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_out.p, pcm, pcm_samples * 2, hipMemcpyHostToDevice, 0));  // keep untouched gaps
-    if (int r = amvhip_adpcm_decode_batch_dev(c, (const uint8_t*)c->h_in.p, blob_bytes, (const uint64_t*)c->h_offs.p,
-                                              (const uint32_t*)c->h_lens.p, n, (int16_t*)c->h_out.p,
-                                              (const uint64_t*)c->h_aux.p, (int32_t*)c->h_status.p, nullptr))
+    hipStream_t st;
+    if (int r = host_stream(c, &st)) return r;
+    // audio staging sits behind the video staging of the same stream: separate buffers, so that a video batch and the
+    // audio batch that travels with it can both be in flight
+    if (int r = ensure(c, c->a_in, blob_bytes + 16)) return r;
+    if (int r = ensure(c, c->a_tab, (size_t)n * 28)) return r;
+    if (int r = ensure(c, c->a_out, pcm_samples * 2)) return r;
+    uint8_t* tab = (uint8_t*)c->a_tab.p;
+    uint64_t* d_offs = (uint64_t*)tab;
+    uint64_t* d_pcm_offs = (uint64_t*)(tab + (size_t)n * 8);
+    int32_t* d_fin = (int32_t*)(tab + (size_t)n * 16);
+    uint32_t* d_lens = (uint32_t*)(tab + (size_t)n * 24);
+    HIP_TRY(c, hipMemcpyAsync(c->a_in.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_offs, offs, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_pcm_offs, pcm_offs, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->a_out.p, pcm, pcm_samples * 2, hipMemcpyHostToDevice, st));  // keep untouched gaps
+    if (int r = amvhip_adpcm_decode_batch_dev(c, (const uint8_t*)c->a_in.p, blob_bytes, d_offs, d_lens, n, (int16_t*)c->a_out.p,
+                                              d_pcm_offs, d_fin, st))
         return r;
-    HIP_TRY(c, hipMemcpyAsync(pcm, c->h_out.p, pcm_samples * 2, hipMemcpyDeviceToHost, 0));
-    if (final_state) HIP_TRY(c, hipMemcpyAsync(final_state, c->h_status.p, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipStreamSynchronize(0));
+    HIP_TRY(c, hipMemcpyAsync(pcm, c->a_out.p, pcm_samples * 2, hipMemcpyDeviceToHost, st));
+    if (final_state) HIP_TRY(c, hipMemcpyAsync(final_state, d_fin, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     return AMVHIP_OK;
+}
+
+extern "C" int amvhip_adpcm_decode_batch(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
+                                         const uint64_t* offs, const uint32_t* lens, uint32_t n, int16_t* pcm,
+                                         uint64_t pcm_samples, const uint64_t* pcm_offs, int32_t* final_state) {
+    if (int r = amvhip_adpcm_decode_batch_async(c, blob, blob_bytes, offs, lens, n, pcm, pcm_samples, pcm_offs, final_state)) return r;
+    return amvhip_sync(c);
 }
 
 extern "C" int amvhip_adpcm_encode_batch(amvhip_ctx* c, const int16_t* pcm, uint64_t pcm_samples,
@@ -637,25 +693,27 @@ extern "C" int amvhip_adpcm_encode_batch(amvhip_ctx* c, const int16_t* pcm, uint
         if (offs[i] + 8ull + (nsamp[i] >> 1) > blob_bytes) return fail(c, AMVHIP_ERR_SPACE, "adpcm_encode: blob too small for chunk %u", i);
     }
     if (int r = use_device(c)) return r;
+    hipStream_t hs;
+    if (int r = host_stream(c, &hs)) return r;
     if (int r = ensure(c, c->h_in, pcm_samples * 2 + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
     if (int r = ensure(c, c->h_out, blob_bytes)) return r;
     if (int r = ensure(c, c->h_aux, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_status, (size_t)n * 4)) return r;
-    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, pcm, pcm_samples * 2, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_aux.p, pcm_offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, nsamp, (size_t)n * 4, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_out.p, blob, blob_bytes, hipMemcpyHostToDevice, 0));
-    if (step_in) HIP_TRY(c, hipMemcpyAsync(c->h_status.p, step_in, (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, pcm, pcm_samples * 2, hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, hipMemcpyAsync(c->h_aux.p, pcm_offs, (size_t)n * 8, hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, nsamp, (size_t)n * 4, hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, hipMemcpyAsync(c->h_out.p, blob, blob_bytes, hipMemcpyHostToDevice, hs));
+    if (step_in) HIP_TRY(c, hipMemcpyAsync(c->h_status.p, step_in, (size_t)n * 4, hipMemcpyHostToDevice, hs));
     if (int r = amvhip_adpcm_encode_batch_dev(c, (const int16_t*)c->h_in.p, (const uint64_t*)c->h_aux.p,
                                               (const uint32_t*)c->h_lens.p, n,
                                               step_in ? (const int32_t*)c->h_status.p : nullptr,
-                                              (uint8_t*)c->h_out.p, (const uint64_t*)c->h_offs.p, nullptr))
+                                              (uint8_t*)c->h_out.p, (const uint64_t*)c->h_offs.p, hs))
         return r;
-    HIP_TRY(c, hipMemcpyAsync(blob, c->h_out.p, blob_bytes, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipStreamSynchronize(0));
+    HIP_TRY(c, hipMemcpyAsync(blob, c->h_out.p, blob_bytes, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipStreamSynchronize(hs));
     return AMVHIP_OK;
 }
 
@@ -670,6 +728,8 @@ extern "C" int amvhip_adpcm_encode_frame(amvhip_ctx* c, const int16_t* samples, 
         return fail(c, AMVHIP_ERR_ARG, "adpcm_encode_frame: bad argument (even, non-zero sample count; index 0..88)");
     if (cap < len) return fail(c, AMVHIP_ERR_SPACE, "adpcm_encode_frame: chunk needs %u bytes", len);
     if (int r = use_device(c)) return r;
+    hipStream_t hs;
+    if (int r = host_stream(c, &hs)) return r;
     // staging: [pcm | chunk | scratch pcm] + small tables {pcm_off, chunk_off, nsamp, len, step, final[2]}
     if (int r = ensure(c, c->h_in, (size_t)nsamp * 2 + 16)) return r;
     if (int r = ensure(c, c->h_out, (size_t)len + 16 + (size_t)nsamp * 2 + 16)) return r;
@@ -678,18 +738,18 @@ extern "C" int amvhip_adpcm_encode_frame(amvhip_ctx* c, const int16_t* samples, 
     uint8_t* aux = (uint8_t*)c->h_aux.p;
     uint8_t* d_chunk = (uint8_t*)c->h_out.p;
     int16_t* d_scratch = (int16_t*)(d_chunk + ((len + 15u) & ~15u));
-    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, samples, (size_t)nsamp * 2, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(aux, &tab, sizeof tab, hipMemcpyHostToDevice, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, samples, (size_t)nsamp * 2, hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, hipMemcpyAsync(aux, &tab, sizeof tab, hipMemcpyHostToDevice, hs));
     if (int r = amvhip_adpcm_encode_batch_dev(c, (const int16_t*)c->h_in.p, (const uint64_t*)aux, (const uint32_t*)(aux + 16), 1,
-                                              (const int32_t*)(aux + 24), d_chunk, (const uint64_t*)(aux + 8), nullptr))
+                                              (const int32_t*)(aux + 24), d_chunk, (const uint64_t*)(aux + 8), hs))
         return r;
     if (int r = amvhip_adpcm_decode_batch_dev(c, d_chunk, len, (const uint64_t*)(aux + 8), (const uint32_t*)(aux + 20), 1, d_scratch,
-                                              (const uint64_t*)aux, (int32_t*)(aux + 28), nullptr))
+                                              (const uint64_t*)aux, (int32_t*)(aux + 28), hs))
         return r;
     int32_t fin[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(chunk, d_chunk, len, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipMemcpyAsync(fin, aux + 28, 8, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipStreamSynchronize(0));
+    HIP_TRY(c, hipMemcpyAsync(chunk, d_chunk, len, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipMemcpyAsync(fin, aux + 28, 8, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipStreamSynchronize(hs));
     *step_index = fin[1];
     return (int)len;
 }
@@ -724,17 +784,19 @@ extern "C" int amvhip_adpcm_wav_encode_frame(amvhip_ctx* c, const int16_t* sampl
     if (!samples || !state || !frame || frame_size < 1 || buf_size < 4 + 4 * groups)
         return fail(c, AMVHIP_ERR_ARG, "adpcm_wav_encode: bad argument");
     if (int r = use_device(c)) return r;
+    hipStream_t hs;
+    if (int r = host_stream(c, &hs)) return r;
     const size_t ns = (size_t)1 + 8 * (size_t)groups;
     if (int r = ensure(c, c->h_in, ns * 2)) return r;
     if (int r = ensure(c, c->h_out, 4 + 4 * (size_t)groups)) return r;
     if (int r = ensure(c, c->h_status, 8)) return r;
-    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, samples, ns * 2, hipMemcpyHostToDevice, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_status.p, state, 8, hipMemcpyHostToDevice, 0));
-    launch_adpcm_wav_encode((const int16_t*)c->h_in.p, groups, (int32_t*)c->h_status.p, (uint8_t*)c->h_out.p, nullptr);
+    HIP_TRY(c, hipMemcpyAsync(c->h_in.p, samples, ns * 2, hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, hipMemcpyAsync(c->h_status.p, state, 8, hipMemcpyHostToDevice, hs));
+    launch_adpcm_wav_encode((const int16_t*)c->h_in.p, groups, (int32_t*)c->h_status.p, (uint8_t*)c->h_out.p, hs);
     if (int r = check_launch(c, "adpcm_wav_encode")) return r;
-    HIP_TRY(c, hipMemcpyAsync(frame, c->h_out.p, 4 + 4 * (size_t)groups, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipMemcpyAsync(state, c->h_status.p, 8, hipMemcpyDeviceToHost, 0));
-    HIP_TRY(c, hipStreamSynchronize(0));
+    HIP_TRY(c, hipMemcpyAsync(frame, c->h_out.p, 4 + 4 * (size_t)groups, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipMemcpyAsync(state, c->h_status.p, 8, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(c, hipStreamSynchronize(hs));
     return 4 + 4 * groups;
 }
 

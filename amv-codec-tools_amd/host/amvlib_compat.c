@@ -204,9 +204,179 @@ AMVDecoder *AmvOpen(const char *amvname)
     return amv;
 }
 
+/* ---- read-ahead -------------------------------------------------------------------------
+ * The reference reopens the file, reads ONE frame and decodes it on the CPU, per call (AMVDec.c:164,259,288).
+ * One frame per call is the worst shape for a GPU: a chunk is a few kilobytes and a decode call would be three
+ * copies, five launches and a synchronisation for it.  So behind the same three calls the reader takes a WINDOW of
+ * frames from the file at once, into page-locked buffers, and the first AmvVideoDecode (AmvAudioDecode) that falls
+ * inside the window sends all of its video (audio) chunks through the batch ABI in one go; every decode call then
+ * only copies its frame out of the window's result.  What the caller sees is unchanged: framebuf holds the
+ * chunk's bytes in memory the decoder owns, videobuf / audiobuf are filled by the decode calls, positions advance
+ * chunk by chunk, AmvRewindFrameStart and edited framebuf contents work (a decode call whose chunk is not byte for
+ * byte the window's falls back to decoding that one chunk).  AMVHIP_READAHEAD=<frames> sets the window (default
+ * 256, 1 = no read-ahead). */
+
+typedef struct ra_entry {
+    long pos;                 /* file position of the frame's "00dc" */
+    uint32_t voff, vlen;      /* video chunk in vblob */
+    uint32_t aoff, alen;      /* audio chunk in ablob, alen = real length; the slot is zero-padded to 8 + round4(alen - 8) */
+} ra_entry;
+
+typedef struct readahead {
+    AMVDecoder *owner;
+    struct readahead *next;
+    FILE *fp;
+    long fsize;
+    uint32_t cap_frames;
+    uint32_t n, cur;          /* frames in the window, next one to hand out */
+    int last;                 /* window index of the frame in framebuf, -1 = none */
+    int vstate, astate;       /* 0 = not sent, 1 = result in vout / aout, -1 = the batch call failed */
+    uint32_t w, h;
+    uint64_t fb;              /* bytes of a decoded frame */
+    ra_entry *e;
+    /* page-locked */
+    uint8_t *vblob, *ablob, *vout;
+    int16_t *aout;
+    size_t vblob_cap, ablob_cap, vout_cap, aout_cap;
+    size_t vbytes, abytes;    /* filled part of vblob / ablob */
+    uint64_t *voffs, *aoffs, *pcm_offs;
+    uint32_t *vlens, *alens;
+    int32_t *vstatus;
+    int pinned;               /* buffers came from amvhip_host_alloc (else malloc: no device in this process) */
+} readahead;
+
+static readahead *g_ra;
+
+static readahead *ra_find(const AMVDecoder *amv)
+{
+    readahead *r;
+    for (r = g_ra; r != NULL; r = r->next)
+        if (r->owner == amv) return r;
+    return NULL;
+}
+
+static void *ra_alloc(readahead *r, size_t bytes)
+{
+    void *p = NULL;
+    if (r->pinned && amvhip_host_alloc(ctx(), &p, bytes) == AMVHIP_OK) return p;
+    return r->pinned ? NULL : malloc(bytes ? bytes : 1);
+}
+
+static void ra_release(readahead *r, void *p)
+{
+    if (p == NULL) return;
+    if (r->pinned) amvhip_host_free(ctx(), p);
+    else free(p);
+}
+
+static void ra_free(readahead *r)
+{
+    if (r == NULL) return;
+    if (ctx() != NULL) amvhip_sync(ctx());
+    if (r->fp) fclose(r->fp);
+    ra_release(r, r->vblob); ra_release(r, r->ablob); ra_release(r, r->vout); ra_release(r, r->aout);
+    ra_release(r, r->voffs); ra_release(r, r->aoffs); ra_release(r, r->pcm_offs);
+    ra_release(r, r->vlens); ra_release(r, r->alens); ra_release(r, r->vstatus);
+    free(r->e);
+    free(r);
+}
+
+static uint32_t round4(uint32_t n) { return (n + 3u) & ~3u; }
+
+/* state of `amv`, made on first use */
+static readahead *ra_get(AMVDecoder *amv)
+{
+    readahead *r = ra_find(amv);
+    const char *env;
+    uint64_t cap;
+    if (r != NULL) return r;
+    r = (readahead *)calloc(1, sizeof *r);
+    if (r == NULL) return NULL;
+    r->owner = amv;
+    r->last = -1;
+    r->w = amv->amvinfo.dwWidth;
+    r->h = amv->amvinfo.dwHeight;
+    r->fb = amvhip_frame_bytes(r->w, r->h);
+    r->pinned = ctx() != NULL;
+    env = getenv("AMVHIP_READAHEAD");
+    cap = env ? (uint64_t)strtoul(env, NULL, 10) : 256u;
+    if (cap < 1) cap = 1;
+    if (cap > 4096) cap = 4096;
+    while (cap > 1 && cap * (r->fb ? r->fb : 1) > (64u << 20)) cap /= 2;   /* at most 64 MB of decoded frames per window */
+    r->cap_frames = (uint32_t)cap;
+    r->fp = fopen(amv->amvfilename, "rb");
+    if (r->fp != NULL && fseek(r->fp, 0, SEEK_END) == 0) r->fsize = ftell(r->fp);
+    /* chunk space: AMV streams run at ~0.2 byte per pixel; a window that meets fatter chunks just ends early */
+    r->vblob_cap = (size_t)cap * ((size_t)r->w * r->h / 2 + 4096) + 64;
+    r->ablob_cap = (size_t)cap * 8192 + 64;
+    r->vout_cap = (size_t)cap * (size_t)r->fb + 64;
+    r->aout_cap = (size_t)cap * 4 * 8192;                       /* 4 bytes of PCM per chunk byte, chunks of at most 8 KB */
+    r->e = (ra_entry *)calloc(cap, sizeof(ra_entry));
+    r->vblob = (uint8_t *)ra_alloc(r, r->vblob_cap);
+    r->ablob = (uint8_t *)ra_alloc(r, r->ablob_cap);
+    r->vout = (uint8_t *)ra_alloc(r, r->vout_cap);
+    r->aout = (int16_t *)ra_alloc(r, r->aout_cap);
+    r->voffs = (uint64_t *)ra_alloc(r, cap * 8);
+    r->aoffs = (uint64_t *)ra_alloc(r, cap * 8);
+    r->pcm_offs = (uint64_t *)ra_alloc(r, cap * 8);
+    r->vlens = (uint32_t *)ra_alloc(r, cap * 4);
+    r->alens = (uint32_t *)ra_alloc(r, cap * 4);
+    r->vstatus = (int32_t *)ra_alloc(r, cap * 4);
+    if (!r->fp || r->fsize <= 0 || !r->e || !r->vblob || !r->ablob || !r->vout || !r->aout || !r->voffs || !r->aoffs ||
+        !r->pcm_offs || !r->vlens || !r->alens || !r->vstatus) {
+        ra_free(r);
+        return NULL;
+    }
+    r->next = g_ra;
+    g_ra = r;
+    return r;
+}
+
+/* Fill the window with the frames that start at `pos`.  Returns the number of frames (0: none complete there),
+ * -1 when `pos` holds the end marker. */
+static int ra_refill(readahead *r, long pos)
+{
+    unsigned char hd[8];
+    size_t vo = 0, ao = 0;
+    if (ctx() != NULL && (r->vstate == 1 || r->astate == 1)) amvhip_sync(ctx());   /* nothing in flight into the buffers */
+    r->n = r->cur = 0;
+    r->last = -1;
+    r->vstate = r->astate = 0;
+    if (fseek(r->fp, pos, SEEK_SET) != 0) return 0;
+    while (r->n < r->cap_frames) {
+        ra_entry *e = &r->e[r->n];
+        uint32_t vlen, alen, slot;
+        if (fread(hd, 1, 8, r->fp) != 8) break;
+        if (is4(hd, "AMV_") && is4(hd + 4, "END_")) return r->n ? (int)r->n : -1;       /* AMVDec.c:173-190 */
+        if (!is4(hd, "00dc")) break;                                                     /* :171,196-208 */
+        vlen = rd32(hd + 4);
+        if ((long)vlen > r->fsize - pos - 8 || vo + vlen + 16 > r->vblob_cap) break;     /* truncated file / window full */
+        if (fread(r->vblob + vo, 1, vlen, r->fp) != vlen) break;
+        if (fread(hd, 1, 8, r->fp) != 8 || !is4(hd, "01wb")) break;                      /* :213-231 */
+        alen = rd32(hd + 4);
+        slot = alen > 8 ? 8 + round4(alen - 8) : 8;
+        if ((long)alen > r->fsize - pos - 16 - (long)vlen || ao + slot + 16 > r->ablob_cap || slot > 8192) break;
+        if (fread(r->ablob + ao, 1, alen, r->fp) != alen) break;
+        memset(r->ablob + ao + alen, 0, slot - alen);       /* the bytes the reference's 4-byte loop reads past the chunk */
+        e->pos = pos;
+        e->voff = (uint32_t)vo; e->vlen = vlen;
+        e->aoff = (uint32_t)ao; e->alen = alen;
+        vo += round4(vlen);
+        ao += slot;
+        pos += 16 + (long)vlen + (long)alen;
+        r->n++;
+        r->vbytes = vo;
+        r->abytes = ao;
+    }
+    return (int)r->n;
+}
+
 void AmvClose(AMVDecoder *amv)
 {
+    readahead *r, **pp;
     if (amv == NULL) return;                                      /* AMVDec.c:131-148 */
+    for (pp = &g_ra; (r = *pp) != NULL; pp = &r->next)
+        if (r->owner == amv) { *pp = r->next; ra_free(r); break; }
     free(amv->amvfilename);
     free(amv->framebuf.audiobuff);
     free(amv->framebuf.videobuff);
@@ -215,52 +385,53 @@ void AmvClose(AMVDecoder *amv)
     free(amv);
 }
 
-static int read_chunk(FILE *fp, AMVDecoder *amv, const char *cc, unsigned char **buf, unsigned int *len)
+/* the chunk's bytes into memory framebuf owns (the reference frees and mallocs per frame, AMVDec.c:196-231) */
+static int hand_out(unsigned char **buf, unsigned int *len, const unsigned char *src, uint32_t n)
 {
-    unsigned char hd[8];
-    uint32_t n;
-    if (fread(hd, 1, 8, fp) != 8 || !is4(hd, cc)) return -1;
-    n = rd32(hd + 4);
+    unsigned char *p = (unsigned char *)malloc(n ? n : 1);
+    if (p == NULL) return -1;
+    memcpy(p, src, n);
     free(*buf);
-    *buf = (unsigned char *)malloc(n ? n : 1);
-    if (*buf == NULL) return -1;
-    if (fread(*buf, 1, n, fp) != n) return -1;
+    *buf = p;
     *len = n;
-    amv->fileseekpos += 8 + (long)n;
     return 0;
 }
 
 int AmvReadNextFrame(AMVDecoder *amv)
 {
-    FILE *fp;
     FRAMEBUFF *fb;
-    unsigned char cc[8];
-    int rc = -1;
+    readahead *r;
+    const ra_entry *e;
 
     if (amv == NULL) return -1;                                   /* AMVDec.c:157-160 */
     if (!amv->opened || amv->amvfilename == NULL) return -1;
     fb = &amv->framebuf;
-    fp = fopen(amv->amvfilename, "rb");                           /* the reference reopens per frame, :164 */
-    if (fp == NULL) return -1;
-    if (fseek(fp, amv->fileseekpos, SEEK_SET) != 0 || fread(cc, 1, 8, fp) != 8) { fclose(fp); return -1; }
-    if (is4(cc, "AMV_") && is4(cc + 4, "END_")) {                 /* :173-190 end of stream */
-        free(fb->videobuff); fb->videobuff = NULL;
-        free(fb->audiobuff); fb->audiobuff = NULL;
-        fb->videobufflen = fb->audiobufflen = 0;
-        fb->framenum = -1;
-        amv->fileseekpos += 8;
-        fclose(fp);
-        return 0;
+    if ((r = ra_get(amv)) == NULL) return -1;
+    if (!(r->cur < r->n && r->e[r->cur].pos == amv->fileseekpos)) {   /* window used up, or the position was moved */
+        const int got = ra_refill(r, amv->fileseekpos);
+        if (got < 0) {                                            /* :173-190 end of stream */
+            free(fb->videobuff); fb->videobuff = NULL;
+            free(fb->audiobuff); fb->audiobuff = NULL;
+            fb->videobufflen = fb->audiobufflen = 0;
+            fb->framenum = -1;
+            amv->fileseekpos += 8;
+            return 0;
+        }
+        if (got == 0) return -1;                                  /* no complete frame here: nothing changes */
     }
-    fseek(fp, amv->fileseekpos, SEEK_SET);
-    if (read_chunk(fp, amv, "00dc", &fb->videobuff, &fb->videobufflen) == 0 &&   /* :171,196-208 */
-        read_chunk(fp, amv, "01wb", &fb->audiobuff, &fb->audiobufflen) == 0) {   /* :213-231 */
-        fb->framenum++;                                           /* :233-234 */
-        amv->currentframe = (unsigned int)fb->framenum;
-        rc = 0;
+    e = &r->e[r->cur];
+    /* both chunks or neither (a reader that took the video chunk and then failed on the audio chunk would be out of
+     * step with the file) */
+    if (hand_out(&fb->videobuff, &fb->videobufflen, r->vblob + e->voff, e->vlen) != 0) return -1;
+    if (hand_out(&fb->audiobuff, &fb->audiobufflen, r->ablob + e->aoff, e->alen) != 0) {
+        fb->videobufflen = 0;
+        return -1;
     }
-    fclose(fp);
-    return rc;
+    amv->fileseekpos += 16 + (long)e->vlen + (long)e->alen;
+    r->last = (int)r->cur++;
+    fb->framenum++;                                               /* :233-234 */
+    amv->currentframe = (unsigned int)fb->framenum;
+    return 0;
 }
 
 int AmvRewindFrameStart(AMVDecoder *amv)
@@ -271,11 +442,50 @@ int AmvRewindFrameStart(AMVDecoder *amv)
     return 0;
 }
 
+/* the window's frame that framebuf still holds, byte for byte; NULL -> decode the single chunk */
+static readahead *ra_current(AMVDecoder *amv, int video)
+{
+    readahead *r = ra_find(amv);
+    const ra_entry *e;
+    const FRAMEBUFF *fb = &amv->framebuf;
+    if (r == NULL || r->last < 0 || ctx() == NULL) return NULL;
+    if (r->w != amv->amvinfo.dwWidth || r->h != amv->amvinfo.dwHeight) return NULL;
+    e = &r->e[r->last];
+    if (video) return (fb->videobufflen == e->vlen && memcmp(fb->videobuff, r->vblob + e->voff, e->vlen) == 0) ? r : NULL;
+    return (fb->audiobufflen == e->alen && e->alen > 8 && memcmp(fb->audiobuff, r->ablob + e->aoff, e->alen) == 0) ? r : NULL;
+}
+
+/* send the window's video (audio) chunks through the batch ABI, once per window */
+static int ra_decode_window(readahead *r, int video)
+{
+    uint32_t i;
+    int *state = video ? &r->vstate : &r->astate;
+    if (*state != 0) return *state;
+    if (video) {
+        for (i = 0; i < r->n; i++) { r->voffs[i] = r->e[i].voff; r->vlens[i] = r->e[i].vlen; }
+        *state = amvhip_decode_batch_async(ctx(), r->vblob, r->vbytes + 16, r->voffs, r->vlens, r->n, r->w, r->h, 0, r->vout,
+                                           r->vstatus) == AMVHIP_OK ? 1 : -1;
+    } else {
+        uint64_t po = 0;
+        for (i = 0; i < r->n; i++) {
+            const uint32_t slot = r->e[i].alen > 8 ? 8 + round4(r->e[i].alen - 8) : 8;
+            r->aoffs[i] = r->e[i].aoff; r->alens[i] = slot; r->pcm_offs[i] = po;
+            po += 2ull * (slot - 8);
+        }
+        *state = amvhip_adpcm_decode_batch_async(ctx(), r->ablob, r->abytes + 16, r->aoffs, r->alens, r->n, r->aout, po, r->pcm_offs,
+                                                 NULL) == AMVHIP_OK ? 1 : -1;
+    }
+    if (*state == 1 && amvhip_sync(ctx()) != AMVHIP_OK) *state = -1;
+    return *state;
+}
+
 int AmvVideoDecode(AMVDecoder *amv)
 {
     FRAMEBUFF *fb;
     VIDEOBUFF *vb;
+    readahead *r;
     uint64_t full;
+    size_t size;
 
     if (amv == NULL) return -1;                                   /* AMVDec.c:265-268 */
     if (!amv->opened) return -1;
@@ -284,10 +494,16 @@ int AmvVideoDecode(AMVDecoder *amv)
     vb = &amv->videobuf;
     full = amvhip_frame_bytes(amv->amvinfo.dwWidth, amv->amvinfo.dwHeight);
     vb->len = amv->amvinfo.dwHeight * amv->amvinfo.dwWidth * 3;   /* :277 */
+    size = full > vb->len ? (size_t)full : (vb->len ? vb->len : 1);
     free(vb->fbmpdat);
-    vb->fbmpdat = (unsigned char *)malloc(full > vb->len ? full : (vb->len ? vb->len : 1));
+    vb->fbmpdat = (unsigned char *)malloc(size);
     if (vb->fbmpdat == NULL) return -2;                           /* :281-282 */
-    memset(vb->fbmpdat, 0, full > vb->len ? full : vb->len);      /* :283 */
+    if ((r = ra_current(amv, 1)) != NULL && ra_decode_window(r, 1) == 1) {
+        /* the whole frame, padding and undecoded remainder included, comes zeroed from the decoder (:283) */
+        memcpy(vb->fbmpdat, r->vout + (size_t)r->last * (size_t)r->fb, (size_t)full);
+        return r->vstatus[r->last] == 0 ? 0 : -1;                 /* AmvJpeg.c:1531-1538 */
+    }
+    memset(vb->fbmpdat, 0, size);                                 /* :283 */
     if (full > vb->len) {                                         /* room for the padded rows: decode in place */
         unsigned int keep = vb->len;
         int rc;
@@ -304,6 +520,7 @@ int AmvAudioDecode(AMVDecoder *amv)
     FRAMEBUFF *fb;
     AUDIOBUFF *ab;
     ADPCMContext audio;
+    readahead *r;
     int rtn, declen = 0;
 
     if (amv == NULL) return -1;                                   /* AMVDec.c:296-299 */
@@ -312,17 +529,23 @@ int AmvAudioDecode(AMVDecoder *amv)
     if (fb->audiobuff == NULL || fb->audiobufflen == 0) return -1; /* :302-303 */
     if (fb->audiobufflen <= 8) return -1;
     ab = &amv->audiobuf;
-    memset(&audio, 0, sizeof audio);
-    audio.channel = amv->amvinfo.nChannels;
-    audio.status[0].predictor = (short)rd16(fb->audiobuff);       /* :312 */
-    audio.status[0].step_index = fb->audiobuff[2];                /* :313 */
-    audio.status[1] = audio.status[0];                            /* :316-317 */
     ab->len = rd32(fb->audiobuff + 4) * 2;                        /* :319-321 */
     if (ab->len < (fb->audiobufflen - 8) * 4) ab->len = (fb->audiobufflen - 8) * 4;  /* :322-323 */
     free(ab->audiodata);
     ab->audiodata = (short *)malloc((size_t)ab->len + 16);        /* :326 */
     if (ab->audiodata == NULL) return -2;
     memset(ab->audiodata, 0, ab->len);                            /* :329 */
+    if (amv->amvinfo.nChannels != 2 && (r = ra_current(amv, 0)) != NULL && ra_decode_window(r, 0) == 1) {
+        const uint32_t n4 = round4(fb->audiobufflen - 8);         /* what AdpcmImaDecodeFrame consumes, AdpcmIma.c:225-241 */
+        memcpy(ab->audiodata, r->aout + r->pcm_offs[r->last], 4u * (size_t)n4);
+        ab->len = 4u * n4;                                        /* :333-337 */
+        return 0;
+    }
+    memset(&audio, 0, sizeof audio);
+    audio.channel = amv->amvinfo.nChannels;
+    audio.status[0].predictor = (short)rd16(fb->audiobuff);       /* :312 */
+    audio.status[0].step_index = fb->audiobuff[2];                /* :313 */
+    audio.status[1] = audio.status[0];                            /* :316-317 */
     rtn = AdpcmImaDecodeFrame(&audio, ab->audiodata, &declen, fb->audiobuff + 8, (int)fb->audiobufflen - 8);
     if (rtn > 0) {                                                /* :333-337 */
         ab->len = (unsigned int)declen;

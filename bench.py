@@ -19,6 +19,8 @@ spot-checked again here before anything is timed.
   --workload coresident  WxH (320x240) video decode on one HIP stream with IMA-ADPCM decode +
                          encode of the frames' audio chunks on a second stream               configs[4]
   --workload adpcm       IMA-ADPCM chunks -> PCM -> chunks, audio alone
+  --workload amvlib      the drop-in surface, one frame per call: AmvReadNextFrame / AmvVideoDecode /
+                         AmvAudioDecode from a C host over AMV files (PCIe inclusive; not the headline)
 
 Extra objects on the JSON line:
   roofline     the dominant kernel against the HBM roof: algorithmic bytes of the path per launch
@@ -494,12 +496,85 @@ def run_adpcm(E, args, with_video=False):
     return result
 
 
+# ---------------------------------------------------------------------------------------------
+def run_amvlib(E, args):
+    """The drop-in surface itself: the player loop of the reference (AMVDecoderDlg.cpp FillBuffer / AmvLibTest.cpp) --
+    AmvReadNextFrame, AmvVideoDecode, AmvAudioDecode, one frame per call -- run by a plain C host
+    (tests/c/amvlib_host.c, compiled here with gcc against include/amvhip.h) over the reference's own clip and over a
+    muxed synthetic 160x120 file; beside it the CPU oracle decoding the same chunks on one thread."""
+    import subprocess
+    import tempfile
+    pkg, ctx, dev = E.pkg, E.ctx, E.dev
+    orc = entry.load_oracle()
+    lib = pkg.load_library()
+    tmp = tempfile.mkdtemp(prefix="amvlib_bench_")
+    exe = os.path.join(tmp, "amvlib_host")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "amvlib_host.c"),
+                    "-L", libdir, "-l:" + os.path.basename(pkg.LIB_PATH), "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    # the synthetic file: device-made 160x120 chunks + the audio that travels with them, through the library's muxer
+    w, h, n, spf = 160, 120, args.frames or 4000, SAMPLES_PER_FRAME
+    d_blob, cap, d_offs, d_lens, _ = make_video_stream(E, 0, n, w, h)
+    A = make_audio(E, 0, n)
+    d_pcm, d_pcm_offs, d_nsamp, d_chunks, d_aoffs, d_alens, clen = A
+    ctx.adpcm_encode_batch_dev(d_pcm, d_pcm_offs, d_nsamp, n, None, d_chunks, d_aoffs, E.stream)
+    torch.cuda.synchronize()
+    blob, offs, lens, ach = d_blob.cpu().numpy(), d_offs.cpu().numpy(), d_lens.cpu().numpy(), d_chunks.cpu().numpy()
+    synth = os.path.join(tmp, "synth160.amv")
+    m = lib.amvhip_mux_open(synth.encode(), w, h, 16, 22050, 200000, 64000)
+    for i in range(n):
+        v = blob[int(offs[i]):int(offs[i]) + int(lens[i])]
+        a = ach[i * clen:(i + 1) * clen]
+        assert lib.amvhip_mux_write_frame(m, v.ctypes.data, v.size, a.ctypes.data, a.size) == 0
+    assert lib.amvhip_mux_close(m) == 0
+
+    def play(path, passes, readahead=None):
+        env = dict(os.environ)
+        if readahead is not None:
+            env["AMVHIP_READAHEAD"] = str(readahead)
+        out = subprocess.run([exe, path, "--bench", str(passes)], check=True, capture_output=True, text=True, env=env).stdout
+        f = dict(line.split(": ", 1) for line in out.strip().splitlines())
+        return int(f["bench frames"]) / float(f["bench seconds"])
+
+    amv1 = os.path.join(ROOT, "tests", "golden", "AMV1.amv")
+    rates = {"AMV1.amv 128x96 (252 frames x 40 passes)": play(amv1, 40),
+             "synthetic 160x120 (%d frames x 4 passes)" % n: play(synth, 4),
+             "synthetic 160x120, AMVHIP_READAHEAD=1 (one frame per GPU round trip)": play(synth, 1, readahead=1) if n <= 4000 else None}
+    # gate: the file decodes to the oracle's frames through the same surface (first frames; the tests cover the rest)
+    amv = lib.AmvOpen(synth.encode())
+    for i in range(3):
+        assert lib.AmvReadNextFrame(amv) == 0 and lib.AmvVideoDecode(amv) == 0
+        got = np.frombuffer(__import__("ctypes").string_at(amv.contents.videobuf.fbmpdat, w * h * 3), np.uint8)
+        ch = blob[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes()
+        if not (got == orc.decode_frame(ch, w, h)[0].ravel()).all():
+            raise SystemExit("amvlib surface differs from the oracle at frame %d" % i)
+    lib.AmvClose(amv)
+
+    value = rates["synthetic 160x120 (%d frames x 4 passes)" % n]
+    result = {"metric": "AMV frames/sec through the amvlib call surface (AmvReadNextFrame + AmvVideoDecode + AmvAudioDecode, "
+                        "160x120, bit-exact)", "value": value, "unit": "frames/s", "n_gpus": 1, "steps": 4, "warmup": 1,
+              "ms_per_step": n / value * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+              "data": "synthetic", "config": {"workload": "amvlib player loop over a muxed %d-frame 160x120 AMV file, one frame per "
+                                                          "call, host buffers (PCIe inclusive), read-ahead windows behind the calls" % n,
+                                              "frames_per_s": rates}}
+    m = min(n, 1024)
+    t = time.perf_counter()
+    orc.decode_batch(blob, offs[:m].astype(np.uint64), lens[:m].astype(np.uint32), w, h, 0, threads=1)
+    for i in range(m):
+        orc.adpcm_decode_chunk(ach[i * clen:(i + 1) * clen])
+    t1 = time.perf_counter() - t
+    result["cpu_baseline"] = {"value": m / t1, "unit": "frames/s", "cores": 1, "kind": "port",
+                              "sample": "first %d frames of the same file: CPU oracle video + audio decode, one thread (the reference's "
+                                        "own loop is single-threaded)" % m}
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("decode", "encode", "coresident", "adpcm"), default="decode")
+    ap.add_argument("--workload", choices=("decode", "encode", "coresident", "adpcm", "amvlib"), default="decode")
     ap.add_argument("--frames", type=int, default=None, help="frames (audio chunks) per GPU per step; default per workload")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -539,6 +614,8 @@ def main():
         result = run_encode(E, args)
     elif args.workload == "coresident":
         result = run_adpcm(E, args, with_video=True)
+    elif args.workload == "amvlib":
+        result = run_amvlib(E, args)
     else:
         result = run_adpcm(E, args, with_video=False)
     if E.rank == 0:

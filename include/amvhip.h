@@ -215,6 +215,21 @@ int amvhip_decode_batch(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_byte
                         uint32_t width, uint32_t height, uint32_t flags,
                         uint8_t *out, int32_t *status);
 
+/*
+ * Asynchronous host-buffer forms, for a host that wants the GPU working while it does something else (the
+ * read-ahead behind AmvReadNextFrame uses them): copies and kernels are queued on a stream the context owns and
+ * the call returns; amvhip_sync waits for everything queued so far.  blob/offs/lens must stay untouched, and
+ * out/status unread, until then.  Page-locked buffers (amvhip_host_alloc) make the copies truly asynchronous;
+ * pageable ones work but block.  Every host-buffer entry point of one context runs on that one stream, in order.
+ */
+int amvhip_decode_batch_async(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_bytes,
+                              const uint64_t *offs, const uint32_t *lens, uint32_t n,
+                              uint32_t width, uint32_t height, uint32_t flags,
+                              uint8_t *out, int32_t *status);
+int amvhip_sync(amvhip_ctx *ctx);
+int amvhip_host_alloc(amvhip_ctx *ctx, void **p, size_t bytes);
+void amvhip_host_free(amvhip_ctx *ctx, void *p);
+
 /* Entropy-stage kernel choice.  AUTO: several lanes per frame (self-synchronising parallel Huffman
  * decode); frames whose chunk does not fit its workspace window fall to the one-lane-per-frame kernel.
  * SERIAL: always the one-lane-per-frame kernel.  Results are identical; the switch exists so the
@@ -307,6 +322,10 @@ int amvhip_adpcm_decode_batch(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blo
                               const uint64_t *offs, const uint32_t *lens, uint32_t n,
                               int16_t *pcm, uint64_t pcm_samples, const uint64_t *pcm_offs,
                               int32_t *final_state);
+int amvhip_adpcm_decode_batch_async(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_bytes,
+                                    const uint64_t *offs, const uint32_t *lens, uint32_t n,
+                                    int16_t *pcm, uint64_t pcm_samples, const uint64_t *pcm_offs,
+                                    int32_t *final_state);   /* see amvhip_decode_batch_async */
 int amvhip_adpcm_encode_batch(amvhip_ctx *ctx, const int16_t *pcm, uint64_t pcm_samples,
                               const uint64_t *pcm_offs, const uint32_t *nsamp, uint32_t n,
                               const int32_t *step_in, uint8_t *blob, uint64_t blob_bytes,

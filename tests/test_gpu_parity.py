@@ -954,3 +954,62 @@ def test_avcodec_plugin_through_the_struct(ctx, pkg, orc, amv1, tmp_path):
             sizes.add(npairs)
         assert len(sizes) >= 2          # the odd-sample carry / the 1 Hz resync really changed chunk sizes
     assert pos == len(raw)
+
+
+def test_amvlib_readahead_semantics(ctx, pkg, orc, amv1, tmp_path):
+    """the read-ahead window behind AmvReadNextFrame changes nothing a caller can see: every frame and every PCM
+    chunk of the clip (window boundaries included) equals the oracle; rewinding mid-window, decoding a frame twice,
+    editing framebuf (falls back to the single-chunk path), a file cut in the middle of a chunk"""
+    import os
+    lib = pkg.load_library()
+    want_v = [orc.decode_frame(c, 128, 96)[0].ravel() for c in amv1["video"]]
+
+    def frame(d):
+        return np.frombuffer(ctypes.string_at(d.videobuf.fbmpdat, d.videobuf.len), np.uint8)
+
+    for window in ("7", "256", "1"):
+        os.environ["AMVHIP_READAHEAD"] = window
+        try:
+            amv = lib.AmvOpen(amv1["path"].encode())
+            d = amv.contents
+            for k in range(252):
+                assert lib.AmvReadNextFrame(amv) == 0 and d.framebuf.framenum == k + 1
+                assert ctypes.string_at(d.framebuf.videobuff, d.framebuf.videobufflen) == amv1["video"][k]
+                assert ctypes.string_at(d.framebuf.audiobuff, d.framebuf.audiobufflen) == amv1["audio"][k]
+                assert lib.AmvVideoDecode(amv) == 0 and (frame(d) == want_v[k]).all(), (window, k)
+                assert lib.AmvAudioDecode(amv) == 0
+                a = amv1["audio"][k]
+                n4 = (len(a) - 8 + 3) & ~3
+                assert d.audiobuf.len == 4 * n4
+                pcm = np.frombuffer(ctypes.string_at(d.audiobuf.audiodata, d.audiobuf.len), np.int16)
+                assert (pcm == orc.adpcm_decode_chunk(a + b"\0" * (n4 - (len(a) - 8)))[0]).all(), (window, k)
+                if k == 100:   # again, and with the chunk edited in place: no stale result
+                    assert lib.AmvVideoDecode(amv) == 0 and (frame(d) == want_v[k]).all()
+                    other = amv1["video"][5]
+                    ctypes.memmove(d.framebuf.videobuff, other, min(len(other), d.framebuf.videobufflen))
+                    keep = d.framebuf.videobufflen
+                    d.framebuf.videobufflen = min(len(other), keep)
+                    rc = lib.AmvVideoDecode(amv)
+                    ref, st, _ = orc.decode_frame(other[: d.framebuf.videobufflen], 128, 96)
+                    assert (rc == 0) == (st == 0) and (frame(d) == ref.ravel()).all()
+                    d.framebuf.videobufflen = keep
+            assert lib.AmvReadNextFrame(amv) == 0 and d.framebuf.framenum == -1          # AMV_END_
+            assert lib.AmvRewindFrameStart(amv) == 0
+            for k in range(10):
+                assert lib.AmvReadNextFrame(amv) == 0 and lib.AmvVideoDecode(amv) == 0 and (frame(d) == want_v[k]).all()
+            assert lib.AmvRewindFrameStart(amv) == 0                                       # mid-window
+            assert lib.AmvReadNextFrame(amv) == 0 and lib.AmvVideoDecode(amv) == 0 and (frame(d) == want_v[0]).all()
+            lib.AmvClose(amv)
+        finally:
+            os.environ.pop("AMVHIP_READAHEAD", None)
+    # truncated file: frames before the cut decode, the cut frame fails without moving the position
+    data = amv1["data"]
+    cut = data.find(amv1["video"][20]) + 100
+    p = str(tmp_path / "cut.amv")
+    open(p, "wb").write(data[:cut])
+    amv = lib.AmvOpen(p.encode())
+    for k in range(20):
+        assert lib.AmvReadNextFrame(amv) == 0 and lib.AmvVideoDecode(amv) == 0 and (frame(amv.contents) == want_v[k]).all()
+    pos = amv.contents.fileseekpos
+    assert lib.AmvReadNextFrame(amv) == -1 and amv.contents.fileseekpos == pos
+    lib.AmvClose(amv)
