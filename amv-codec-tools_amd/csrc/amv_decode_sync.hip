@@ -54,9 +54,18 @@ namespace amv {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerGroup = 10;        // independent waves per workgroup (they share only the tables)
-constexpr int kGroupsPerCu = 2;           // 20 waves per CU: what the kernel's VGPR count allows (5 per SIMD)
+// independent waves per workgroup (they share only the tables) and workgroups per CU.  Dense form: 10 x 2 = 20 waves
+// per CU, what the kernel's VGPR count allows (5 per SIMD).  Records form: every wave also stages its records in LDS
+// (8 KB per wave with the stream window), so one workgroup of 16 waves per CU (137 KB of the 160 KB).
+constexpr int waves_per_group(bool rec) { return rec ? 16 : 10; }
+constexpr int groups_per_cu(bool rec) { return rec ? 1 : 2; }
 constexpr uint32_t kRingWords = 16;       // LDS words per lane: the window of its stream a lane works in
+// Records are staged per lane in LDS and leave as whole, aligned 32-byte pieces (a 4-byte store per record from 64
+// lanes into 64 different lines was written back to HBM as partial lines several times over: 9.8 GB of writes per
+// 160 000 frames for 0.7 GB of records, and with one or two lanes per frame those stores were what the walk waited on).
+constexpr uint32_t kStageSlots = 16;      // records a lane can hold
+constexpr uint32_t kFlush = 8;            // records per store burst: 32 bytes
+constexpr uint32_t kDummyRecord = 0xfffffu;   // block 16383 (never a real block: frames of >= 16384 blocks take the serial kernel), index 63
 constexpr uint32_t kNever = 0xffffffffu;
 constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + 4u * kLut2PagesPerTable * (1u << kLut2Bits) * 2u;
 
@@ -194,6 +203,8 @@ struct Stream {
 // A walk may run kStride symbols between services: a symbol is at most 27 bits (16 code + 11 magnitude),
 // so 10 of them move the read index by at most 9 words, and a service leaves every lane >= 9 words.
 constexpr int kStride = 10;
+// the writing walk runs 8 symbols between services: at most 8 new records then join at most 7 staged ones
+constexpr int kStrideWrite = 8;
 
 __device__ __forceinline__ uint32_t ring_word(const Stream& s, uint32_t x) {
     return s.ring[(x & (kRingWords - 1u)) * kWave];
@@ -332,11 +343,28 @@ struct Sink {
 };
 
 // The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state.
+// stage: this lane's 16-byte granule of the wave's staging area; record slot q of lane l lives at dword
+// (q / 4) * 256 + l * 4 + q % 4, so that four consecutive records of a lane leave LDS as one 16-byte read
+__device__ __forceinline__ void stage_put(uint32_t* stage, uint32_t pos, uint32_t word) {
+    stage[((pos & (kStageSlots - 1u)) >> 2) * (kWave * 4u) + (pos & 3u)] = word;
+}
+
+// records [from, from + 8) of this lane -> rec (from is a multiple of 8; rec + from is 32-byte aligned)
+__device__ __forceinline__ void stage_flush(const uint32_t* stage, uint32_t* __restrict__ rec, uint32_t from, uint32_t rec_cap) {
+    const uint32_t g = (from & (kStageSlots - 1u)) >> 2;
+    const uint4 a = *reinterpret_cast<const uint4*>(stage + g * (kWave * 4u));
+    const uint4 b = *reinterpret_cast<const uint4*>(stage + (g + 1u) * (kWave * 4u));
+    if (from + kFlush <= rec_cap) {   // never past the frame's record space; an overfull frame is redone densely
+        *reinterpret_cast<uint4*>(rec + from) = a;
+        *reinterpret_cast<uint4*>(rec + from + 4u) = b;
+    }
+}
+
 template <bool kRec>
 __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __restrict__ m1,
                                                   const uint16_t* __restrict__ m2, State s, uint32_t limit,
                                                   uint32_t blk, uint32_t blocks_per_frame, const Sink& out,
-                                                  uint32_t recpos, uint32_t rec_cap) {
+                                                  uint32_t recpos, uint32_t rec_cap, uint32_t* stage) {
     WriteResult r{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, recpos, (int)blk - (s.k ? 0 : 1)};
     int16_t* __restrict__ coef = out.coef;
     uint32_t p = s.p, k = s.k, k6 = s.k6;
@@ -353,9 +381,14 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
     // one symbol per step; everything but the two stores is straight-line selects, so that lanes in
     // different states (DC / AC / end of block) share every instruction
     alive = p < limit;
+    uint32_t flushed = recpos;   // records before this one have left for memory (a multiple of kFlush)
     while (__ballot(alive) != 0ull) {
     if (alive) stream_service(w, widx);
-    for (int it = 0; it < kStride; ++it) {
+    if (kRec && r.recpos - flushed >= kFlush) {
+        stage_flush(stage, out.rec, flushed, rec_cap);
+        flushed += kFlush;
+    }
+    for (int it = 0; it < (kRec ? kStrideWrite : kStride); ++it) {
       if (alive) {
         const uint32_t cand = ring_word(w, widx);
         const uint32_t v = (uint32_t)(acc >> 32);
@@ -398,8 +431,8 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
         }
         const bool emit = good && !isdc && !iseob && size != 0u;
         if (emit) {
-            if (kRec) {   // never past the frame's record space; an overfull frame is redone densely
-                if (r.recpos < rec_cap) out.rec[r.recpos] = idx | (blk << 6) | ((uint32_t)val << 20);
+            if (kRec) {
+                stage_put(stage, r.recpos, idx | (blk << 6) | ((uint32_t)val << 20));
             } else {
                 coef[(uint64_t)blk * 64u + idx] = (int16_t)val;
             }
@@ -421,6 +454,14 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
         alive = alive && p < limit;
       }
     }
+    }
+    if (kRec) {   // what is still staged leaves padded to a whole piece with records no block owns
+        const uint32_t end = (r.recpos + kFlush - 1u) & ~(kFlush - 1u);
+        for (uint32_t q = r.recpos; q < end; ++q) stage_put(stage, q, kDummyRecord);
+        while (flushed < end) {
+            stage_flush(stage, out.rec, flushed, rec_cap);
+            flushed += kFlush;
+        }
     }
     r.sum[0] = s0; r.sum[1] = s1; r.sum[2] = s2;
     return r;
@@ -444,10 +485,10 @@ struct SyncOut {
     uint32_t* retry_count;
 };
 
-// dynamic LDS: [ m1 4 KB | m2 5 KB | per wave: ring of kRingWords words per lane ]
+// dynamic LDS: [ m1 4 KB | m2 5 KB | per wave: ring of kRingWords words per lane | records form, per wave: staged records ]
 // With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).
 template <int L, bool kRec>
-__global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel(
+__global__ __launch_bounds__(kWave* waves_per_group(kRec)) void amv_huffman_sync_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
     uint32_t blocks_per_frame, uint32_t cap_words,
@@ -466,7 +507,9 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
+    constexpr uint32_t kWaves = (uint32_t)waves_per_group(kRec);
     uint32_t* ring = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + wave * (kRingWords * kWave) + lane;
+    uint32_t* stage = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + kWaves * (kRingWords * kWave) + wave * (kStageSlots * kWave) + lane * 4u;
     if (list) n = *list_count;
     const uint32_t ntasks = (n + kFrames - 1) / kFrames;
     // Tasks (kFrames frames each) are handed out through a counter: a wave that finishes early -- the
@@ -533,14 +576,16 @@ __global__ __launch_bounds__(kWave* kWavesPerGroup) void amv_huffman_sync_kernel
     uint32_t all_blocks, all_recs = 0;
     const uint32_t blk0 = seg_excl_sum<L>(my_blocks, sub, all_blocks);
     uint32_t rec0 = 0;
-    if (kRec) rec0 = seg_excl_sum<L>(my_recs, sub, all_recs);   // (the last lane has not walked: its count is 0, it is last)
+    // every lane's records start on a 32-byte piece (the gap behind its last record is filled with dummies);
+    // (the last lane has not walked: its count is 0, it is last)
+    if (kRec) rec0 = seg_excl_sum<L>((my_recs + kFlush - 1u) & ~(kFlush - 1u), sub, all_recs);
 
     // ---- 4. the strict, writing pass.  Lanes left of the frame's end (or first error) are exact;
     // whatever a lane to the right of it does is ignored below.
     __builtin_amdgcn_s_waitcnt(0);   // dense form: the zeroing stores have landed before the sparse ones go out
     WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, 0u, -1};
     if (live && blk0 < blocks_per_frame)
-        wr = walk_write<kRec>(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, sink, rec0, out.cap_rec);
+        wr = walk_write<kRec>(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, sink, rec0, out.cap_rec, stage);
     if (timing) tc[4] = clock64();
     const uint64_t stop_mask = __ballot(wr.done || wr.err != 0u) & seg;
     uint32_t st = 0, good_blocks = blocks_per_frame, rec_total = 0;
@@ -606,8 +651,9 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
                  const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
                  uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
-    constexpr uint32_t kPerGroup = (uint32_t)(kWave / L) * kWavesPerGroup;
-    constexpr uint32_t kLds = kTableBytes + kWavesPerGroup * kRingWords * kWave * 4u;
+    constexpr uint32_t kWaves = (uint32_t)waves_per_group(kRec);
+    constexpr uint32_t kPerGroup = (uint32_t)(kWave / L) * kWaves;
+    constexpr uint32_t kLds = kTableBytes + kWaves * kRingWords * kWave * 4u + (kRec ? kWaves * kStageSlots * kWave * 4u : 0u);
     static bool raised = false;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L, kRec>),
@@ -616,8 +662,8 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
     }
     // enough workgroups to fill the chip, never more than there are tasks (the rest come from the queue)
     uint32_t grid = (n + kPerGroup - 1) / kPerGroup;
-    if (grid > cus * kGroupsPerCu) grid = cus * kGroupsPerCu;
-    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * kWavesPerGroup), kLds, s, ws, ws_bytes, n,
+    if (grid > cus * (uint32_t)groups_per_cu(kRec)) grid = cus * (uint32_t)groups_per_cu(kRec);
+    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * kWaves), kLds, s, ws, ws_bytes, n,
                        list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
 }
 
@@ -631,7 +677,7 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
 // it at ~10 waves per CU (10 000 frames of 160x120: 16; 2 000 of 320x240: 64).  `wanted` (8, 16, 32 or
 // 64) overrides.
 int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
-    if (wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
+    if (wanted == 1 || wanted == 2 || wanted == 4 || wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
     int full = 8;                                  // chip full: a share of ~4 000 bits, i.e. ~4 096 pixels
     while (full < 64 && (uint64_t)full * 2u * 4096u <= pixels) full *= 2;
     const uint64_t waves = (uint64_t)cus * 10u;
@@ -662,6 +708,9 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
             case 64: launch_sync<64, true>(AMV_SYNC_ARGS); break;
             case 32: launch_sync<32, true>(AMV_SYNC_ARGS); break;
             case 8: launch_sync<8, true>(AMV_SYNC_ARGS); break;
+            case 4: launch_sync<4, true>(AMV_SYNC_ARGS); break;
+            case 2: launch_sync<2, true>(AMV_SYNC_ARGS); break;
+            case 1: launch_sync<1, true>(AMV_SYNC_ARGS); break;
             default: launch_sync<16, true>(AMV_SYNC_ARGS); break;
         }
     } else {
@@ -669,6 +718,9 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
             case 64: launch_sync<64, false>(AMV_SYNC_ARGS); break;
             case 32: launch_sync<32, false>(AMV_SYNC_ARGS); break;
             case 8: launch_sync<8, false>(AMV_SYNC_ARGS); break;
+            case 4: launch_sync<4, false>(AMV_SYNC_ARGS); break;
+            case 2: launch_sync<2, false>(AMV_SYNC_ARGS); break;
+            case 1: launch_sync<1, false>(AMV_SYNC_ARGS); break;
             default: launch_sync<16, false>(AMV_SYNC_ARGS); break;
         }
     }

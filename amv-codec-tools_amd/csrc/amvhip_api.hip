@@ -224,7 +224,7 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
     if (const char* e = getenv("AMVHIP_DENSE")) c->dense_intermediate = atoi(e) != 0;
     if (const char* e = getenv("AMVHIP_SYNC_LANES")) {   // tuning knob: lanes per frame of the entropy kernel
         const int v = atoi(e);
-        if (v == 8 || v == 16 || v == 32 || v == 64) c->sync_lanes = v;
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->sync_lanes = v;
     }
     if (hipMalloc((void**)&c->d_dec, sizeof dec) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
     if (hipMalloc((void**)&c->d_enc, sizeof enc) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
