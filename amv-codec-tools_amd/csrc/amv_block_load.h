@@ -2,37 +2,51 @@
 //
 // A wave owns an MCU-row segment of `cnt` MCUs (<= 10, i.e. <= 60 blocks).  Lane b ends up with block b's 64
 // coefficients (scan order, int16 pairs in 32 dwords): from its dense 128-byte line, or -- records form -- after
-// the wave has scattered the segment's (block, index, value) records and DC values into a zeroed LDS image of the
-// blocks (16-byte granules XOR-swizzled by block so that the per-lane 128-byte reads do not collide on banks).
+// the wave has scattered the segment's (block, index, value) records into a zeroed LDS image of the blocks (16-byte
+// granules XOR-swizzled by block so that the per-lane 128-byte reads do not collide on banks) and added the DC base
+// of the entropy lane that decoded the block (SyncSinks::lane_tab).
 #pragma once
 #include "amv_kernels.h"
 
 namespace amv {
 
 // s_img: >= cnt * 6 * 128 bytes of LDS, 16-byte aligned; the caller may reuse it after a __syncthreads().
+// segidx: this segment's number in the frame (mcu_row * segments_per_row + segment).
 // Returns true when this lane holds a block (lane < cnt * 6).
-__device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_t f, const FrameGeom& g, uint32_t mcu0,
-                                                    uint32_t cnt, uint32_t ok, uint32_t lane, uint8_t* s_img,
-                                                    uint32_t (&c)[32]) {
+__device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_t f, const FrameGeom& g, uint32_t segidx,
+                                                    uint32_t nsegs, uint32_t mcu0, uint32_t cnt, uint32_t ok, uint32_t lane,
+                                                    uint8_t* s_img, uint32_t (&c)[32]) {
     constexpr uint32_t kWave = 64;
     const uint32_t nb = cnt * 6u;
     const bool records = in.rec != nullptr && in.rec_count[f] != 0xffffffffu;
+    int dc_base = 0;
     if (records) {   // records -> dense image of the segment's blocks in LDS
         uint4* img16 = reinterpret_cast<uint4*>(s_img);
         for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
-        const uint32_t* ms = in.mcu_start + (uint64_t)f * (g.mcus + 1u);
-        const uint32_t r0 = ms[mcu0], r1 = ms[mcu0 + cnt_ok];
+        const uint32_t* ss = in.seg_start + (uint64_t)f * (nsegs + 1u) + segidx;
+        const uint32_t r0 = ss[0], r1 = cnt_ok ? ss[1] : r0;
         const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec;
         int16_t* img = reinterpret_cast<int16_t*>(s_img);
+        const uint32_t b0 = (mcu0 * 6u) & 63u;
         for (uint32_t r = r0 + lane; r < r1; r += kWave) {
             const uint32_t w = rec[r];
-            const uint32_t b = ((w >> 6) & 0x3fffu) - mcu0 * 6u, k = w & 63u;
-            if (b < cnt_ok * 6u) img[b * 64u + ((((k >> 3) ^ b) & 7u) << 3) + (k & 7u)] = (int16_t)((int)w >> 20);
+            const uint32_t b = (((w >> 6) & 63u) - b0) & 63u, k = w & 63u;   // the segment's <= 60 blocks are consecutive
+            if (!(w & 0x8000u) && b < cnt_ok * 6u) img[b * 64u + ((((k >> 3) ^ b) & 7u) << 3) + (k & 7u)] = (int16_t)((int)w >> 16);
         }
-        if (lane < cnt_ok * 6u)
-            img[lane * 64u + ((lane & 7u) << 3)] = in.dcv[(uint64_t)f * g.blocks + mcu0 * 6u + lane];   // k = 0: granule 0 ^ b
+        // a DC record counts from its lane's first block: the base of the lane that decoded this block's DC
+        if (in.lanes > 1u) {
+            const uint32_t babs = mcu0 * 6u + lane, k6 = lane % 6u;
+            const uint4 ent = lane < in.lanes ? reinterpret_cast<const uint4*>(in.lane_tab)[(uint64_t)f * in.lanes + lane]
+                                              : make_uint4(0xffffffffu, 0u, 0u, 0u);
+            for (uint32_t l = 1; l < in.lanes; ++l) {   // lane 0 starts the frame: base 0
+                const uint32_t first = __builtin_amdgcn_readlane(ent.x, l);
+                const int by = (int)__builtin_amdgcn_readlane(ent.y, l), bu = (int)__builtin_amdgcn_readlane(ent.z, l),
+                          bv = (int)__builtin_amdgcn_readlane(ent.w, l);
+                if (babs >= first) dc_base = k6 < 4u ? by : (k6 == 4u ? bu : bv);
+            }
+        }
         __syncthreads();
     }
     if (lane >= nb) return false;
@@ -43,6 +57,7 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
             const uint4 q = src[(uint32_t)i ^ (lane & 7u)];
             c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
         }
+        c[0] = (c[0] & 0xffff0000u) | ((c[0] + (uint32_t)dc_base) & 0xffffu);   // int16 arithmetic, as the predictors wrap
     } else {
         const uint4* src = reinterpret_cast<const uint4*>(in.coef + (((uint64_t)f * g.mcus + mcu0) * 6u + lane) * 64u);
 #pragma unroll

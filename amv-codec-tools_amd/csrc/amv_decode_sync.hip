@@ -65,7 +65,7 @@ constexpr uint32_t kRingWords = 16;       // LDS words per lane: the window of i
 // 160 000 frames for 0.7 GB of records, and with one or two lanes per frame those stores were what the walk waited on).
 constexpr uint32_t kStageSlots = 16;      // records a lane can hold
 constexpr uint32_t kFlush = 8;            // records per store burst: 32 bytes
-constexpr uint32_t kDummyRecord = 0xfffffu;   // block 16383 (never a real block: frames of >= 16384 blocks take the serial kernel), index 63
+constexpr uint32_t kDummyRecord = 0x8000u;    // bit 15: a filler no block owns
 constexpr uint32_t kNever = 0xffffffffu;
 constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + 4u * kLut2PagesPerTable * (1u << kLut2Bits) * 2u;
 
@@ -297,7 +297,7 @@ __device__ __forceinline__ uint32_t walk_skip(Stream& w, const uint16_t* __restr
                 const uint32_t e = lookup(m1, m2, tab, (uint32_t)(acc >> 32));
                 const uint32_t used = max(e & 31u, 1u);        // nonsense under a guessed start: slip one bit
                 const uint32_t kn = k + ((e >> 5) & 63u);
-                nrec += (k != 0u && (e & 0x7800u) != 0u) ? 1u : 0u;   // an AC symbol that carries a value
+                nrec += (k == 0u || (e & 0x7800u) != 0u) ? 1u : 0u;   // a DC symbol, or an AC symbol that carries a value
                 acc <<= used;
                 nb -= (int)used;
                 p += used;
@@ -329,18 +329,27 @@ struct WriteResult {
     uint32_t dc_count;
     int sum[3];          // the lane's DC differences added up per component (Y, Cb, Cr)
     uint32_t recpos;     // records mode: next free record when the walk ended
-    int last_dc;         // last block whose DC symbol is decoded (by this lane or one to its left)
+    uint32_t seg_next;   // records mode: index of the next MCU-row segment whose start this path has not seen yet
 };
 
 // Where the strict pass puts its output.  Dense: the frame's coefficient lines (zeroed before).
-// Records: one 32-bit word per non-zero AC coefficient, in stream order -- bits 0-5 index in block,
-// bits 6-19 block, bits 20-31 value -- plus a DC array and the record index at which every MCU starts.
+// Records: one 32-bit word per DC coefficient and per non-zero AC coefficient, in stream order -- bits 0-5 index
+// in block (0 = DC), bits 6-11 block modulo 64 (a reader works on <= 60 consecutive blocks), bit 15 "no block owns
+// this record" (filler), bits 16-31 value; a DC value is the sum of the DC differences from the lane's first block
+// on, the reader adds the lane's base (lane table) -- plus the record index at which every MCU-row segment starts.
 struct Sink {
     int16_t* coef;        // dense
     uint32_t* rec;        // records
-    int16_t* dcv;
-    uint32_t* mcu_start;
+    uint32_t* seg_start;
 };
+
+// The MCU-row segments amv_reconstruct_kernel works in: kSegMcus MCUs, the last one of a row shorter.
+struct SegGeom {
+    uint32_t mcu_cols;    // MCUs per row
+    uint32_t per_row;     // segments per row
+    uint32_t count;       // segments per frame
+};
+constexpr uint32_t kSegMcus = 10;   // = amv_reconstruct.hip's
 
 // The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state.
 // stage: this lane's 16-byte granule of the wave's staging area; record slot q of lane l lives at dword
@@ -364,8 +373,19 @@ template <bool kRec>
 __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __restrict__ m1,
                                                   const uint16_t* __restrict__ m2, State s, uint32_t limit,
                                                   uint32_t blk, uint32_t blocks_per_frame, const Sink& out,
-                                                  uint32_t recpos, uint32_t rec_cap, uint32_t* stage) {
-    WriteResult r{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, recpos, (int)blk - (s.k ? 0 : 1)};
+                                                  uint32_t recpos, uint32_t rec_cap, uint32_t* stage, const SegGeom& sg) {
+    WriteResult r{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, recpos, 0u};
+    // the first segment start this lane can meet: the first MCU at or after its first DC block
+    uint32_t seg_col = 0, seg_blk = 0;   // that segment's place in its row, and its first block
+    if (kRec) {
+        const uint32_t m_first = (blk + (s.k ? 1u : 0u) + 5u) / 6u;
+        uint32_t row = m_first / sg.mcu_cols;
+        const uint32_t col = m_first - row * sg.mcu_cols;
+        seg_col = (col + kSegMcus - 1u) / kSegMcus;
+        if (seg_col >= sg.per_row) { ++row; seg_col = 0u; }
+        r.seg_next = row * sg.per_row + seg_col;
+        seg_blk = (row * sg.mcu_cols + seg_col * kSegMcus) * 6u;
+    }
     int16_t* __restrict__ coef = out.coef;
     uint32_t p = s.p, k = s.k, k6 = s.k6;
     uint32_t widx = p >> 5;
@@ -414,25 +434,32 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
         nextw = need ? cand : nextw;
         widx += need ? 1u : 0u;
         const bool good = !bad && !over;
+        int dcval = 0;
         if (isdc && good) {                                  // DC difference (:945-951), summed per component (:1200-1221)
             const int t = (k6 < 4u ? s0 : (k6 == 4u ? s1 : s2)) + val;
             s0 = k6 < 4u ? t : s0;
             s1 = k6 == 4u ? t : s1;
             s2 = k6 == 5u ? t : s2;
-            // relative to this lane's start; pass 5 adds the base
+            // relative to this lane's start; the reader (records) / pass 5 (dense) adds the base
             if (kRec) {
-                out.dcv[blk] = (int16_t)t;
-                if (k6 == 0u) out.mcu_start[blk / 6u] = r.recpos;
+                dcval = t;
+                if (blk == seg_blk) {   // an MCU-row segment starts with this block (once per <= 60 blocks: a real branch)
+                    out.seg_start[r.seg_next++] = r.recpos;
+                    const bool last = seg_col + 1u == sg.per_row;
+                    seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
+                    seg_col = last ? 0u : seg_col + 1u;
+                }
             } else {
                 coef[(uint64_t)blk * 64u] = (int16_t)t;
             }
             ++r.dc_count;
-            r.last_dc = (int)blk;
         }
-        const bool emit = good && !isdc && !iseob && size != 0u;
+        const bool emit = good && ((!isdc && !iseob && size != 0u) || (kRec && isdc));
         if (emit) {
             if (kRec) {
-                stage_put(stage, r.recpos, idx | (blk << 6) | ((uint32_t)val << 20));
+                const uint32_t pos = isdc ? 0u : idx;
+                const uint32_t v16 = (uint32_t)(isdc ? dcval : val) << 16;
+                stage_put(stage, r.recpos, pos | ((blk & 63u) << 6) | v16);
             } else {
                 coef[(uint64_t)blk * 64u + idx] = (int16_t)val;
             }
@@ -469,17 +496,18 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
 
 }  // namespace
 
-// Outputs of the records form (SyncOut::rec != nullptr), all per frame: rec[cap_rec] records,
-// dcv[blocks] predicted DC values, mcu_start[mcus + 1] record index at which each MCU starts (entries
-// of MCUs the decoder never reached hold the total), rec_count = total, or ~0 when the frame was
-// handed to the serial kernel, whose output is dense coefficient lines.
+// Outputs of the records form (SyncOut::rec != nullptr), all per frame: rec[cap_rec] records, seg_start[segs + 1]
+// record index at which each MCU-row segment starts (entries of segments the decoder never reached, and the last
+// one, hold the total), lane_tab[L] = {first block whose DC the lane decoded, DC base Y, Cb, Cr} (lanes right of the
+// one that met the frame's end or first error: first block ~0), rec_count = total, or ~0 when the frame was handed to
+// the serial kernel, whose output is dense coefficient lines.
 struct SyncOut {
     int16_t* coef;
     uint32_t* rec;
     uint32_t cap_rec;
-    int16_t* dcv;
-    uint32_t* mcu_start;
-    uint32_t mcus;
+    uint32_t* seg_start;
+    uint32_t* lane_tab;
+    SegGeom sg;
     uint32_t* rec_count;
     uint32_t* retry_list;    // frames for amv_huffman_kernel
     uint32_t* retry_count;
@@ -488,7 +516,7 @@ struct SyncOut {
 // dynamic LDS: [ m1 4 KB | m2 5 KB | per wave: ring of kRingWords words per lane | records form, per wave: staged records ]
 // With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).
 template <int L, bool kRec>
-__global__ __launch_bounds__(kWave* waves_per_group(kRec)) void amv_huffman_sync_kernel(
+__global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
     uint32_t blocks_per_frame, uint32_t cap_words,
@@ -507,9 +535,9 @@ __global__ __launch_bounds__(kWave* waves_per_group(kRec)) void amv_huffman_sync
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
-    constexpr uint32_t kWaves = (uint32_t)waves_per_group(kRec);
+    const uint32_t nwaves = blockDim.x >> 6;   // the launch sizes the workgroup (and its LDS) to the batch
     uint32_t* ring = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + wave * (kRingWords * kWave) + lane;
-    uint32_t* stage = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + kWaves * (kRingWords * kWave) + wave * (kStageSlots * kWave) + lane * 4u;
+    uint32_t* stage = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + nwaves * (kRingWords * kWave) + wave * (kStageSlots * kWave) + lane * 4u;
     if (list) n = *list_count;
     const uint32_t ntasks = (n + kFrames - 1) / kFrames;
     // Tasks (kFrames frames each) are handed out through a counter: a wave that finishes early -- the
@@ -534,8 +562,7 @@ __global__ __launch_bounds__(kWave* waves_per_group(kRec)) void amv_huffman_sync
     Sink sink;
     sink.coef = kRec ? nullptr : out.coef + (uint64_t)fsafe * blocks_per_frame * 64u;
     sink.rec = kRec ? out.rec + (uint64_t)fsafe * out.cap_rec : nullptr;
-    sink.dcv = kRec ? out.dcv + (uint64_t)fsafe * blocks_per_frame : nullptr;
-    sink.mcu_start = kRec ? out.mcu_start + (uint64_t)fsafe * (out.mcus + 1u) : nullptr;
+    sink.seg_start = kRec ? out.seg_start + (uint64_t)fsafe * (out.sg.count + 1u) : nullptr;
     const uint32_t valid_bits = live ? total * 8u : 0u;
     if (!kRec && live) {   // dense form: the frame's coefficient lines start as zeros
         uint4* z = reinterpret_cast<uint4*>(sink.coef);
@@ -583,20 +610,20 @@ __global__ __launch_bounds__(kWave* waves_per_group(kRec)) void amv_huffman_sync
     // ---- 4. the strict, writing pass.  Lanes left of the frame's end (or first error) are exact;
     // whatever a lane to the right of it does is ignored below.
     __builtin_amdgcn_s_waitcnt(0);   // dense form: the zeroing stores have landed before the sparse ones go out
-    WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, 0u, -1};
+    WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, 0u, 0u};
     if (live && blk0 < blocks_per_frame)
-        wr = walk_write<kRec>(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, sink, rec0, out.cap_rec, stage);
+        wr = walk_write<kRec>(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, sink, rec0, out.cap_rec, stage, out.sg);
     if (timing) tc[4] = clock64();
     const uint64_t stop_mask = __ballot(wr.done || wr.err != 0u) & seg;
-    uint32_t st = 0, good_blocks = blocks_per_frame, rec_total = 0;
-    int last_dc = -1;
+    uint32_t st = 0, good_blocks = blocks_per_frame, rec_total = 0, seg_seen = 0;
+    int stop_lane = 0;
     if (stop_mask) {
-        const int stop_lane = __builtin_ctzll(stop_mask);   // leftmost = the true path
+        stop_lane = __builtin_ctzll(stop_mask);   // leftmost = the true path
         const uint32_t e = __shfl(wr.err, stop_lane);
         const uint32_t eb = __shfl(wr.err_blk, stop_lane);
         const uint32_t sp = __shfl(wr.stop_p, stop_lane);
         rec_total = __shfl(wr.recpos, stop_lane);
-        last_dc = __shfl(wr.last_dc, stop_lane);
+        seg_seen = __shfl(wr.seg_next, stop_lane);
         st = e;
         if (e) good_blocks = eb;
         if (sp > valid_bits) st |= kStTruncated;
@@ -604,22 +631,30 @@ __global__ __launch_bounds__(kWave* waves_per_group(kRec)) void amv_huffman_sync
         st = kStFormat; good_blocks = 0;   // unreachable: the last lane runs until the frame ends or fails
     }
 
-    // ---- 5. DC prediction: every lane adds the sums of the lanes to its left to the DCs it stored.
-    // A lane reads back only its own stores (same thread, ordered by the wait), so no cache is in play.
+    // ---- 5. DC prediction: the sums of the lanes to the left are a lane's base.  Records form: the base goes into
+    // the frame's lane table and the reader adds it.  Dense form: every lane adds it to the DCs it stored (a lane
+    // reads back only its own stores -- same thread, ordered by the wait -- so no cache is in play).
     uint32_t tot;
     const int by = (int)seg_excl_sum<L>((uint32_t)wr.sum[0], sub, tot);
     const int bu = (int)seg_excl_sum<L>((uint32_t)wr.sum[1], sub, tot);
     const int bv = (int)seg_excl_sum<L>((uint32_t)wr.sum[2], sub, tot);
-    __builtin_amdgcn_s_waitcnt(0);
-    for (uint32_t j = 0; j < wr.dc_count; ++j) {
-        const uint32_t b = wr.dc_first + j, c6 = b % 6u;
-        const int base = c6 < 4u ? by : (c6 == 4u ? bu : bv);
-        int16_t* q = kRec ? sink.dcv + b : sink.coef + (uint64_t)b * 64u;
-        *q = (int16_t)(*q + base);
-    }
-    if (kRec && live) {   // MCUs the decoder never started begin (and end) at the total
-        const uint32_t started = last_dc < 0 ? 0u : (uint32_t)last_dc / 6u + 1u;
-        for (uint32_t m = started + sub; m <= out.mcus; m += L) sink.mcu_start[m] = rec_total;
+    if (kRec) {
+        if (live) {
+            // lanes right of the one that met the end (or the first error) walked from states no decoder reaches
+            const bool real = (int)lane <= stop_lane && blk0 < blocks_per_frame;
+            uint4 ent = make_uint4(real ? wr.dc_first : kNever, (uint32_t)by, (uint32_t)bu, (uint32_t)bv);
+            reinterpret_cast<uint4*>(out.lane_tab)[(uint64_t)frame * L + sub] = ent;
+            // segments the decoder never started begin (and end) at the total; so does the end of the last one
+            for (uint32_t m = seg_seen + sub; m <= out.sg.count; m += L) sink.seg_start[m] = rec_total;
+        }
+    } else {
+        __builtin_amdgcn_s_waitcnt(0);
+        for (uint32_t j = 0; j < wr.dc_count; ++j) {
+            const uint32_t b = wr.dc_first + j, c6 = b % 6u;
+            const int base = c6 < 4u ? by : (c6 == 4u ? bu : bv);
+            int16_t* q = sink.coef + (uint64_t)b * 64u;
+            *q = (int16_t)(*q + base);
+        }
     }
     if (timing) {
         tc[5] = clock64();
@@ -651,20 +686,25 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
                  const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
                  uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
-    constexpr uint32_t kWaves = (uint32_t)waves_per_group(kRec);
-    constexpr uint32_t kPerGroup = (uint32_t)(kWave / L) * kWaves;
-    constexpr uint32_t kLds = kTableBytes + kWaves * kRingWords * kWave * 4u + (kRec ? kWaves * kStageSlots * kWave * 4u : 0u);
+    constexpr uint32_t kMaxWaves = (uint32_t)waves_per_group(kRec);
+    constexpr uint32_t kPerWave = kRingWords * kWave * 4u + (kRec ? kStageSlots * kWave * 4u : 0u);
     static bool raised = false;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L, kRec>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTableBytes + kMaxWaves * kPerWave));
         raised = true;
     }
-    // enough workgroups to fill the chip, never more than there are tasks (the rest come from the queue)
-    uint32_t grid = (n + kPerGroup - 1) / kPerGroup;
-    if (grid > cus * (uint32_t)groups_per_cu(kRec)) grid = cus * (uint32_t)groups_per_cu(kRec);
-    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * kWaves), kLds, s, ws, ws_bytes, n,
-                       list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
+    // Workgroups: as many as the chip holds (the rest of the tasks come from the queue); a batch that does not fill
+    // them gets smaller workgroups, so that its waves spread over all the compute units instead of filling a few.
+    const uint32_t groups = cus * (uint32_t)groups_per_cu(kRec);
+    const uint32_t tasks = (n + (uint32_t)(kWave / L) - 1u) / (uint32_t)(kWave / L);
+    uint32_t waves = (tasks + groups - 1u) / groups;
+    if (waves < 4u) waves = 4u;
+    if (waves > kMaxWaves) waves = kMaxWaves;
+    uint32_t grid = (tasks + waves - 1u) / waves;
+    if (grid > groups) grid = groups;
+    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * waves), kTableBytes + waves * kPerWave, s, ws,
+                       ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
 }
 
 }  // namespace
@@ -701,7 +741,9 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
                          const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status, uint32_t* nmcu_ok,
                          uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
     if (n == 0) return;
-    SyncOut out{sinks.coef, sinks.rec, sinks.cap_rec, sinks.dcv, sinks.mcu_start, g.mcus, sinks.rec_count, sinks.retry_list, sinks.retry_count};
+    const uint32_t per_row = (g.mcu_cols + kSegMcus - 1u) / kSegMcus;
+    SyncOut out{sinks.coef, sinks.rec, sinks.cap_rec, sinks.seg_start, sinks.lane_tab, SegGeom{g.mcu_cols, per_row, per_row * g.mcu_rows},
+                sinks.rec_count, sinks.retry_list, sinks.retry_count};
 #define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, d_img, out, status, nmcu_ok, queue, stats, cus, s
     if (sinks.rec) {
         switch (lanes_per_frame) {

@@ -26,16 +26,19 @@ void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
 // lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units (amv_decode_sync.hip)
 int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels);
 // Where the entropy stage puts its result.  rec == nullptr: dense coefficient lines in coef
-// ([n][blocks][64] int16).  Otherwise the records form, per frame: rec[cap_rec] (one word per
-// non-zero AC coefficient: bits 0-5 index in block, 6-19 block, 20-31 value), dcv[blocks] predicted
-// DC values, mcu_start[mcus + 1] first record of each MCU, rec_count (total, or ~0 = this frame is in
+// ([n][blocks][64] int16).  Otherwise the records form, per frame: rec[cap_rec] (one word per DC coefficient and
+// per non-zero AC coefficient, stream order: bits 0-5 index in block (0 = DC), 6-11 block modulo 64, bit 15 filler,
+// 16-31 value; a DC value counts from the decoding lane's first block), seg_start[segs + 1] first record of each
+// MCU-row segment of kSegMcus MCUs (what one wave of the reconstruction takes), lane_tab[lanes] = {first block,
+// DC base Y, Cb, Cr} of each of the `lanes` lanes that decoded the frame, rec_count (total, or ~0 = this frame is in
 // dense form in coef because it went through amv_huffman_kernel).
 struct SyncSinks {
     int16_t* coef;
     uint32_t* rec;
     uint32_t cap_rec;
-    int16_t* dcv;
-    uint32_t* mcu_start;
+    uint32_t* seg_start;
+    uint32_t* lane_tab;
+    uint32_t lanes;
     uint32_t* rec_count;
     uint32_t* retry_list;
     uint32_t* retry_count;

@@ -18,7 +18,7 @@
 //
 // Pixels of MCUs at or after a frame's first decode error are zero (AMVDec.c:283 + the reference
 // stopping at the error).  Compiled with -fwrapv, as the reference's arithmetic wraps.
-#include "amv_kernels.h"
+#include "amv_block_load.h"
 
 namespace amv {
 
@@ -89,17 +89,11 @@ __device__ __forceinline__ void idct8(int& v0, int& v1, int& v2, int& v3, int& v
 __device__ __forceinline__ int clamp_iclp(int x) { return min(max(x, -256), 255); }
 __device__ __forceinline__ uint32_t clamp_u8(int x) { return (uint32_t)min(max(x, 0), 255); }
 
-// int16 number `i` of a block held as 32 dwords
-__device__ __forceinline__ int coef_at(const uint32_t (&c)[32], int i) {
-    return (i & 1) ? ((int)c[i >> 1] >> 16) : (int)(int16_t)(c[i >> 1] & 0xffffu);
-}
-
 }  // namespace
 
 __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n,
     FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
-    const int16_t* __restrict__ coef = in.coef;
     constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;   // int16 units
     // 7 680 bytes: first the records' image of the 60 blocks (128 bytes each), then the three planes
     __shared__ __attribute__((aligned(16))) int16_t s_mem[16 * kPitchY + 2 * 8 * kPitchC];
@@ -112,51 +106,15 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     const uint32_t f = blockIdx.x, my = blockIdx.y, seg = blockIdx.z;   // no integer division to find them
     const uint32_t m0 = seg * kSegMcus;
     const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
-    const uint32_t nb = cnt * 6;
 
     const uint32_t ok = nmcu_ok[f];
     const uint32_t mcu0 = my * g.mcu_cols + m0;                       // first MCU of this segment
-    const bool records = in.rec != nullptr && in.rec_count[f] != 0xffffffffu;
-    if (records) {   // records -> dense image of the segment's blocks in LDS
-        uint4* img16 = reinterpret_cast<uint4*>(s_img);
-        for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
-        const uint32_t* ms = in.mcu_start + (uint64_t)f * (g.mcus + 1u);
-        const uint32_t r0 = ms[mcu0], r1 = ms[mcu0 + cnt_ok];
-        const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec;
-        int16_t* img = reinterpret_cast<int16_t*>(s_img);
-        for (uint32_t r = r0 + lane; r < r1; r += kWave) {
-            const uint32_t w = rec[r];
-            const uint32_t b = ((w >> 6) & 0x3fffu) - mcu0 * 6u, k = w & 63u;
-            if (b < cnt_ok * 6u) img[b * 64u + ((((k >> 3) ^ b) & 7u) << 3) + (k & 7u)] = (int16_t)((int)w >> 20);
-        }
-        if (lane < cnt_ok * 6u)
-            img[lane * 64u + ((lane & 7u) << 3)] = in.dcv[(uint64_t)f * g.blocks + mcu0 * 6u + lane];   // k = 0: granule 0 ^ b
-        __syncthreads();
-    }
 
     // ---- A + B + C: one block per lane
-    if (lane < nb) {
+    uint32_t c[32];
+    if (load_segment_blocks(in, f, g, my * nseg + seg, g.mcu_rows * nseg, mcu0, cnt, ok, lane, s_img, c)) {
         const uint32_t m = lane / 6u, k6 = lane % 6u;
         const bool chroma = k6 >= 4u;
-        uint32_t c[32];
-        if (records) {
-            const uint4* src = reinterpret_cast<const uint4*>(s_img) + lane * 8u;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint4 q = src[(uint32_t)i ^ (lane & 7u)];
-                c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
-            }
-        } else {
-            const uint4* src = reinterpret_cast<const uint4*>(
-                coef + (((uint64_t)f * g.mcus + mcu0) * 6u + lane) * 64u);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint4 q = src[i];
-                c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
-            }
-        }
         // IQtIZzBlock's gather (AmvJpeg.c:1035-1042): out[nat] = coef[scan(nat)] * step[scan(nat)]
         int v[64];
 #pragma unroll

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
     const uint32_t mcu0 = my * g.mcu_cols + m0;
 
     uint32_t c[32];
-    if (!load_segment_blocks(in, f, g, mcu0, cnt, ok, lane, s_img, c)) return;
+    if (!load_segment_blocks(in, f, g, my * gridDim.z + seg, gridDim.y * gridDim.z, mcu0, cnt, ok, lane, s_img, c)) return;
     const uint32_t m = lane / 6u, k6 = lane % 6u;
     const bool chroma = k6 >= 4u;
     const bool decoded = mcu0 + m < ok;

@@ -39,7 +39,7 @@ struct amvhip_ctx {
     HuffDecodeImage* d_dec = nullptr;
     HuffEncodeImage* d_enc = nullptr;
     // workspace
-    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, dcv, mcu_start, rec_count;
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count;
     bool dense_intermediate = false;   // AMVHIP_DENSE=1: dense coefficient lines between the decode stages (experiments)
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
     uint32_t cus = 256;   // compute units of the device
@@ -241,7 +241,7 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->dcv, &c->mcu_start, &c->rec_count, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out})
+                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -300,7 +300,7 @@ static int entropy_stage(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
         Timed t(c, AMVHIP_K_HUFFMAN, st);
         unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
         launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, cap_words,
-                            huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height), c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1,
+                            sinks.rec ? (int)sinks.lanes : huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height), c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1,
                             stats, c->cus, st);
     }
     if (int r = check_launch(c, "huffman_sync")) return r;
@@ -323,7 +323,7 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     if (int r = use_device(c)) return r;
     if (n == 0) return AMVHIP_OK;
     std::lock_guard<std::mutex> lk(c->mu);
-    SyncSinks sinks{d_coef, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SyncSinks sinks{d_coef, nullptr, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr};
     return entropy_stage(c, d_blob, blob_bytes, d_offs, d_lens, n, make_geom(w, h), sinks, d_status, d_nmcu_ok, (hipStream_t)stream);
 }
 
@@ -356,7 +356,7 @@ extern "C" int amvhip_reconstruct_dev(amvhip_ctx* c, const int16_t* d_coef, cons
     if (((uintptr_t)d_out & 3u) || ((uintptr_t)d_coef & 15u)) return fail(c, AMVHIP_ERR_ARG, "reconstruct: out must be 4-byte, coef 16-byte aligned");
     if (int r = use_device(c)) return r;
     if (n == 0) return AMVHIP_OK;
-    SyncSinks sinks{const_cast<int16_t*>(d_coef), nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SyncSinks sinks{const_cast<int16_t*>(d_coef), nullptr, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr};
     return reconstruct_stage(c, sinks, d_nmcu_ok, n, make_geom(w, h), flags, d_out, (hipStream_t)stream);
 }
 
@@ -372,16 +372,18 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     if (int r = use_device(c)) return r;
     const FrameGeom g = make_geom(w, h);
     std::lock_guard<std::mutex> lk(c->mu);
-    // between the two stages coefficients travel as records (one word per non-zero AC coefficient) +
-    // DC values; the dense lines are only touched by frames that go through the serial kernel
-    const uint32_t cap_rec = g.blocks * 20u;
+    // between the two stages coefficients travel as records (one word per DC and per non-zero AC coefficient);
+    // the dense lines are only touched by frames that go through the serial kernel
+    const uint32_t cap_rec = g.blocks * 20u;                     // a multiple of 8: frames start on 32-byte pieces
+    const uint32_t lanes = (uint32_t)huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height);
+    const uint32_t segs = ((g.mcu_cols + 9u) / 10u) * g.mcu_rows;
     if (int r = ensure(c, c->coef, (size_t)n * g.blocks * 128)) return r;
     if (int r = ensure(c, c->nmcu, (size_t)n * 4)) return r;
     if (int r = ensure(c, c->rec, (size_t)n * cap_rec * 4)) return r;
-    if (int r = ensure(c, c->dcv, (size_t)n * g.blocks * 2 + 16)) return r;
-    if (int r = ensure(c, c->mcu_start, (size_t)n * (g.mcus + 1) * 4)) return r;
+    if (int r = ensure(c, c->seg_start, (size_t)n * (segs + 1) * 4)) return r;
+    if (int r = ensure(c, c->lane_tab, (size_t)n * lanes * 16)) return r;
     if (int r = ensure(c, c->rec_count, (size_t)n * 4)) return r;
-    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)c->rec.p, cap_rec, (int16_t*)c->dcv.p, (uint32_t*)c->mcu_start.p,
+    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)c->rec.p, cap_rec, (uint32_t*)c->seg_start.p, (uint32_t*)c->lane_tab.p, lanes,
                     (uint32_t*)c->rec_count.p, nullptr, nullptr};
     if (c->dense_intermediate) sinks.rec = nullptr;
     if (int r = entropy_stage(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, (uint32_t*)c->nmcu.p, (hipStream_t)stream))
