@@ -10,9 +10,9 @@
 //      copies the scan into a workspace as big-endian words with the byte after every FF removed
 //      (ReadByte, AmvJpeg.c:1061-1071), so that a decoder state is just a bit index.
 //
-//   amv_huffman_sync_kernel<L, records> (12 independent waves per workgroup sharing the tables, two
-//   workgroups per CU; L lanes per frame, 64/L frames per wave; waves take tasks of 64/L frames from
-//   an atomic queue)
+//   amv_huffman_sync_kernel<L, records> (independent waves sharing the tables: up to 16 per workgroup, one
+//   workgroup per CU, in the records form, 10 x 2 in the dense form; L lanes per frame, 64/L frames per
+//   wave; waves take tasks of 64/L frames from an atomic queue)
 //   0. a lane reads its part of the stream through a 16-word window in LDS that it refills from the
 //      workspace (L2) with 16-byte loads whenever any lane of the wave has used its window up, so a
 //      wave needs 4 KB of LDS whatever the frame size (dense form: the frames' coefficient lines are
@@ -35,13 +35,15 @@
 //   3. a prefix sum of "blocks finished per lane" gives every lane its first block number;
 //   3'. records form: a prefix sum of "value-carrying AC symbols per lane" gives every lane its first
 //      record;
-//   4. one strict pass decodes values and writes them: records form, one 32-bit word per non-zero
-//      AC coefficient (index, block, value) in stream order + a DC array + the first record of every
-//      MCU -- what amv_reconstruct_kernel scatters into LDS; dense form, 2-byte stores into the
-//      frame's zeroed coefficient lines.  DC prediction (ycoef/ucoef/vcoef, AmvJpeg.c:1200-1221) is a
-//      running sum per component: each lane stores sums relative to its own start,
-//   5. a prefix sum over the lanes' totals gives every lane its three bases, which it adds to the DC
-//      values it stored itself.
+//   4. one strict pass decodes values and writes them: records form, one 32-bit word per DC coefficient
+//      and per non-zero AC coefficient (index, block modulo 64, value) in stream order, staged per lane
+//      in LDS and stored as aligned 32-byte pieces, + the first record of every MCU-row segment -- what
+//      amv_reconstruct_kernel scatters into LDS; dense form, 2-byte stores into the frame's zeroed
+//      coefficient lines.  DC prediction (ycoef/ucoef/vcoef, AmvJpeg.c:1200-1221) is a running sum per
+//      component: each lane's sums count from its own start,
+//   5. a prefix sum over the lanes' totals gives every lane its three bases: records form, they go into
+//      the frame's lane table and the reader adds them; dense form, the lane adds them to the DC values
+//      it stored itself.
 //
 // Statuses equal the serial kernel's bit for bit (tests): the first error on the true path stops
 // the frame, nmcu_ok counts whole MCUs before it, TRUNCATED compares consumed with stored bits.
@@ -67,7 +69,7 @@ constexpr uint32_t kStageSlots = 16;      // records a lane can hold
 constexpr uint32_t kFlush = 8;            // records per store burst: 32 bytes
 constexpr uint32_t kDummyRecord = 0x8000u;    // bit 15: a filler no block owns
 constexpr uint32_t kNever = 0xffffffffu;
-constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + 4u * kLut2PagesPerTable * (1u << kLut2Bits) * 2u;
+constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + (4u << kM2Bits) * 2u;   // m1 + m2 of HuffDecodeImage, contiguous
 
 struct State {
     uint32_t p;   // bit index in the unstuffed stream
@@ -177,10 +179,10 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
 // means "the code is longer than 9 bits, see m2".
 //
 // Codes longer than 9 bits sit at the top of the 9-bit prefix space (canonical codes ascend with
-// length): in every table they are the prefixes [507, 512) or fewer.  m2 therefore gives each
-// table 5 pages of 128 entries, page = prefix - 507, and its address follows from the bits alone:
-// both levels are read together and the right one is selected afterwards -- no dependent second
-// LDS round trip, no branch.
+// length): in every table they are the prefixes [507, 512) or fewer, i.e. they all begin with six
+// one-bits, and a code is at most 16 bits long.  m2 is therefore indexed by the ten bits behind those
+// six, 1024 entries per table: its address follows from the window alone, both levels are read
+// together and the right one is selected afterwards -- no dependent second LDS round trip, no branch.
 // =============================================================================================
 
 namespace {
@@ -252,67 +254,84 @@ __device__ __forceinline__ void stream_service(Stream& s, uint32_t widx) {
     while (widx + 9u > s.hi) stream_advance(s);
 }
 
-// tab = table number << kLut1Bits
+// tab = table number << kLut1Bits; v = the next 32 bits of the stream
 __device__ __forceinline__ uint32_t lookup(const uint16_t* __restrict__ m1, const uint16_t* __restrict__ m2,
                                            uint32_t tab, uint32_t v) {
-    constexpr uint32_t kFirst = (1u << kLut1Bits) - kLut2PagesPerTable;
-    const uint32_t prefix = v >> (32 - kLut1Bits);
-    const uint32_t page = max(prefix, kFirst) - kFirst;
-    const uint32_t e1 = m1[tab + prefix];
-    // table stride in m2 = 5 * 128 = 512 + 128 entries = tab + tab / 4
-    const uint32_t e2 = m2[tab + (tab >> 2) + (page << kLut2Bits) + ((v >> (32 - kLut1Bits - kLut2Bits)) & ((1u << kLut2Bits) - 1u))];
+    const uint32_t e1 = m1[tab + (v >> (32 - kLut1Bits))];
+    const uint32_t e2 = m2[(tab << 1) + ((v >> (32 - 6 - kM2Bits)) & ((1u << kM2Bits) - 1u))];
     return (e1 & 0x8000u) ? e2 : e1;
 }
 
+// table of the symbol that comes next: k = 0 -> DC, else AC; blocks 4 and 5 of an MCU are chroma
 __device__ __forceinline__ uint32_t table_of(uint32_t k, uint32_t k6) {
     return ((k ? 2u : 0u) + (k6 >= 4u ? 1u : 0u)) << kLut1Bits;
 }
 
+// The bit window of a walk: two consecutive stream words hi:lo and bo in [1, 32], the number of bits of hi that are
+// used up; the next 32 bits of the stream are ({hi, lo} >> (32 - bo)) -- one v_alignbit_b32.  nextw is the word
+// after lo, widx the index of the word after that (fetched from the lane's ring while the look-ups are in flight).
+struct Window {
+    uint32_t hi, lo, nextw, widx, bo;
+};
+
+__device__ __forceinline__ Window window_open(Stream& w, uint32_t p) {
+    const uint32_t b = p & 31u, w0 = p >> 5;
+    stream_open(w, w0);
+    Window x;
+    x.bo = b ? b : 32u;                                   // a word boundary: "all of the word before is used up"
+    const uint32_t base = b ? w0 : w0 - 1u;               // (then hi is never looked at; any ring word will do)
+    x.hi = ring_word(w, base);
+    x.lo = ring_word(w, base + 1u);
+    x.nextw = ring_word(w, base + 2u);
+    x.widx = base + 3u;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t window_bits(const Window& x) {
+    return __builtin_amdgcn_alignbit(x.hi, x.lo, 32u - x.bo);
+}
+
+// `used` (<= 27) bits consumed; cand = the ring word at x.widx
+__device__ __forceinline__ void window_consume(Window& x, uint32_t used, uint32_t cand) {
+    x.bo += used;
+    const bool step = x.bo > 32u;
+    x.hi = step ? x.lo : x.hi;
+    x.lo = step ? x.nextw : x.lo;
+    x.nextw = step ? cand : x.nextw;
+    x.widx += step ? 1u : 0u;
+    x.bo -= step ? 32u : 0u;
+}
+
 // Speculative walk from `s` while s.p < limit: where symbols start and how the block position
-// moves, nothing else.  Returns the number of blocks finished.
+// moves, nothing else.  Returns the number of blocks finished.  A stride of kStride symbols is straight-line code
+// (a lane that is past its limit goes through the motions without moving), so that the scheduler can overlap the
+// table look-up of one symbol with the bookkeeping of the one before.
 __device__ __forceinline__ uint32_t walk_skip(Stream& w, const uint16_t* __restrict__ m1,
                                               const uint16_t* __restrict__ m2, State& s, uint32_t limit,
                                               uint32_t& nrec_out) {
     uint32_t p = s.p, k = s.k, k6 = s.k6, nblk = 0, nrec = 0;
     nrec_out = 0u;
     bool active = p < limit;
-    uint32_t widx = p >> 5;
-    uint64_t acc = 0;
-    int nb = 0;
-    uint32_t nextw = 0;                                // appended when the register window runs low
-    if (active) {
-        stream_open(w, widx);
-        const uint32_t bo = p & 31u;
-        acc = (((uint64_t)ring_word(w, widx) << 32) | ring_word(w, widx + 1u)) << bo;
-        nb = 64 - (int)bo;
-        nextw = ring_word(w, widx + 2u);
-        widx += 3u;
-    }
+    if (!__ballot(active)) return 0u;
+    Window x = window_open(w, active ? p : 0u);
     uint32_t tab = table_of(k, k6);
     while (__ballot(active) != 0ull) {
-        if (active) stream_service(w, widx);
+        if (active) stream_service(w, x.widx);
+#pragma unroll
         for (int it = 0; it < kStride; ++it) {
-            if (active) {
-                const uint32_t cand = ring_word(w, widx);      // the word after nextw, in flight with the look-ups
-                const uint32_t e = lookup(m1, m2, tab, (uint32_t)(acc >> 32));
-                const uint32_t used = max(e & 31u, 1u);        // nonsense under a guessed start: slip one bit
-                const uint32_t kn = k + ((e >> 5) & 63u);
-                nrec += (k == 0u || (e & 0x7800u) != 0u) ? 1u : 0u;   // a DC symbol, or an AC symbol that carries a value
-                acc <<= used;
-                nb -= (int)used;
-                p += used;
-                const bool need = nb <= 32;
-                acc |= need ? (uint64_t)nextw << (need ? 32 - nb : 0) : 0ull;
-                nb += need ? 32 : 0;
-                nextw = need ? cand : nextw;
-                widx += need ? 1u : 0u;
-                const bool end = kn >= 64u;                    // end of block, a full block, or an over-long run
-                k = end ? 0u : kn;
-                k6 = end ? (k6 == 5u ? 0u : k6 + 1u) : k6;
-                nblk += end ? 1u : 0u;
-                tab = table_of(k, k6);
-                active = p < limit;
-            }
+            const uint32_t cand = ring_word(w, x.widx);        // the word after nextw, in flight with the look-ups
+            const uint32_t e = lookup(m1, m2, tab, window_bits(x));
+            const uint32_t used = active ? max(e & 31u, 1u) : 0u;   // nonsense under a guessed start: slip one bit
+            const uint32_t kn = k + (active ? (e >> 5) & 63u : 0u);
+            nrec += (active && (k == 0u || (e & 0x7800u) != 0u)) ? 1u : 0u;   // a DC symbol, or an AC symbol that carries a value
+            p += used;
+            window_consume(x, used, cand);
+            const bool end = kn >= 64u;                        // end of block, a full block, or an over-long run
+            k = end ? 0u : kn;
+            k6 = end ? (k6 == 5u ? 0u : k6 + 1u) : k6;
+            nblk += end ? 1u : 0u;
+            tab = table_of(k, k6);
+            active = active && p < limit;
         }
     }
     s.p = p; s.k = k; s.k6 = k6;
@@ -369,6 +388,10 @@ __device__ __forceinline__ void stage_flush(const uint32_t* stage, uint32_t* __r
     }
 }
 
+// Records form: a stride of kStrideWrite symbols is straight-line code -- every lane goes through every step, a lane
+// that has stopped (end of frame, error, end of its share) without moving or emitting -- so that the scheduler can
+// overlap one symbol's table look-up with the bookkeeping of the one before; a record is always written to the next
+// free staging slot and only counted when it is real.  Dense form: the 2-byte stores are conditional.
 template <bool kRec>
 __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __restrict__ m1,
                                                   const uint16_t* __restrict__ m2, State s, uint32_t limit,
@@ -388,100 +411,84 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
     }
     int16_t* __restrict__ coef = out.coef;
     uint32_t p = s.p, k = s.k, k6 = s.k6;
-    uint32_t widx = p >> 5;
-    const uint32_t bo = p & 31u;
-    stream_open(w, widx);
-    uint64_t acc = (((uint64_t)ring_word(w, widx) << 32) | ring_word(w, widx + 1u)) << bo;
-    int nb = 64 - (int)bo;
-    uint32_t nextw = ring_word(w, widx + 2u);
-    widx += 3u;
     r.dc_first = blk + (k ? 1u : 0u);
     int s0 = 0, s1 = 0, s2 = 0;
-    bool alive = true;
-    // one symbol per step; everything but the two stores is straight-line selects, so that lanes in
-    // different states (DC / AC / end of block) share every instruction
-    alive = p < limit;
+    bool alive = p < limit;
+    uint32_t stop = 0;           // why the lane stopped: 1 invalid code, 2 index past 63, 3 the frame's last block is done
     uint32_t flushed = recpos;   // records before this one have left for memory (a multiple of kFlush)
+    uint32_t seg_pos = 0;        // where the segment that starts inside the current stride starts (at most one does:
+    bool seg_hit = false;        // a segment is >= 6 blocks = 12 symbols, a stride 8)
+    Window x = window_open(w, p);
+    uint32_t tab = table_of(k, k6);
     while (__ballot(alive) != 0ull) {
-    if (alive) stream_service(w, widx);
-    if (kRec && r.recpos - flushed >= kFlush) {
-        stage_flush(stage, out.rec, flushed, rec_cap);
-        flushed += kFlush;
-    }
-    for (int it = 0; it < (kRec ? kStrideWrite : kStride); ++it) {
-      if (alive) {
-        const uint32_t cand = ring_word(w, widx);
-        const uint32_t v = (uint32_t)(acc >> 32);
-        const uint32_t e = lookup(m1, m2, table_of(k, k6), v);
-        const uint32_t used = e & 31u, size = (e >> 11) & 15u, adv = (e >> 5) & 63u;
-        const bool bad = used == 0u;                         // no code matches: FUNC_FORMAT_ERROR, AmvJpeg.c:887
-        const bool isdc = k == 0u;
-        const bool iseob = !isdc && adv == 63u;              // end of block (:959-964)
-        const uint32_t idx = k + adv - 1u;                   // AC: where the coefficient goes
-        const bool over = !bad && !isdc && !iseob && idx > 63u;   // the reference writes out of bounds here (:967-969)
-        // magnitude bits -> value (:924-933); size 0 gives 0
-        const uint32_t mag = ((v << (used - size)) >> 1) >> (31u - size);
-        const uint32_t half = (1u << size) >> 1;
-        const int val = (int)mag - (mag < half ? (int)((1u << size) - 1u) : 0);
-        // consume (a code that matches nothing consumes nothing; the reference has read 17 bits by then)
-        const uint32_t eat = bad ? 0u : used;
-        acc <<= eat;
-        nb -= (int)eat;
-        p += eat;
-        const bool need = nb <= 32;
-        acc |= need ? (uint64_t)nextw << (need ? 32 - nb : 0) : 0ull;
-        nb += need ? 32 : 0;
-        nextw = need ? cand : nextw;
-        widx += need ? 1u : 0u;
-        const bool good = !bad && !over;
-        int dcval = 0;
-        if (isdc && good) {                                  // DC difference (:945-951), summed per component (:1200-1221)
+        if (alive) stream_service(w, x.widx);
+        if (kRec && r.recpos - flushed >= kFlush) {
+            stage_flush(stage, out.rec, flushed, rec_cap);
+            flushed += kFlush;
+        }
+#pragma unroll
+        for (int it = 0; it < (kRec ? kStrideWrite : kStride); ++it) {
+            const uint32_t cand = ring_word(w, x.widx);
+            const uint32_t v = window_bits(x);
+            const uint32_t e = lookup(m1, m2, tab, v);
+            const uint32_t used = e & 31u, size = (e >> 11) & 15u, adv = (e >> 5) & 63u;
+            const bool bad = used == 0u;                         // no code matches: FUNC_FORMAT_ERROR, AmvJpeg.c:887
+            const bool isdc = k == 0u;
+            const bool iseob = !isdc && adv == 63u;              // end of block (:959-964)
+            const uint32_t idx = k + adv - 1u;                   // AC: where the coefficient goes
+            const bool over = !bad && !isdc && !iseob && idx > 63u;   // the reference writes out of bounds here (:967-969)
+            // magnitude bits -> value (:924-933): the `size` bits behind the code; size 0 gives 0
+            const uint32_t mag = __builtin_amdgcn_ubfe(v, 32u - used, size);
+            const uint32_t full = (1u << size) - 1u;
+            const int val = (int)mag - (mag <= (full >> 1) ? (int)full : 0);
+            // consume (a code that matches nothing consumes nothing; the reference has read 17 bits by then)
+            const uint32_t eat = (alive && !bad) ? used : 0u;
+            p += eat;
+            window_consume(x, eat, cand);
+            const bool good = alive && !bad && !over;
+            const bool dc = isdc && good;                        // DC difference (:945-951), summed per component (:1200-1221)
             const int t = (k6 < 4u ? s0 : (k6 == 4u ? s1 : s2)) + val;
-            s0 = k6 < 4u ? t : s0;
-            s1 = k6 == 4u ? t : s1;
-            s2 = k6 == 5u ? t : s2;
-            // relative to this lane's start; the reader (records) / pass 5 (dense) adds the base
+            s0 = (dc && k6 < 4u) ? t : s0;
+            s1 = (dc && k6 == 4u) ? t : s1;
+            s2 = (dc && k6 == 5u) ? t : s2;
+            r.dc_count += dc ? 1u : 0u;
+            const bool ac = good && !isdc && !iseob && size != 0u;
             if (kRec) {
-                dcval = t;
-                if (blk == seg_blk) {   // an MCU-row segment starts with this block (once per <= 60 blocks: a real branch)
-                    out.seg_start[r.seg_next++] = r.recpos;
-                    const bool last = seg_col + 1u == sg.per_row;
-                    seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
-                    seg_col = last ? 0u : seg_col + 1u;
-                }
-            } else {
-                coef[(uint64_t)blk * 64u] = (int16_t)t;
-            }
-            ++r.dc_count;
-        }
-        const bool emit = good && ((!isdc && !iseob && size != 0u) || (kRec && isdc));
-        if (emit) {
-            if (kRec) {
+                // the sum counts from this lane's start; the reader adds the lane's base
+                const bool hit = dc && blk == seg_blk;           // an MCU-row segment starts with this block
+                seg_pos = hit ? r.recpos : seg_pos;
+                seg_hit = seg_hit || hit;
                 const uint32_t pos = isdc ? 0u : idx;
-                const uint32_t v16 = (uint32_t)(isdc ? dcval : val) << 16;
-                stage_put(stage, r.recpos, pos | ((blk & 63u) << 6) | v16);
+                stage_put(stage, r.recpos, pos | ((blk & 63u) << 6) | ((uint32_t)(isdc ? t : val) << 16));
+                r.recpos += (dc || ac) ? 1u : 0u;                // (the slot behind the last record is always free)
             } else {
-                coef[(uint64_t)blk * 64u + idx] = (int16_t)val;
+                if (dc) coef[(uint64_t)blk * 64u] = (int16_t)t;  // pass 5 adds the base
+                if (ac) coef[(uint64_t)blk * 64u + idx] = (int16_t)val;
             }
+            const uint32_t newk = isdc ? 1u : idx + 1u;
+            const bool block_end = good && (iseob || (!isdc && newk == 64u));
+            k = good ? (block_end ? 0u : newk) : k;
+            k6 = block_end ? (k6 == 5u ? 0u : k6 + 1u) : k6;
+            blk += block_end ? 1u : 0u;
+            tab = table_of(k, k6);
+            const bool finished = block_end && blk == blocks_per_frame;
+            const uint32_t why = bad ? 1u : (over ? 2u : (finished ? 3u : 0u));
+            stop = (alive && why) ? why : stop;
+            alive = alive && !why && p < limit;
         }
-        r.recpos += (kRec && emit) ? 1u : 0u;
-        const uint32_t newk = isdc ? 1u : idx + 1u;
-        const bool block_end = good && (iseob || (!isdc && newk == 64u));
-        k = good ? (block_end ? 0u : newk) : k;
-        k6 = block_end ? (k6 == 5u ? 0u : k6 + 1u) : k6;
-        blk += block_end ? 1u : 0u;
-        const bool finished = block_end && blk == blocks_per_frame;
-        if (bad || over || finished) {
-            r.err = bad ? kStFormat : (over ? kStOverrun : 0u);
-            r.err_blk = blk;
-            r.stop_p = bad ? p + 17u : p;
-            r.done = finished;
-            alive = false;
+        if (kRec && seg_hit) {   // once per <= 60 blocks
+            out.seg_start[r.seg_next++] = seg_pos;
+            const bool last = seg_col + 1u == sg.per_row;
+            seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
+            seg_col = last ? 0u : seg_col + 1u;
+            seg_hit = false;
         }
-        alive = alive && p < limit;
-      }
     }
-    }
+    // the state froze where the lane stopped
+    r.err = stop == 1u ? kStFormat : (stop == 2u ? kStOverrun : 0u);
+    r.err_blk = blk;
+    r.stop_p = stop == 1u ? p + 17u : p;
+    r.done = stop == 3u;
     if (kRec) {   // what is still staged leaves padded to a whole piece with records no block owns
         const uint32_t end = (r.recpos + kFlush - 1u) & ~(kFlush - 1u);
         for (uint32_t q = r.recpos; q < end; ++q) stage_put(stage, q, kDummyRecord);
@@ -513,7 +520,7 @@ struct SyncOut {
     uint32_t* retry_count;
 };
 
-// dynamic LDS: [ m1 4 KB | m2 5 KB | per wave: ring of kRingWords words per lane | records form, per wave: staged records ]
+// dynamic LDS: [ m1 4 KB | m2 8 KB | per wave: ring of kRingWords words per lane | records form, per wave: staged records ]
 // With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).
 template <int L, bool kRec>
 __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
@@ -712,12 +719,17 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
 // Lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units.
 // More lanes per frame mean shorter walks (a shorter launch when the chip is not full) but more
 // speculative work per frame: every lane needs ~4 400 bits to fall in step whatever its share of the
-// frame.  Measured on MI355X: when the chip is full the best share is about that long (160x120 at
-// ~1.5 bits per pixel: 8 lanes; 320x240: 16), and a small batch does best with the most lanes that keep
-// it at ~10 waves per CU (10 000 frames of 160x120: 16; 2 000 of 320x240: 64).  `wanted` (8, 16, 32 or
-// 64) overrides.
+// frame.  Measured on MI355X: a batch that fills the chip with ONE lane per frame (>= ~400 frames per CU: two
+// waves per SIMD) does best with exactly that -- no speculative work at all, 2.7 ms per 160 000 frames of
+// 160x120 against 3.1 with two lanes and 4.9 with eight; from ~200 frames per CU two lanes (lane 0 is exact, so
+// lane 1 starts right after one walk); below that the best share is about the synchronisation length (160x120
+// at ~1.5 bits per pixel: 8 lanes; 320x240: 16), and a small batch does best with the most lanes that keep
+// it at ~10 waves per CU (10 000 frames of 160x120: 16; 2 000 of 320x240: 64).  `wanted` (a power of two
+// up to 64) overrides.
 int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     if (wanted == 1 || wanted == 2 || wanted == 4 || wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
+    if (n >= cus * 400u) return 1;
+    if (n >= cus * 200u) return 2;
     int full = 8;                                  // chip full: a share of ~4 000 bits, i.e. ~4 096 pixels
     while (full < 64 && (uint64_t)full * 2u * 4096u <= pixels) full *= 2;
     const uint64_t waves = (uint64_t)cus * 10u;

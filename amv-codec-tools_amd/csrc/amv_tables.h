@@ -103,14 +103,15 @@ static constexpr int kLut2Pages = 16;
 // m1/m2 are the same codes in the form the synchronising kernel wants (amv_decode_sync.hip):
 // bits 0-4 code length + magnitude bits (0 = no such code), bits 5-10 how far the coefficient index
 // moves (run + 1; 1 for a DC symbol; 63 for end-of-block), bits 11-14 magnitude bits, m1 bit 15 "the
-// code is longer than 9 bits".  Long codes occupy the top prefixes of every table (at most the
-// last 5), so m2 gives each table 5 pages: page = prefix - 507.
+// code is longer than 9 bits".  Long codes occupy the top prefixes of every table (at most the last 5 of
+// the 512: they all begin with six one-bits), so m2 is indexed by the 10 bits behind those six.
 static constexpr int kLut2PagesPerTable = 5;
+static constexpr int kM2Bits = 10;
 struct HuffDecodeImage {
     uint16_t l1[4][1 << kLut1Bits];
     uint16_t l2[kLut2Pages][1 << kLut2Bits];
     uint16_t m1[4][1 << kLut1Bits];
-    uint16_t m2[4][kLut2PagesPerTable][1 << kLut2Bits];
+    uint16_t m2[4][1 << kM2Bits];
 };
 
 // Encoder code book: for symbol s of table t, code | (length << 16)

@@ -134,14 +134,20 @@ void build_images(HuffDecodeImage& dec, HuffEncodeImage& enc) {
         return (uint16_t)((len + size) | (adv << 5) | (size << 11));
     };
     const int first = (1 << kLut1Bits) - kLut2PagesPerTable;
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
         for (int i = 0; i < (1 << kLut1Bits); ++i) {
             const uint16_t e = dec.l1[t][i];
             if (!(e & 0x8000u)) { dec.m1[t][i] = merged(e, t); continue; }
             if (i < first) abort();   // static property of the K.3 tables: long codes live in the last 5 prefixes
             dec.m1[t][i] = 0x8000u;
-            for (int j = 0; j < (1 << kLut2Bits); ++j) dec.m2[t][i - first][j] = merged(dec.l2[e & 0xffu][j], t);
         }
+        // m2: the 16-bit window 111111 xxxxxxxxxx -> entry of the code it starts with (0 where none does)
+        for (int x = 0; x < (1 << kM2Bits); ++x) {
+            const uint32_t w16 = 0xfc00u | (uint32_t)x;
+            const uint16_t e1 = dec.l1[t][w16 >> (16 - kLut1Bits)];
+            if (e1 & 0x8000u) dec.m2[t][x] = merged(dec.l2[e1 & 0xffu][(w16 >> (16 - kLut1Bits - kLut2Bits)) & ((1u << kLut2Bits) - 1u)], t);
+        }
+    }
 }
 
 // ---- timing ---------------------------------------------------------------------------------
