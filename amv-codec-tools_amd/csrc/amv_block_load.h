@@ -18,15 +18,23 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
                                                     uint8_t* s_img, uint32_t (&c)[32]) {
     constexpr uint32_t kWave = 64;
     const uint32_t nb = cnt * 6u;
-    const bool records = in.rec != nullptr && in.rec_count[f] != 0xffffffffu;
+    // everything the wave must know before it can ask for its records is requested at once (one round trip to
+    // memory, not three in a row): form of the frame, the segment's record range
+    uint32_t rc = 0xffffffffu, r0 = 0u, r1 = 0u;
+    if (in.rec != nullptr) {
+        const uint32_t* ss = in.seg_start + (uint64_t)f * (nsegs + 1u) + segidx;
+        rc = in.rec_count[f];
+        r0 = ss[0];
+        r1 = ss[1];
+    }
+    const bool records = rc != 0xffffffffu;
     int dc_base = 0;
     if (records) {   // records -> dense image of the segment's blocks in LDS
         uint4* img16 = reinterpret_cast<uint4*>(s_img);
         for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
-        const uint32_t* ss = in.seg_start + (uint64_t)f * (nsegs + 1u) + segidx;
-        const uint32_t r0 = ss[0], r1 = cnt_ok ? ss[1] : r0;
+        if (!cnt_ok) r1 = r0;
         const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec;
         int16_t* img = reinterpret_cast<int16_t*>(s_img);
         const uint32_t b0 = (mcu0 * 6u) & 63u;

@@ -12,7 +12,8 @@
 //      arithmetic -- no transposition, no LDS between the passes;
 //   C. results go to 16-row Y and 8-row U/V planes in LDS (one 16-byte store per block row; the
 //      planes reuse the space of the records' image, which every lane has read by then);
-//   D. colour conversion of a 4x2-pixel patch per lane step; the 12 bytes of each patch row go
+//   D. colour conversion of a 4x2-pixel patch per lane step, two pixels per instruction in packed
+//      16-bit arithmetic; the 12 bytes of each patch row go
 //      straight to the frame (the lanes of a step cover consecutive 12-byte pieces of a row, so a
 //      wave store is one contiguous run; the picture is stored bottom-up, AmvJpeg.c:800).
 //
@@ -87,7 +88,14 @@ __device__ __forceinline__ void idct8(int& v0, int& v1, int& v2, int& v3, int& v
 // iclp[] of AmvJpeg.c:1073-1080 (table spans -512..511; beyond it the reference reads out of
 // bounds, defined here as saturation)
 __device__ __forceinline__ int clamp_iclp(int x) { return min(max(x, -256), 255); }
-__device__ __forceinline__ uint32_t clamp_u8(int x) { return (uint32_t)min(max(x, 0), 255); }
+
+// two pixels of one channel: (y0 + c, y1 + c) clamped to 0..255, in bytes 0 and 1
+__device__ __forceinline__ uint32_t sat_pair(uint32_t yy, uint32_t cc) {
+    uint32_t sum, d;
+    asm("v_pk_add_i16 %0, %1, %2" : "=v"(sum) : "v"(yy), "v"(cc));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(sum));
+    return d;
+}
 
 }  // namespace
 
@@ -133,10 +141,9 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
 #pragma unroll
         for (int col = 0; col < 8; ++col)
             idct8<true>(v[col], v[8 + col], v[16 + col], v[24 + col], v[32 + col], v[40 + col], v[48 + col], v[56 + col]);
-        // GetYUV (AmvJpeg.c:754-787) + the +128 of IQtIZzBlock (:1023,1047): one 16-byte row at a time.
-        // (The +128 cannot ride through the column pass on the DC term: the reference's 32-bit arithmetic
-        // wraps on absurd coefficients, and the parity tests hold the kernel to that.)
-        const int offset = chroma ? 0 : 128;
+        // GetYUV (AmvJpeg.c:754-787): one 16-byte row at a time.  The +128 of IQtIZzBlock (:1023,1047) joins the
+        // chroma terms in stage D (it cannot ride through the column pass on the DC term: the reference's 32-bit
+        // arithmetic wraps on absurd coefficients, and the parity tests hold the kernel to that).
         int16_t* dst = chroma ? (k6 == 4u ? s_u : s_v) + m * 8u
                               : s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u;
         const uint32_t pitch = chroma ? kPitchC : kPitchY;
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
             uint32_t w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int lo = clamp_iclp(v[8 * r + 2 * q]) + offset;
-                const int hi = clamp_iclp(v[8 * r + 2 * q + 1]) + offset;
+                const int lo = clamp_iclp(v[8 * r + 2 * q]);
+                const int hi = clamp_iclp(v[8 * r + 2 * q + 1]);
                 w[q] = __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);   // low halves: lo | hi << 16
             }
             *reinterpret_cast<uint4*>(dst + r * pitch) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -154,62 +161,68 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     }
     __syncthreads();
 
-    // ---- D: StoreBuffer (AmvJpeg.c:789-840), straight to the frame.  A lane takes a 4x2-pixel patch: the two rows share their chroma samples, whose three products
-    // (:808-810) are formed once; (y*256 + c) >> 8 == y + (c >> 8) exactly, so a pixel costs an add
-    // and a clamp per channel.  MCUs that were not decoded get y = -1024, c = 0: every channel clamps to 0.
+    // ---- D: StoreBuffer (AmvJpeg.c:789-840), straight to the frame.  A lane takes a 4x2-pixel patch: the two rows
+    // share their chroma samples, whose three products (:808-810) are formed once, with luma's +128 folded in:
+    // (256 (y + 128) + c) >> 8 == y + ((c + 32768) >> 8) exactly.  Everything that follows fits 16 bits (|y| <= 256,
+    // |c >> 8| <= 440), so two pixels go through each instruction: v_pk_add_i16 adds the pair's luma to the (doubled)
+    // chroma term, v_sat_pk_u8_i16 clamps both to 0..255 (:812-827) and packs them into two bytes, and three byte
+    // permutes interleave B, G, R.  MCUs that were not decoded get y = -1024, c = 0: every channel clamps to 0.
     const uint32_t vr = min(16u, g.height - my * 16u);                 // rows of this MCU row inside the picture (:798); even
     const uint32_t px = min(cnt * 16u, g.width - m0 * 16u);            // pixels of this segment inside it (:803)
     const uint32_t groups = cnt * 4u;
-    const uint32_t inv_groups = (65536u + groups - 1u) / groups;       // t / groups == (t * inv) >> 16 for t < 8 * 40
-    for (uint32_t t = lane; t < ((vr + 1u) >> 1) * groups; t += kWave) {
-        const uint32_t i2 = (t * inv_groups) >> 16, gi = t - i2 * groups, lc = gi * 4u;
-        const bool decoded = (my * g.mcu_cols + m0 + (gi >> 2)) < ok;
+    const bool all_decoded = mcu0 + cnt <= ok;                         // wave-uniform: the usual case skips the per-patch test
+    const uint32_t pairs = (vr + 1u) >> 1;
+    // patch t = lane, lane + 64, ...: row pair i2 = t / groups, group gi = t % groups, kept up by addition
+    const uint32_t step_i2 = kWave / groups, step_gi = kWave - step_i2 * groups;
+    uint32_t i2 = lane / groups, gi = lane - i2 * groups;
+    uint8_t* const frame = out + (uint64_t)f * g.frame_bytes + (uint64_t)(g.height - 1u - my * 16u) * g.stride + m0 * 48u;
+    for (; i2 < pairs; i2 += step_i2, gi += step_gi) {
+        if (gi >= groups) { gi -= groups; ++i2; if (i2 >= pairs) break; }
+        const uint32_t lc = gi * 4u;
         uint2 ya = *reinterpret_cast<const uint2*>(s_y + (2u * i2) * kPitchY + lc);
         uint2 yb = *reinterpret_cast<const uint2*>(s_y + (2u * i2 + 1u) * kPitchY + lc);
         uint32_t uu = *reinterpret_cast<const uint32_t*>(s_u + i2 * kPitchC + (lc >> 1));
         uint32_t vv = *reinterpret_cast<const uint32_t*>(s_v + i2 * kPitchC + (lc >> 1));
-        constexpr uint32_t kDark = 0xfc00fc00u;                        // two int16 of -1024
-        ya.x = decoded ? ya.x : kDark; ya.y = decoded ? ya.y : kDark;
-        yb.x = decoded ? yb.x : kDark; yb.y = decoded ? yb.y : kDark;
-        uu = decoded ? uu : 0u;
-        vv = decoded ? vv : 0u;
-        int cr[2], cg[2], cb[2];
+        if (!all_decoded && (mcu0 + (gi >> 2)) >= ok) {
+            constexpr uint32_t kDark = 0xfc00fc00u;                    // two int16 of -1024
+            ya.x = ya.y = yb.x = yb.y = kDark;
+            uu = vv = 0u;
+        }
+        uint32_t cr[2], cg[2], cb[2];                                  // the chroma term of both pixels of a pair
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int u = e ? ((int)uu >> 16) : (int)(int16_t)(uu & 0xffffu);
             const int w = e ? ((int)vv >> 16) : (int)(int16_t)(vv & 0xffffu);
-            cr[e] = (18 * u + 367 * w) >> 8;                         // :808-810
-            cg[e] = (-159 * u - 220 * w) >> 8;
-            cb[e] = (411 * u - 29 * w) >> 8;
+            const uint32_t r = (uint32_t)((18 * u + 367 * w + 32768) >> 8);     // :808-810, +128
+            const uint32_t gg = (uint32_t)((-159 * u - 220 * w + 32768) >> 8);
+            const uint32_t b = (uint32_t)((411 * u - 29 * w + 32768) >> 8);
+            cr[e] = __builtin_amdgcn_perm(r, r, 0x05040100u);
+            cg[e] = __builtin_amdgcn_perm(gg, gg, 0x05040100u);
+            cb[e] = __builtin_amdgcn_perm(b, b, 0x05040100u);
         }
+        if (lc >= px) continue;                                        // right of the picture
+        // picture row my*16+i is destination row H-1-(my*16+i) (:800)
+        uint8_t* d8 = frame - (uint64_t)(2u * i2) * g.stride + lc * 3u;
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
             const uint2 yy = row ? yb : ya;
-            uint32_t b[12];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t yw = j < 2 ? yy.x : yy.y;
-                const int y = (j & 1) ? ((int)yw >> 16) : (int)(int16_t)(yw & 0xffffu);
-                b[3 * j + 0] = clamp_u8(y + cb[j >> 1]);               // :829-831 B,G,R
-                b[3 * j + 1] = clamp_u8(y + cg[j >> 1]);
-                b[3 * j + 2] = clamp_u8(y + cr[j >> 1]);
-            }
-            const uint32_t i = 2u * i2 + (uint32_t)row;                    // row inside the MCU row
-            if (i >= vr || lc >= px) break;                                // odd picture height / right of the picture
-            // picture row my*16+i is destination row H-1-(my*16+i) (:800)
-            uint8_t* d8 = out + (uint64_t)f * g.frame_bytes + (uint64_t)(g.height - 1u - my * 16u - i) * g.stride +
-                          (m0 * 16u + lc) * 3u;
+            const uint32_t b01 = sat_pair(yy.x, cb[0]), g01 = sat_pair(yy.x, cg[0]), r01 = sat_pair(yy.x, cr[0]);
+            const uint32_t b23 = sat_pair(yy.y, cb[1]), g23 = sat_pair(yy.y, cg[1]), r23 = sat_pair(yy.y, cr[1]);
+            const uint32_t gr = g01 | (r01 << 16);                         // G0 G1 R0 R1
+            const uint32_t bg = b23 | (g23 << 16);                         // B2 B3 G2 G3
+            Px12 v;                                                        // :829-831 B,G,R
+            v.w[0] = __builtin_amdgcn_perm(gr, b01, 0x01060400u);          // B0 G0 R0 B1
+            v.w[1] = __builtin_amdgcn_perm(bg, gr, 0x06040301u);           // G1 R1 B2 G2
+            v.w[2] = __builtin_amdgcn_perm(bg, r23, 0x01070500u);          // R2 B3 G3 R3
+            if (2u * i2 + (uint32_t)row >= vr) break;                      // odd picture height
             if (lc + 4u <= px) {                                           // rows are 4-byte aligned (AmvJpeg.c:1524), lc*3 is 0 mod 4
-                Px12 v;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    v.w[q] = b[4 * q] | (b[4 * q + 1] << 8) | (b[4 * q + 2] << 16) | (b[4 * q + 3] << 24);
                 *reinterpret_cast<Px12*>(d8) = v;
             } else {                                                       // the picture's last 1-3 pixels
 #pragma unroll
                 for (uint32_t q = 0; q < 9u; ++q)
-                    if (q < (px - lc) * 3u) d8[q] = (uint8_t)b[q];
+                    if (q < (px - lc) * 3u) d8[q] = (uint8_t)(v.w[q >> 2] >> (8u * (q & 3u)));
             }
+            d8 -= g.stride;
         }
     }
 }
