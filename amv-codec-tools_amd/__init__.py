@@ -91,6 +91,7 @@ SYMBOLS = {
     "amvhip_encode_bound": (_u32, [_u32, _u32]),
     "amvhip_jpeg_header": (_u32, [ctypes.c_ushort, ctypes.c_ushort, _vp, _u32]),
     "amvhip_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "amvhip_decode_workspace_per_frame": (ctypes.c_double, [_vp]),
     "amvhip_decode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_decode_batch_async": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_sync": (_int, [_vp]),
@@ -215,6 +216,9 @@ class Context:
     def decode_batch_dev(self, blob, blob_bytes, offs, lens, n, w, h, flags, out, status, stream=None):
         return self._check(self.lib.amvhip_decode_batch_dev(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens), n,
                                                             w, h, flags, _ptr(out), _ptr(status), stream), "decode_batch_dev")
+
+    def decode_workspace_per_frame(self):
+        return self.lib.amvhip_decode_workspace_per_frame(self.h)
 
     def huffman_decode_dev(self, blob, blob_bytes, offs, lens, n, w, h, coef, status, nmcu_ok, stream=None):
         return self._check(self.lib.amvhip_huffman_decode_dev(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens), n,

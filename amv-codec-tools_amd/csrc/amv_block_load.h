@@ -13,21 +13,38 @@ namespace amv {
 // s_img: >= cnt * 6 * 128 bytes of LDS, 16-byte aligned; the caller may reuse it after a __syncthreads().
 // segidx: this segment's number in the frame (mcu_row * segments_per_row + segment).
 // Returns true when this lane holds a block (lane < cnt * 6).
-__device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_t f, const FrameGeom& g, uint32_t segidx,
+// Which frame this workgroup works on: work item `item` of the launch (FrameSel); false when there is none (past
+// the end of a round's work).  slot: where the frame's dense lines live, if it has any.  A default launch has one
+// item per workgroup (blockIdx.x); a round launch is small and its workgroups walk the round's items.
+__device__ __forceinline__ bool select_frame(const FrameSel& sel, uint32_t n, uint32_t item, uint32_t& f, uint32_t& slot) {
+    f = slot = item;
+    if (!sel.round) return true;
+    const uint32_t p = sel.base + item;
+    if (item >= sel.round || p >= (sel.count ? *sel.count : n)) return false;
+    f = sel.list ? sel.list[p] : p;
+    return true;
+}
+
+// dense_only: a round launch -- the frame's lines are in slot `slot` whatever rec_count says.  A default launch over
+// records leaves frames that went to the serial kernel alone: skip = true (for the whole workgroup), nothing loaded.
+__device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_t f, uint32_t slot, bool dense_only,
+                                                    const FrameGeom& g, uint32_t segidx,
                                                     uint32_t nsegs, uint32_t mcu0, uint32_t cnt, uint32_t ok, uint32_t lane,
-                                                    uint8_t* s_img, uint32_t (&c)[32]) {
+                                                    uint8_t* s_img, uint32_t (&c)[32], bool& skip) {
     constexpr uint32_t kWave = 64;
     const uint32_t nb = cnt * 6u;
     // everything the wave must know before it can ask for its records is requested at once (one round trip to
     // memory, not three in a row): form of the frame, the segment's record range
     uint32_t rc = 0xffffffffu, r0 = 0u, r1 = 0u;
-    if (in.rec != nullptr) {
+    if (in.rec != nullptr && !dense_only) {
         const uint32_t* ss = in.seg_start + (uint64_t)f * (nsegs + 1u) + segidx;
         rc = in.rec_count[f];
         r0 = ss[0];
         r1 = ss[1];
     }
     const bool records = rc != 0xffffffffu;
+    skip = !records && in.rec != nullptr && !dense_only;   // a round launch reconstructs this frame
+    if (skip) return false;
     int dc_base = 0;
     if (records) {   // records -> dense image of the segment's blocks in LDS
         uint4* img16 = reinterpret_cast<uint4*>(s_img);
@@ -67,7 +84,7 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
         }
         c[0] = (c[0] & 0xffff0000u) | ((c[0] + (uint32_t)dc_base) & 0xffffu);   // int16 arithmetic, as the predictors wrap
     } else {
-        const uint4* src = reinterpret_cast<const uint4*>(in.coef + (((uint64_t)f * g.mcus + mcu0) * 6u + lane) * 64u);
+        const uint4* src = reinterpret_cast<const uint4*>(in.coef + (((uint64_t)slot * g.mcus + mcu0) * 6u + lane) * 64u);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint4 q = src[i];

@@ -113,20 +113,21 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
     const uint32_t* __restrict__ lens, uint32_t n, uint32_t blocks_per_frame,
     const HuffDecodeImage* __restrict__ img, int16_t* __restrict__ coef,
     int32_t* __restrict__ status, uint32_t* __restrict__ nmcu_ok,
-    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count, uint32_t base, uint32_t by_slot) {
     __shared__ __attribute__((aligned(16))) uint16_t s_l1[4 << kLut1Bits];
     __shared__ __attribute__((aligned(16))) uint16_t s_l2[kLut2Pages << kLut2Bits];
     __shared__ __attribute__((aligned(16))) uint4 s_slots[kWave * 8];
     __shared__ uint32_t s_frame[kWave];
 
-    // with a list (frames the wave-per-frame kernel handed back) this kernel decodes
-    // list[0 .. *list_count); without one, frames 0 .. n
+    // Work items base .. : with a list (frames the synchronising kernel handed back) item p is frame list[p],
+    // p < *list_count; without one, item p is frame p, p < n.  by_slot: the coefficient lines of item p go to slot
+    // p - base of a workspace that holds one round of items (amvhip_api.hip), else to the frame's own place.
     const uint32_t lane = threadIdx.x;
-    const uint32_t f0 = blockIdx.x * kWave;
+    const uint32_t f0 = base + blockIdx.x * kWave;
     if (list) n = *list_count;
     if (f0 >= n) return;
     const uint32_t frame = f0 + lane < n ? (list ? list[f0 + lane] : f0 + lane) : 0xffffffffu;
-    s_frame[lane] = frame;
+    s_frame[lane] = frame == 0xffffffffu ? frame : (by_slot ? f0 + lane - base : frame);
 
     {   // table image -> LDS, slots cleared
         const uint4* src = reinterpret_cast<const uint4*>(img);
@@ -218,11 +219,12 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
 void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
                     const uint32_t* lens, uint32_t n, const FrameGeom& g,
                     const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
-                    uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, hipStream_t s) {
-    if (n == 0) return;
-    const uint32_t grid = (n + kWave - 1) / kWave;   // with a list: upper bound, surplus groups exit at once
+                    uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, uint32_t base, uint32_t items,
+                    bool by_slot, hipStream_t s) {
+    if (items == 0) return;
+    const uint32_t grid = (items + kWave - 1) / kWave;   // an upper bound: groups past the end of the work exit at once
     hipLaunchKernelGGL(amv_huffman_kernel, dim3(grid), dim3(kWave), 0, s, blob, blob_bytes, offs,
-                       lens, n, g.blocks, d_img, coef, status, nmcu_ok, list, list_count);
+                       lens, n, g.blocks, d_img, coef, status, nmcu_ok, list, list_count, base, by_slot ? 1u : 0u);
 }
 
 }  // namespace amv

@@ -12,11 +12,14 @@ enum : uint32_t { kFlagZigzagFixed = 1u, kFlagFfmpeg = 2u };
 
 // ---- decode -------------------------------------------------------------------------------
 // entropy stage: one lane per frame, coefficients staged per block in LDS and written out as
-// whole 128-byte lines.  coef: [n][blocks][64] int16, scan order, DC already predicted.
+// whole 128-byte lines.  coef: [..][blocks][64] int16, scan order, DC already predicted.
+// Work items base .. base + items: item p is frame list[p] (p < *list_count) or, without a list, frame p (p < n);
+// its lines go to coef slot p - base (by_slot) or to the frame's own place.
 void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
                     const uint32_t* lens, uint32_t n, const FrameGeom& g,
                     const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
-                    uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, hipStream_t s);
+                    uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, uint32_t base, uint32_t items,
+                    bool by_slot, hipStream_t s);
 // entropy stage with parallelism inside a frame (amv_decode_sync.hip): unstuff into a workspace
 // (cap_words words per frame, ws_bytes[i] = unstuffed length or ~0 when the frame is handed to
 // launch_huffman through retry_list / *retry_count), then L lanes per frame synchronise and decode.
@@ -48,16 +51,27 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
                          const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
                          const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status, uint32_t* nmcu_ok,
                          uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s);
+// Which frames a reconstruction launch takes.  Default: frame = blockIdx.x for all n frames, dense lines (if any) at
+// the frame's own place; frames of a records launch that went to the serial kernel (rec_count ~0) are skipped --
+// a round launch picks them up.  Round: work items base .. base + round, item p = frame list[p] (p < *count) or
+// frame p (p < n), dense lines in slot p - base; the launch is small (its workgroups walk the items) because the
+// round usually has nothing to do and the host cannot know.
+struct FrameSel {
+    const uint32_t* list;
+    const uint32_t* count;
+    uint32_t base;
+    uint32_t round;   // items of this round; 0 = default launch
+};
 // dequantise + IDCT + YCbCr->BGR + flipped store: one wave per MCU-row segment
 // sinks.rec == nullptr: every frame is dense in sinks.coef; otherwise per frame as rec_count says
-void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n,
+void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameSel& sel, uint32_t items,
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s);
 
 // FFmpeg-compat back half (amv_reconstruct_ff.hip): Q60 dequantisation, simple_idct_put, YUVJ420P planes
 // (Y, Cb, Cr; tight rows) flipped as mjpegdec.c:672-677 does.  yuv_store_covers_planes: false when that formula
 // leaves plane rows unwritten (the caller clears the output first).
-void launch_reconstruct_yuv(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameGeom& g,
-                            uint64_t yuv_frame_bytes, uint8_t* out, hipStream_t s);
+void launch_reconstruct_yuv(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameSel& sel, uint32_t items,
+                            const FrameGeom& g, uint64_t yuv_frame_bytes, uint8_t* out, hipStream_t s);
 bool yuv_store_covers_planes(const FrameGeom& g);
 
 // ---- encode -------------------------------------------------------------------------------

@@ -99,8 +99,10 @@ __device__ __forceinline__ uint32_t sat_pair(uint32_t yy, uint32_t cc) {
 
 }  // namespace
 
+// kRound: a round launch (FrameSel::round != 0), whose workgroups walk the items of the round
+template <bool kRound>
 __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
-    SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n,
+    SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameSel sel,
     FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
     constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;   // int16 units
     // 7 680 bytes: first the records' image of the 60 blocks (128 bytes each), then the three planes
@@ -111,7 +113,10 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     uint8_t* const s_img = reinterpret_cast<uint8_t*>(s_mem);
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t f = blockIdx.x, my = blockIdx.y, seg = blockIdx.z;   // no integer division to find them
+    const uint32_t my = blockIdx.y, seg = blockIdx.z;   // no integer division to find them
+    for (uint32_t item = blockIdx.x;; item += gridDim.x) {
+    uint32_t f, slot;
+    if (!select_frame(sel, n, item, f, slot)) return;
     const uint32_t m0 = seg * kSegMcus;
     const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
 
@@ -120,7 +125,8 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
 
     // ---- A + B + C: one block per lane
     uint32_t c[32];
-    if (load_segment_blocks(in, f, g, my * nseg + seg, g.mcu_rows * nseg, mcu0, cnt, ok, lane, s_img, c)) {
+    bool skip;
+    if (load_segment_blocks(in, f, slot, kRound, g, my * nseg + seg, g.mcu_rows * nseg, mcu0, cnt, ok, lane, s_img, c, skip)) {
         const uint32_t m = lane / 6u, k6 = lane % 6u;
         const bool chroma = k6 >= 4u;
         // IQtIZzBlock's gather (AmvJpeg.c:1035-1042): out[nat] = coef[scan(nat)] * step[scan(nat)]
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
             *reinterpret_cast<uint4*>(dst + r * pitch) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
+    if (skip) return;   // (wave-uniform) not this launch's frame
     __syncthreads();
 
     // ---- D: StoreBuffer (AmvJpeg.c:789-840), straight to the frame.  A lane takes a 4x2-pixel patch: the two rows
@@ -225,14 +232,22 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
             d8 -= g.stride;
         }
     }
+    if (!kRound) return;
+    __syncthreads();   // the planes are free again
+    }   // next item of the round
 }
 
-void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n,
+void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameSel& sel, uint32_t items,
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
-    if (n == 0) return;
+    if (items == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
-    hipLaunchKernelGGL(amv_reconstruct_kernel, dim3(n, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok, n, g, nseg,
-                       flags, out);
+    if (sel.round) {
+        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, dim3(items > 512u ? 512u : items, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok,
+                           n, sel, g, nseg, flags, out);
+    } else {
+        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, dim3(items, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok, n, sel, g, nseg,
+                           flags, out);
+    }
 }
 
 }  // namespace amv

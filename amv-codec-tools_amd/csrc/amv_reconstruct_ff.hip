@@ -65,19 +65,25 @@ __device__ __forceinline__ void sidct_col(int& c0, int& c1, int& c2, int& c3, in
 }  // namespace
 
 // out: per frame, Y plane width*height, then Cb and Cr of ((w+1)/2) x ((h+1)/2), rows tight
+// kRound: a round launch (FrameSel::round != 0), whose workgroups walk the items of the round
+template <bool kRound>
 __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
-    SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameGeom g, uint64_t yuv_frame_bytes,
+    SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameSel sel, FrameGeom g, uint64_t yuv_frame_bytes,
     uint8_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_img[kSegMcus * 6 * 128];
     const uint32_t lane = threadIdx.x;
-    const uint32_t f = blockIdx.x, my = blockIdx.y, seg = blockIdx.z;
+    const uint32_t my = blockIdx.y, seg = blockIdx.z;
+    for (uint32_t item = blockIdx.x;; item += gridDim.x) {
+    uint32_t f, slot;
+    if (!select_frame(sel, n, item, f, slot)) return;
     const uint32_t m0 = seg * kSegMcus;
     const uint32_t cnt = min((uint32_t)kSegMcus, g.mcu_cols - m0);
     const uint32_t ok = nmcu_ok[f];
     const uint32_t mcu0 = my * g.mcu_cols + m0;
 
     uint32_t c[32];
-    if (!load_segment_blocks(in, f, g, my * gridDim.z + seg, gridDim.y * gridDim.z, mcu0, cnt, ok, lane, s_img, c)) return;
+    bool skip;
+    if (load_segment_blocks(in, f, slot, kRound, g, my * gridDim.z + seg, gridDim.y * gridDim.z, mcu0, cnt, ok, lane, s_img, c, skip)) {
     const uint32_t m = lane / 6u, k6 = lane % 6u;
     const bool chroma = k6 >= 4u;
     const bool decoded = mcu0 + m < ok;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
     const int sy = (int)((chroma ? my : 2u * my + (k6 >> 1)) * 8u);
     uint8_t* plane = out + (uint64_t)f * yuv_frame_bytes +
                      (chroma ? (uint64_t)g.width * g.height + (k6 == 5u ? (uint64_t)cw * ch : 0ull) : 0ull);
-    if (sx >= pw) return;
+    if (sx < pw) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int p = start - (sy + i);
@@ -128,6 +134,11 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
                 if (sx + j < pw) d[j] = (uint8_t)((j < 4u ? lo >> (8u * j) : hi >> (8u * (j - 4u))) & 0xffu);
         }
     }
+    }
+    }
+    if (!kRound) return;
+    __syncthreads();   // the image is free again
+    }   // next item of the round
 }
 
 // true when every row of every plane is reached by mjpegdec.c:672-677's formula (then the kernel writes each
@@ -138,12 +149,17 @@ bool yuv_store_covers_planes(const FrameGeom& g) {
     return start_y >= (int)g.height - 1 && start_c >= (int)((g.height + 1u) >> 1) - 1;
 }
 
-void launch_reconstruct_yuv(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameGeom& g,
-                            uint64_t yuv_frame_bytes, uint8_t* out, hipStream_t s) {
-    if (n == 0) return;
+void launch_reconstruct_yuv(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameSel& sel, uint32_t items,
+                            const FrameGeom& g, uint64_t yuv_frame_bytes, uint8_t* out, hipStream_t s) {
+    if (items == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
-    hipLaunchKernelGGL(amv_reconstruct_yuv_kernel, dim3(n, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok, n, g,
-                       yuv_frame_bytes, out);
+    if (sel.round) {
+        hipLaunchKernelGGL(amv_reconstruct_yuv_kernel<true>, dim3(items > 512u ? 512u : items, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks,
+                           nmcu_ok, n, sel, g, yuv_frame_bytes, out);
+    } else {
+        hipLaunchKernelGGL(amv_reconstruct_yuv_kernel<false>, dim3(items, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok, n, sel, g,
+                           yuv_frame_bytes, out);
+    }
 }
 
 }  // namespace amv

@@ -44,6 +44,7 @@ struct amvhip_ctx {
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
     uint32_t cus = 256;   // compute units of the device
     bool want_stats = false;
+    double ws_bytes_per_frame = 0.0;
     int entropy_mode = AMVHIP_ENTROPY_AUTO;
     // host-pointer staging (one in-order stream of the context's own carries every host-buffer entry point)
     DevBuf h_in, h_offs, h_lens, h_out, h_status, h_aux, a_in, a_tab, a_out;
@@ -273,20 +274,30 @@ extern "C" uint32_t amvhip_encode_bound(uint32_t w, uint32_t h) {
 
 static int size_ok(uint32_t w, uint32_t h) { return w > 0 && h > 0 && w <= 16384 && h <= 16384; }
 
-// The entropy stage into `sinks` (dense when sinks.rec == nullptr, records otherwise).
-static int entropy_stage(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offs,
+// Frames the synchronising kernel does not decode go through amv_huffman_kernel, whose output is dense coefficient
+// lines: all of them in AMVHIP_ENTROPY_SERIAL mode (and for pictures of >= 16384 blocks), else the few it hands back
+// (oversize chunks, long FF runs, more records than the record space holds).  `items` bounds the work; with a list the
+// real count sits on the device.
+struct Fallback {
+    const uint32_t* list;
+    const uint32_t* count;
+    uint32_t items;
+};
+
+// unstuffing + the synchronising kernel into `sinks` (dense when sinks.rec == nullptr, records otherwise); fb says
+// what is left for the serial kernel
+static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offs,
                          const uint32_t* d_lens, uint32_t n, const FrameGeom& g, SyncSinks sinks, int32_t* d_status,
-                         uint32_t* d_nmcu_ok, hipStream_t st) {
+                         uint32_t* d_nmcu_ok, hipStream_t st, Fallback& fb) {
     // window per frame for the unstuffed scan in the global workspace: ~1.6x the 0.2 B/pixel AMV streams
     // run at; larger chunks take the serial kernel
     uint32_t cap_bytes = ((g.width * g.height * 5u / 16u) + 1023u) & ~1023u;
     if (cap_bytes < 2048u) cap_bytes = 2048u;
     const uint32_t cap_words = cap_bytes / 4u;
-    if (c->entropy_mode == AMVHIP_ENTROPY_SERIAL || g.blocks >= 16384u) {   // (the records' block field has 14 bits)
+    if (c->entropy_mode == AMVHIP_ENTROPY_SERIAL || g.blocks >= 16384u) {
         if (sinks.rec) HIP_TRY(c, hipMemsetAsync(sinks.rec_count, 0xff, (size_t)n * 4, st));   // every frame dense
-        Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
-        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, sinks.coef, d_status, d_nmcu_ok, nullptr, nullptr, st);
-        return check_launch(c, "huffman");
+        fb = Fallback{nullptr, nullptr, n};
+        return AMVHIP_OK;
     }
     if (int r = ensure(c, c->retry, ((size_t)n + 8) * 4)) return r;   // [retry count, task counter, 6 spare | retry list n]
     if (int r = ensure(c, c->ws, (size_t)n * cap_bytes)) return r;
@@ -306,16 +317,11 @@ static int entropy_stage(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
         Timed t(c, AMVHIP_K_HUFFMAN, st);
         unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
         launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, cap_words,
-                            sinks.rec ? (int)sinks.lanes : huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height), c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1,
-                            stats, c->cus, st);
+                            sinks.rec ? (int)sinks.lanes : huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height),
+                            c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1, stats, c->cus, st);
     }
-    if (int r = check_launch(c, "huffman_sync")) return r;
-    {   // frames handed back (oversize chunks, long FF runs, too many coefficients): usually none, exits at once
-        Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
-        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, sinks.coef, d_status, d_nmcu_ok, retry_list,
-                       retry_count, st);
-    }
-    return check_launch(c, "huffman");
+    fb = Fallback{retry_list, retry_count, n};
+    return check_launch(c, "huffman_sync");
 }
 
 extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
@@ -329,29 +335,38 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     if (int r = use_device(c)) return r;
     if (n == 0) return AMVHIP_OK;
     std::lock_guard<std::mutex> lk(c->mu);
+    const FrameGeom g = make_geom(w, h);
+    hipStream_t st = (hipStream_t)stream;
     SyncSinks sinks{d_coef, nullptr, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr};
-    return entropy_stage(c, d_blob, blob_bytes, d_offs, d_lens, n, make_geom(w, h), sinks, d_status, d_nmcu_ok, (hipStream_t)stream);
+    Fallback fb;
+    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu_ok, st, fb)) return r;
+    {   // the caller's array has a place for every frame: one launch, lines at the frames' own places
+        Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
+        launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, fb.list, fb.count, 0u,
+                       fb.items, false, st);
+    }
+    return check_launch(c, "huffman");
 }
 
-static int reconstruct_stage(amvhip_ctx* c, const SyncSinks& sinks, const uint32_t* d_nmcu_ok, uint32_t n,
-                             const FrameGeom& g, uint32_t flags, uint8_t* d_out, hipStream_t st) {
-    if (flags & AMVHIP_FLAG_FFMPEG) {   // the patched FFmpeg's amv_decoder: YUVJ420P planes
-        const uint64_t fb = amvhip_yuv420_frame_bytes(g.width, g.height);
-        if (!yuv_store_covers_planes(g))  // mjpegdec.c:672-677 leaves rows of such heights unwritten: they read as zero
-            HIP_TRY(c, hipMemsetAsync(d_out, 0, fb * n, st));
-        {
-            Timed t(c, AMVHIP_K_RECON, st);
-            launch_reconstruct_yuv(sinks, d_nmcu_ok, n, g, fb, d_out, st);
-        }
-        return check_launch(c, "reconstruct_yuv");
-    }
-    if (g.stride != g.width * 3)  // row padding bytes stay zero as in AMVDec.c:283
-        HIP_TRY(c, hipMemsetAsync(d_out, 0, g.frame_bytes * n, st));
-    {
-        Timed t(c, AMVHIP_K_RECON, st);
-        launch_reconstruct(sinks, d_nmcu_ok, n, g, flags, d_out, st);
-    }
+static int reconstruct_launch(amvhip_ctx* c, const SyncSinks& sinks, const uint32_t* d_nmcu_ok, uint32_t n, const FrameSel& sel,
+                              uint32_t items, const FrameGeom& g, uint32_t flags, uint8_t* d_out, hipStream_t st) {
+    Timed t(c, AMVHIP_K_RECON, st);
+    if (flags & AMVHIP_FLAG_FFMPEG)   // the patched FFmpeg's amv_decoder: YUVJ420P planes
+        launch_reconstruct_yuv(sinks, d_nmcu_ok, n, sel, items, g, amvhip_yuv420_frame_bytes(g.width, g.height), d_out, st);
+    else
+        launch_reconstruct(sinks, d_nmcu_ok, n, sel, items, g, flags, d_out, st);
     return check_launch(c, "reconstruct");
+}
+
+// bytes of the output no kernel writes are cleared first: row padding (AMVDec.c:283), and in FFmpeg mode the plane
+// rows mjpegdec.c:672-677 leaves untouched for some heights
+static int clear_unwritten(amvhip_ctx* c, uint32_t n, const FrameGeom& g, uint32_t flags, uint8_t* d_out, hipStream_t st) {
+    if (flags & AMVHIP_FLAG_FFMPEG) {
+        if (!yuv_store_covers_planes(g)) HIP_TRY(c, hipMemsetAsync(d_out, 0, amvhip_yuv420_frame_bytes(g.width, g.height) * n, st));
+    } else if (g.stride != g.width * 3) {
+        HIP_TRY(c, hipMemsetAsync(d_out, 0, g.frame_bytes * n, st));
+    }
+    return AMVHIP_OK;
 }
 
 extern "C" int amvhip_reconstruct_dev(amvhip_ctx* c, const int16_t* d_coef, const uint32_t* d_nmcu_ok,
@@ -362,9 +377,14 @@ extern "C" int amvhip_reconstruct_dev(amvhip_ctx* c, const int16_t* d_coef, cons
     if (((uintptr_t)d_out & 3u) || ((uintptr_t)d_coef & 15u)) return fail(c, AMVHIP_ERR_ARG, "reconstruct: out must be 4-byte, coef 16-byte aligned");
     if (int r = use_device(c)) return r;
     if (n == 0) return AMVHIP_OK;
+    const FrameGeom g = make_geom(w, h);
     SyncSinks sinks{const_cast<int16_t*>(d_coef), nullptr, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr};
-    return reconstruct_stage(c, sinks, d_nmcu_ok, n, make_geom(w, h), flags, d_out, (hipStream_t)stream);
+    if (int r = clear_unwritten(c, n, g, flags, d_out, (hipStream_t)stream)) return r;
+    return reconstruct_launch(c, sinks, d_nmcu_ok, n, FrameSel{nullptr, nullptr, 0u, 0u}, n, g, flags, d_out, (hipStream_t)stream);
 }
+
+// dense coefficient lines the context keeps for frames that go through the serial kernel: a round's worth
+static uint32_t dense_round(uint32_t n) { return n <= 4096u ? n : (n / 4u > 4096u ? (n + 3u) / 4u : 4096u); }
 
 extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
                                        const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
@@ -377,13 +397,22 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     if (((uintptr_t)d_blob & 3u) || ((uintptr_t)d_out & 3u)) return fail(c, AMVHIP_ERR_ARG, "decode: blob and out must be 4-byte aligned");
     if (int r = use_device(c)) return r;
     const FrameGeom g = make_geom(w, h);
+    hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(c->mu);
-    // between the two stages coefficients travel as records (one word per DC and per non-zero AC coefficient);
-    // the dense lines are only touched by frames that go through the serial kernel
-    const uint32_t cap_rec = g.blocks * 20u;                     // a multiple of 8: frames start on 32-byte pieces
+    // Between the two stages coefficients travel as records (one word per DC and per non-zero AC coefficient).
+    // Record space per frame: 20 per block is the most the synchronising kernel is given (a frame that needs more
+    // goes to the serial kernel); a stream whose chunks are small gets proportionally less -- a record costs at
+    // least 3 bits of scan, in practice ~6 -- but never under 8 per block.  Always a multiple of 8 (32-byte pieces).
+    uint32_t cap_rec = g.blocks * 20u;
+    {
+        const uint64_t by_stream = (blob_bytes / n) * 2u;                // records, at 4 bits of scan each
+        const uint64_t floor_rec = (uint64_t)g.blocks * 8u;
+        if (by_stream < cap_rec) cap_rec = (uint32_t)((by_stream > floor_rec ? by_stream : floor_rec) + 7u) & ~7u;
+    }
     const uint32_t lanes = (uint32_t)huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height);
     const uint32_t segs = ((g.mcu_cols + 9u) / 10u) * g.mcu_rows;
-    if (int r = ensure(c, c->coef, (size_t)n * g.blocks * 128)) return r;
+    const uint32_t round = dense_round(n);
+    if (int r = ensure(c, c->coef, (size_t)round * g.blocks * 128)) return r;
     if (int r = ensure(c, c->nmcu, (size_t)n * 4)) return r;
     if (int r = ensure(c, c->rec, (size_t)n * cap_rec * 4)) return r;
     if (int r = ensure(c, c->seg_start, (size_t)n * (segs + 1) * 4)) return r;
@@ -391,11 +420,31 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     if (int r = ensure(c, c->rec_count, (size_t)n * 4)) return r;
     SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)c->rec.p, cap_rec, (uint32_t*)c->seg_start.p, (uint32_t*)c->lane_tab.p, lanes,
                     (uint32_t*)c->rec_count.p, nullptr, nullptr};
-    if (c->dense_intermediate) sinks.rec = nullptr;
-    if (int r = entropy_stage(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, (uint32_t*)c->nmcu.p, (hipStream_t)stream))
-        return r;
-    return reconstruct_stage(c, sinks, (const uint32_t*)c->nmcu.p, n, g, flags, d_out, (hipStream_t)stream);
+    uint32_t* d_nmcu = (uint32_t*)c->nmcu.p;
+    Fallback fb;
+    if (int r = clear_unwritten(c, n, g, flags, d_out, st)) return r;
+    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu, st, fb)) return r;
+    if (fb.list)   // the frames in records form (a launch that skips the others)
+        if (int r = reconstruct_launch(c, sinks, d_nmcu, n, FrameSel{nullptr, nullptr, 0u, 0u}, n, g, flags, d_out, st)) return r;
+    // The others, a round of dense lines at a time.  With a list the count is on the device: the rounds past it find
+    // nothing to do and leave at once (usually all of them: one pair of empty launches per round).
+    for (uint32_t base = 0; base < fb.items; base += round) {
+        const uint32_t items = fb.items - base < round ? fb.items - base : round;
+        {
+            Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
+            launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, sinks.coef, d_status, d_nmcu, fb.list, fb.count, base,
+                           items, true, st);
+        }
+        if (int r = check_launch(c, "huffman")) return r;
+        if (int r = reconstruct_launch(c, sinks, d_nmcu, n, FrameSel{fb.list, fb.count, base, items}, items, g, flags, d_out, st)) return r;
+    }
+    c->ws_bytes_per_frame = (double)(c->ws.cap + c->rec.cap + c->coef.cap + c->seg_start.cap + c->lane_tab.cap + c->rec_count.cap +
+                                     c->nmcu.cap + c->retry.cap + c->ws_bytes.cap) / n;
+    return AMVHIP_OK;
 }
+
+// device workspace the last amvhip_decode_batch_dev call held, in bytes per frame of that call (a diagnostic)
+extern "C" double amvhip_decode_workspace_per_frame(const amvhip_ctx* c) { return c ? c->ws_bytes_per_frame : 0.0; }
 
 extern "C" int amvhip_decode_batch_async(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
                                          const uint64_t* offs, const uint32_t* lens, uint32_t n, uint32_t w,

@@ -79,7 +79,7 @@ def make_video_stream(E, first, n, w, h):
         pos = (pos + 3) & ~3                  # keep every slice's base 4-byte aligned
         if pos > cap:
             raise SystemExit("synthetic stream overflowed its buffer")
-    return d_blob, cap, d_offs, d_lens, int(d_lens.sum().item())
+    return d_blob, pos, d_offs, d_lens, int(d_lens.sum().item())   # pos: the bytes of the blob the stream occupies
 
 
 def timed(E, step, steps, warmup):
@@ -104,13 +104,15 @@ def timed(E, step, steps, warmup):
     return E.sh.max_over_ranks(elapsed, E.dev)
 
 
-def kernel_times(E, ids, ctx=None):
+def kernel_times(E, ids, ctx=None, steps=1):
+    """per kernel: launches in the timed region and milliseconds per STEP (a step may launch a kernel more than once:
+    the decode path's fall-back rounds)"""
     ctx = ctx or E.ctx
     kern = {}
     for k in ids:
         launches, ms = ctx.prof_read(k)
         if launches:
-            kern[ctx.kernel_name(k)] = {"launches": launches, "avg_ms": ms / launches}
+            kern[ctx.kernel_name(k)] = {"launches": launches, "avg_ms": ms / max(steps, 1)}
     return kern
 
 
@@ -184,7 +186,8 @@ def run_decode(E, args):
             raise SystemExit("device-made stream differs from the oracle's encoder at frame %d" % (first + i))
 
     elapsed = timed(E, step, args.steps, args.warmup)
-    kern = kernel_times(E, (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON))
+    kern = kernel_times(E, (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON), steps=args.steps)
+    workspace = ctx.decode_workspace_per_frame()     # device bytes the context holds per frame of this batch
     ctx.entropy_stats(True)          # one extra, untimed step: how many synchronisation rounds the frames needed
     step()
     sync = ctx.entropy_stats(False)
@@ -208,6 +211,7 @@ def run_decode(E, args):
                         "per_gpu_frames_per_s": result["value"] / E.world}
     if small is not None:
         result["config"]["frames_per_s_with_10000_frames_per_step"] = small
+    result["config"]["decode_workspace_bytes_per_frame"] = workspace
     result["roofline"] = roofline(
         kern, stream_bytes + n * 3 * w * h, elapsed / args.steps,
         (lambda dom: profiled_traffic("", dom)) if (w, h, n) == (160, 120, DECODE_FRAMES) else None,
@@ -352,7 +356,7 @@ def run_encode(E, args):
         raise SystemExit("round-trip PSNR %.2f dB is below the %.1f dB floor" % (psnr, args.psnr_floor))
 
     elapsed = timed(E, step, args.steps, args.warmup)
-    kern = kernel_times(E, (pkg.K_FDCT, pkg.K_PACK, pkg.K_PACK_SERIAL, pkg.K_COMPACT))
+    kern = kernel_times(E, (pkg.K_FDCT, pkg.K_PACK, pkg.K_PACK_SERIAL, pkg.K_COMPACT), steps=args.steps)
     result = base_result(E, args, "AMV frames/sec/GPU (%dx%d encode, PSNR-checked round trip)" % (w, h), "frames/s", n, elapsed)
     result["config"] = {"workload": "%dx%d AMV encode (rgb24 -> yuvj420p, fdct, quantise, Huffman), %d synthetic frames per GPU "
                                     "resident in HBM" % (w, h, n),
@@ -461,8 +465,8 @@ def run_adpcm(E, args, with_video=False):
     elapsed = timed(E, step, args.steps, args.warmup)
     audio_bytes = na * (clen + 2 * spf)
     if with_video:
-        kern = kernel_times(E, (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON))
-        audio_kern = kernel_times(E, (pkg.K_ADPCM_DEC, pkg.K_ADPCM_ENC), actx)   # on the second stream, overlapped with the video kernels
+        kern = kernel_times(E, (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON), steps=args.steps)
+        audio_kern = kernel_times(E, (pkg.K_ADPCM_DEC, pkg.K_ADPCM_ENC), actx, steps=args.steps)   # on the second stream, overlapped with the video kernels
         result = base_result(E, args, "AMV frames/sec/GPU (%dx%d decode with co-resident IMA-ADPCM, bit-exact)" % (w, h),
                              "frames/s", n, elapsed)
         result["config"] = {"workload": "%dx%d AMV decode of %d frames per GPU on one HIP stream, IMA-ADPCM encode + decode of "
@@ -472,7 +476,7 @@ def run_adpcm(E, args, with_video=False):
         result["roofline"] = roofline(kern, stream_bytes + n * 3 * w * h, elapsed / args.steps, None,
                                       {"co_resident_audio_kernels": audio_kern, "audio_algorithmic_bytes_per_step": audio_bytes})
     else:
-        kern = kernel_times(E, (pkg.K_ADPCM_DEC, pkg.K_ADPCM_ENC))
+        kern = kernel_times(E, (pkg.K_ADPCM_DEC, pkg.K_ADPCM_ENC), steps=args.steps)
         result = base_result(E, args, "IMA-ADPCM samples/sec/GPU (encode + decode, bit-exact)", "samples/s", 2 * na * spf, elapsed)
         result["dtype"] = "int32"
         result["config"] = {"workload": "%d AMV audio chunks of %d samples per GPU: PCM -> ADPCM (step index carried through "

@@ -209,6 +209,9 @@ int amvhip_decode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64_t blo
                             uint32_t width, uint32_t height, uint32_t flags,
                             uint8_t *d_out, int32_t *d_status, void *stream);
 
+/* device workspace the context held for the last amvhip_decode_batch_dev call, in bytes per frame of that call */
+double amvhip_decode_workspace_per_frame(const amvhip_ctx *ctx);
+
 /* Same with host buffers: H2D, decode, D2H, synchronous. */
 int amvhip_decode_batch(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_bytes,
                         const uint64_t *offs, const uint32_t *lens, uint32_t n,

@@ -1013,3 +1013,37 @@ def test_amvlib_readahead_semantics(ctx, pkg, orc, amv1, tmp_path):
     pos = amv.contents.fileseekpos
     assert lib.AmvReadNextFrame(amv) == -1 and amv.contents.fileseekpos == pos
     lib.AmvClose(amv)
+
+
+def test_decode_fallback_rounds(ctx, pkg, orc):
+    """frames that go through the serial kernel are reconstructed a round of dense lines at a time (the context keeps
+    lines for 4096 frames or a quarter of the batch, not for all of it): 9000 small frames, more than half of them
+    handed back by the unstuffer (a run of FF bytes longer than its look-back), and the whole batch again in
+    AMVHIP_ENTROPY_SERIAL mode -- every frame and status against the oracle, in both output modes"""
+    w, h, n = 32, 16, 9000
+    rng = np.random.default_rng(99)
+    base = [orc.encode_frame(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), w, h) for _ in range(40)]
+    chunks = []
+    for i in range(n):
+        c = base[i % 40]
+        if i % 9 < 5:   # a long run of FF FF ... in the scan: invalid, but every decoder must agree on what it does
+            cut = 10 + (i % 17)
+            c = c[:cut] + b"\\xff" * 12 + c[cut:]
+        chunks.append(c)
+    uniq = {}
+    for c in set(chunks):
+        uniq[c] = (orc.decode_frame(c, w, h)[:2], orc.decode_frame_ffmpeg(c, w, h)[:2])
+    for flags, pick in ((0, 0), (pkg.FLAG_FFMPEG, 1)):
+        for mode in (pkg.ENTROPY_AUTO, pkg.ENTROPY_SERIAL):
+            ctx.set_entropy_mode(mode)
+            try:
+                got, st = (_gpu_decode(ctx, chunks, w, h) if not flags else _gpu_decode_ffmpeg(ctx, pkg, chunks, w, h))
+            finally:
+                ctx.set_entropy_mode(pkg.ENTROPY_AUTO)
+            for i in range(n):
+                want, wst = uniq[chunks[i]][pick]
+                assert st[i] == wst and (got[i].ravel() == want.ravel()).all(), (flags, mode, i)
+    fresh = pkg.Context(0)   # buffers only grow: a context of its own shows what this batch needs
+    _gpu_decode(fresh, chunks, w, h)
+    assert 0 < fresh.decode_workspace_per_frame() < 16 * 1024
+    fresh.close()
