@@ -49,6 +49,8 @@
 // the frame, nmcu_ok counts whole MCUs before it, TRUNCATED compares consumed with stored bits.
 // Chunks larger than the per-frame workspace window, or with a run of FF bytes longer than the 8-byte
 // look-back of the unstuffer (never in a valid stream), are queued for amv_huffman_kernel.
+#include <atomic>
+
 #include "amv_kernels.h"
 
 namespace amv {
@@ -695,11 +697,15 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
                  uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
     constexpr uint32_t kMaxWaves = (uint32_t)waves_per_group(kRec);
     constexpr uint32_t kPerWave = kRingWords * kWave * 4u + (kRec ? kStageSlots * kWave * 4u : 0u);
-    static bool raised = false;
-    if (!raised) {
+    // the attribute belongs to the device's copy of the function: once per device and instantiation
+    static std::atomic<uint64_t> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L, kRec>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTableBytes + kMaxWaves * kPerWave));
-        raised = true;
+        raised.fetch_or(bit, std::memory_order_relaxed);
     }
     // Workgroups: as many as the chip holds (the rest of the tasks come from the queue); a batch that does not fill
     // them gets smaller workgroups, so that its waves spread over all the compute units instead of filling a few.

@@ -116,20 +116,24 @@ def kernel_times(E, ids, ctx=None, steps=1):
     return kern
 
 
+TRAFFIC_ROUND = "r02"   # profiles/<round>_traffic*.json: this round's PMC passes (tools/profile_round.sh)
+
+
 def profiled_traffic(tag, dom):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of this same command
-    (tools/summarize_pmc.py -> profiles/r01_traffic*.json); only quoted for the workload that was profiled"""
+    """HBM bytes per launch of the dominant kernel from the PMC passes of this same command (tools/summarize_pmc.py ->
+    profiles/r02_traffic*.json, one row per kernel and grid size; the timed batch is the largest grid) and where the
+    figure comes from: it is a profile of the commit named there, not a measurement of this run."""
+    path = os.path.join(ROOT, "profiles", "%s_traffic%s.json" % (TRAFFIC_ROUND, tag))
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic%s.json" % tag)))
-        # several instantiations of a template may show up (the 10 000-frame extra runs another one): the
-        # timed batch is the big one
+        prof = json.load(open(path))
         hits = [rec["hbm_corrected"] for kname, rec in prof["kernels"].items()
-                if kname.split("<")[0].endswith(dom) and rec["hbm_corrected"] > 1e6]
+                if kname.split(" grid=")[0].split("<")[0].endswith(dom) and rec["hbm_corrected"] > 1e6]
         if hits:
-            return max(hits)
+            return max(hits), {"file": os.path.relpath(path, ROOT), "head": prof.get("head", ""),
+                               "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + WRITE_SIZE, separate passes"}
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
 def cpu_cores():
@@ -147,12 +151,17 @@ def base_result(E, args, metric, unit, units_per_step_per_gpu, elapsed):
 
 
 def roofline(kern, algo_bytes, elapsed_per_step, traffic, extra=None):
+    """achieved / frac: the path's algorithmic bytes per launch over the dominant kernel's time, as the bench contract
+    defines them; path_achieved / path_frac: the same bytes over the whole step (every kernel of the path), the
+    figure to read the path by"""
     dom = max(kern, key=lambda name: kern[name]["avg_ms"])
     achieved = algo_bytes / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+    tr, src = traffic(dom) if callable(traffic) else (traffic, None)
+    path = algo_bytes / elapsed_per_step / 1e9
     r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic(dom) if callable(traffic) else traffic,
+         "frac": achieved / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
          "algorithmic_bytes_per_launch": algo_bytes, "kernels": kern,
-         "path_achieved": algo_bytes / elapsed_per_step / 1e9}
+         "path_achieved": path, "path_frac": path / HBM_PEAK_GBS}
     if extra:
         r.update(extra)
     return r

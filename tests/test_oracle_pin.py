@@ -342,3 +342,16 @@ def test_ffmpeg_compat_decode_properties(orc, amv1):
                 r = start - p
                 want = full[r, : plane.shape[1]] if 0 <= r < full.shape[0] else np.zeros(plane.shape[1], np.uint8)
                 assert (plane[p] == want).all(), (w, h, comp, p)
+
+
+def test_oracle_under_sanitizers(amv1):
+    """the restatement, built with -fsanitize=address,undefined, over every chunk of the reference
+    clip, truncated / damaged / random chunks, wrong geometries and the encoders -- where the reference itself reads out
+    of bounds (AdpcmIma.c:225-237, AmvJpeg.c:967-969,1167) the oracle must define the outcome without doing so"""
+    import subprocess
+    here = os.path.join(os.path.dirname(GOLDEN), "..", "oracle")
+    subprocess.run(["make", "-C", here, "-s", "sanitize"], check=True)
+    out = subprocess.run([os.path.join(here, "sanitize_main"), amv1["path"]], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "sanitized: 252 video chunks, 252 audio chunks" in out.stdout

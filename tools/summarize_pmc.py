@@ -26,7 +26,9 @@ def collect(d, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter or "amv::" not in r["Kernel_Name"]:
             continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        # one row per kernel AND launch shape: a template may run at several batch sizes in one process (the
+        # bench's untimed 10 000-frame extra), and a median over all of them would describe none
+        name = "%s grid=%s" % (r["Kernel_Name"].split("(")[0].replace("void ", "").strip(), r["Grid_Size"])
         vals[name].append(float(r["Counter_Value"]))
         rows.append((name, r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["Counter_Value"]))
     with open("%s_pmc_%s.csv" % (tag, counter.lower()), "w") as f:
@@ -38,7 +40,13 @@ def collect(d, counter):
 
 fetch = collect(fetch_dir, "FETCH_SIZE")
 write = collect(write_dir, "WRITE_SIZE")
-out = {"unit": "bytes per launch", "fetch_correction": "FETCH_SIZE x2 (gfx950 wide-read undercount)", "kernels": {}}
+import subprocess
+try:
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+except OSError:
+    head = ""
+out = {"unit": "bytes per launch (median over the launches of one grid size)", "fetch_correction": "FETCH_SIZE x2 (gfx950 wide-read undercount)",
+       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/profile_round.sh)", "head": head, "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     fr, wr = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
     out["kernels"][k] = {"fetch_raw": fr, "write": wr, "hbm_corrected": 2 * fr + wr}
