@@ -103,6 +103,8 @@ SYMBOLS = {
     "amvhip_encode_batch": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp]),
     "amvhip_encode_yuv420_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "amvhip_encode_yuv420_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp]),
+    "amvhip_resample_yuv420_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _vp]),
+    "amvhip_encode_yuv420_scaled_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "amvhip_encode_coefs_dev": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_adpcm_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "amvhip_adpcm_encode_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),

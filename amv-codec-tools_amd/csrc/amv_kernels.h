@@ -101,6 +101,21 @@ bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const
 void launch_compact(const uint8_t* tmp, uint32_t bound, uint32_t* lens, uint32_t n,
                     uint64_t* offs, uint8_t* blob, uint64_t blob_cap, int32_t* overflow, hipStream_t s);
 
+// ---- picture rescale (amv_resample.hip): img_resample of libavcodec/imgresample.c ------------------------
+struct ResamplePlanes {     // YUV420P frames: frame i's planes at y + i*y_frame, cb/cr + i*c_frame; chroma (w>>1) x (h>>1)
+    uint8_t* y;
+    uint8_t* cb;
+    uint8_t* cr;
+    uint32_t y_stride, c_stride;
+    uint64_t y_frame, c_frame;
+    uint32_t width, height;
+};
+struct ResampleFilters {    // img_resample_full_init (:425-472): 16 phases x 4 taps each way, 16.16 increments
+    int16_t h[64], v[64];
+    int h_incr, v_incr;
+};
+void launch_resample(const ResamplePlanes& src, const ResamplePlanes& dst, const ResampleFilters& f, uint32_t n, hipStream_t s);
+
 // ---- ADPCM --------------------------------------------------------------------------------
 void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
                          const uint32_t* lens, uint32_t n, int16_t* pcm, const uint64_t* pcm_offs,

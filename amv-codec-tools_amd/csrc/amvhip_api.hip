@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #include <mutex>
@@ -39,7 +40,7 @@ struct amvhip_ctx {
     HuffDecodeImage* d_dec = nullptr;
     HuffEncodeImage* d_enc = nullptr;
     // workspace
-    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count;
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count, scaled;
     bool dense_intermediate = false;   // AMVHIP_DENSE=1: dense coefficient lines between the decode stages (experiments)
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
     uint32_t cus = 256;   // compute units of the device
@@ -248,7 +249,7 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out})
+                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -657,6 +658,84 @@ extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const
                                                (uint32_t*)c->h_lens.p, hs))
         return r;
     return encode_fetch(c, hs, n, blob, blob_cap, offs, lens);
+}
+
+// =============================================================================================
+// picture rescale
+// =============================================================================================
+
+// av_build_filter(filter, factor, NB_TAPS = 4, NB_PHASES = 16, 1 << FILTER_BITS, type 0) -- libavcodec/resample2.c:93-140
+// as img_resample_full_init calls it (imgresample.c:468-471): cubic, first-order derivative -0.5, every phase
+// normalised to 256; host arithmetic in double / float exactly as there.
+static void build_resample_filter(int16_t* filter, uint32_t out_size, uint32_t in_size) {
+    double factor = (float)out_size / (float)in_size;
+    if (factor > 1.0) factor = 1.0;                          // upsampling only interpolates
+    for (int ph = 0; ph < 16; ++ph) {
+        double tab[4], norm = 0;
+        for (int i = 0; i < 4; ++i) {
+            const float d = -0.5f;
+            const double x = fabs(((double)(i - 1) - (double)ph / 16) * factor);
+            const double y = x < 1.0 ? 1 - 3 * x * x + 2 * x * x * x + d * (-x * x + x * x * x)
+                                     : d * (-4 + 8 * x - 5 * x * x + x * x * x);
+            tab[i] = y;
+            norm += y;
+        }
+        for (int i = 0; i < 4; ++i) {
+            const long v = lrintf((float)(tab[i] * 256 / norm));
+            filter[ph * 4 + i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+        }
+    }
+}
+
+extern "C" int amvhip_resample_yuv420_dev(amvhip_ctx* c, const uint8_t* d_src_y, const uint8_t* d_src_cb, const uint8_t* d_src_cr,
+                                          uint32_t src_y_stride, uint32_t src_c_stride, uint64_t src_y_frame, uint64_t src_c_frame,
+                                          uint32_t src_w, uint32_t src_h, uint8_t* d_dst_y, uint8_t* d_dst_cb, uint8_t* d_dst_cr,
+                                          uint32_t dst_y_stride, uint32_t dst_c_stride, uint64_t dst_y_frame, uint64_t dst_c_frame,
+                                          uint32_t dst_w, uint32_t dst_h, uint32_t n, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(src_w, src_h) || !size_ok(dst_w, dst_h) || src_w < 2 || src_h < 2 || dst_w < 2 || dst_h < 2 ||
+        src_y_stride < src_w || src_c_stride < src_w / 2 || dst_y_stride < dst_w || dst_c_stride < dst_w / 2 ||
+        (n && (!d_src_y || !d_src_cb || !d_src_cr || !d_dst_y || !d_dst_cb || !d_dst_cr)))
+        return fail(c, AMVHIP_ERR_ARG, "resample: bad argument");
+    if (n == 0) return AMVHIP_OK;
+    if (n > 65535u) return fail(c, AMVHIP_ERR_ARG, "resample: at most 65535 frames per call");
+    if (int r = use_device(c)) return r;
+    ResampleFilters f;
+    f.h_incr = (int)(((uint64_t)src_w << 16) / dst_w);      // imgresample.c:465-466
+    f.v_incr = (int)(((uint64_t)src_h << 16) / dst_h);
+    build_resample_filter(f.h, dst_w, src_w);
+    build_resample_filter(f.v, dst_h, src_h);
+    ResamplePlanes src{const_cast<uint8_t*>(d_src_y), const_cast<uint8_t*>(d_src_cb), const_cast<uint8_t*>(d_src_cr), src_y_stride,
+                       src_c_stride, src_y_frame, src_c_frame, src_w, src_h};
+    ResamplePlanes dst{d_dst_y, d_dst_cb, d_dst_cr, dst_y_stride, dst_c_stride, dst_y_frame, dst_c_frame, dst_w, dst_h};
+    launch_resample(src, dst, f, n, (hipStream_t)stream);
+    return check_launch(c, "resample");
+}
+
+// rescale + encode in one call: what ffmpeg.c:757-814 does per picture (sws_scale, then avcodec_encode_video) for a
+// source that is not the target size.  The rescaled planes live in the context's workspace.
+extern "C" int amvhip_encode_yuv420_scaled_batch_dev(amvhip_ctx* c, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
+                                                     uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                                     uint64_t c_frame_stride, uint32_t src_w, uint32_t src_h, uint32_t n,
+                                                     uint32_t w, uint32_t h, uint32_t qbias, uint8_t* d_blob, uint64_t blob_cap,
+                                                     uint64_t* d_offs, uint32_t* d_lens, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if ((w & 1) || (h & 1)) return fail(c, AMVHIP_ERR_ARG, "encode_scaled: width/height must be even");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    const uint64_t fb = (uint64_t)w * h + 2ull * (w / 2) * (h / 2);
+    uint8_t* p;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (int r = ensure(c, c->scaled, fb * n)) return r;
+        p = (uint8_t*)c->scaled.p;
+    }
+    if (int r = amvhip_resample_yuv420_dev(c, d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride, src_w, src_h, p,
+                                           p + (uint64_t)w * h, p + (uint64_t)w * h + (uint64_t)(w / 2) * (h / 2), w, w / 2, fb, fb, w, h,
+                                           n, stream))
+        return r;
+    return amvhip_encode_yuv420_batch_dev(c, p, p + (uint64_t)w * h, p + (uint64_t)w * h + (uint64_t)(w / 2) * (h / 2), w, w / 2, fb, fb, n,
+                                          w, h, qbias, d_blob, blob_cap, d_offs, d_lens, stream);
 }
 
 // =============================================================================================

@@ -296,6 +296,26 @@ int amvhip_encode_yuv420_batch(amvhip_ctx *ctx, const uint8_t *y, const uint8_t 
                                uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
                                uint64_t c_frame_stride, uint32_t n, uint32_t width, uint32_t height,
                                uint32_t qbias, uint8_t *blob, uint64_t blob_cap, uint64_t *offs, uint32_t *lens);
+/*
+ * The picture rescaler in front of the encoder: img_resample (libavcodec/imgresample.c:474-495), the arithmetic of
+ * the sws_scale shim (:599) ffmpeg.c:757 runs when the source is not the target size (AMVmuxer/Makefile:15-17 asks for
+ * -s 160x120): four-tap, 16-phase polyphase filter built as av_build_filter does (resample2.c:93-140), horizontal pass
+ * into bytes, vertical pass over four such lines, edges repeated; the luma increments and filters also serve the
+ * chroma planes, which are (w >> 1) x (h >> 1).  YUV420P frames in, YUV420P frames out, plane layout as in
+ * amvhip_encode_yuv420_batch_dev; at most 65535 frames per call.  Byte-identical to the reference's routine.
+ */
+int amvhip_resample_yuv420_dev(amvhip_ctx *ctx, const uint8_t *d_src_y, const uint8_t *d_src_cb, const uint8_t *d_src_cr,
+                               uint32_t src_y_stride, uint32_t src_c_stride, uint64_t src_y_frame_stride,
+                               uint64_t src_c_frame_stride, uint32_t src_width, uint32_t src_height,
+                               uint8_t *d_dst_y, uint8_t *d_dst_cb, uint8_t *d_dst_cr,
+                               uint32_t dst_y_stride, uint32_t dst_c_stride, uint64_t dst_y_frame_stride,
+                               uint64_t dst_c_frame_stride, uint32_t dst_width, uint32_t dst_height, uint32_t n, void *stream);
+/* rescale to width x height, then encode: one call for ffmpeg.c's sws_scale + avcodec_encode_video pair (:757-814) */
+int amvhip_encode_yuv420_scaled_batch_dev(amvhip_ctx *ctx, const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr,
+                                          uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                          uint64_t c_frame_stride, uint32_t src_width, uint32_t src_height, uint32_t n,
+                                          uint32_t width, uint32_t height, uint32_t qbias, uint8_t *d_blob,
+                                          uint64_t blob_cap, uint64_t *d_offs, uint32_t *d_lens, void *stream);
 /* Stage access: quantised coefficients (zig-zag order, not predicted), n*nmcu*6*64 int16 */
 int amvhip_encode_coefs_dev(amvhip_ctx *ctx, const uint8_t *d_pix, uint32_t pix_stride, int is_bgr,
                             uint32_t n, uint32_t width, uint32_t height, uint32_t qbias,

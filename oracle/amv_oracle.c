@@ -560,6 +560,94 @@ int amvo_decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uin
 }
 
 /* ------------------------------------------------------------------------------------
+ * picture rescale: img_resample (lavc/imgresample.c:340-505), the routine behind the sws_scale shim
+ * (:515-660) that ffmpeg.c:757 calls before amv_encode_picture when the source is not 160x120.
+ * Four-tap polyphase filter, 16 phases, 16.16 positions; every line is filtered horizontally into
+ * bytes (clipped), then four such lines vertically (clipped again).
+ * ---------------------------------------------------------------------------------- */
+#define RS_PHASE_BITS 4
+#define RS_TAPS 4
+#define RS_POS_BITS 16
+#define RS_FILTER_BITS 8
+
+/* av_build_filter(filter, factor, 4, 16, 256, 0) -- lavc/resample2.c:93-140, type 0 = cubic, d = -0.5 */
+void amvo_build_resample_filter(int16_t filter[16 * 4], int out_size, int in_size)
+{
+    double factor = (float)out_size / (float)in_size;               /* imgresample.c:468-471 */
+    const int center = (RS_TAPS - 1) / 2;
+    if (factor > 1.0) factor = 1.0;                                  /* resample2.c:100-101 */
+    for (int ph = 0; ph < 16; ph++) {
+        double tab[RS_TAPS], norm = 0;
+        for (int i = 0; i < RS_TAPS; i++) {
+            const float d = -0.5f;
+            double x = fabs(((double)(i - center) - (double)ph / 16) * factor), y;
+            if (x < 1.0) y = 1 - 3 * x * x + 2 * x * x * x + d * (-x * x + x * x * x);
+            else y = d * (-4 + 8 * x - 5 * x * x + x * x * x);
+            tab[i] = y;
+            norm += y;
+        }
+        for (int i = 0; i < RS_TAPS; i++) {
+            long v = lrintf((float)(tab[i] * 256 / norm));           /* :137 */
+            filter[ph * RS_TAPS + i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+        }
+    }
+}
+
+static inline int rs_phase(int pos) { return (pos >> (RS_POS_BITS - RS_PHASE_BITS)) & 15; }
+static inline uint8_t rs_clip(int sum) { sum >>= RS_FILTER_BITS; return (uint8_t)(sum < 0 ? 0 : (sum > 255 ? 255 : sum)); }
+
+/* one output sample of h_resample (:312-339; the slow form :288-310 is the general one, the fast forms are the
+ * same sums where no clamping is needed) */
+static uint8_t rs_h(const uint8_t *src, int iw, int x, int h_incr, const int16_t *hf)
+{
+    const int pos = -(1 << RS_POS_BITS) + x * h_incr;               /* src_start = -FCENTER * POS_FRAC, :367 */
+    const int s0 = pos >> RS_POS_BITS;
+    const int16_t *f = hf + rs_phase(pos) * RS_TAPS;
+    int sum = 0;
+    for (int j = 0; j < RS_TAPS; j++) {
+        int s = s0 + j;
+        s = s < 0 ? 0 : (s >= iw ? iw - 1 : s);
+        sum += src[s] * f[j];
+    }
+    return rs_clip(sum);
+}
+
+/* component_resample (:341-405) */
+void amvo_resample_plane(const uint8_t *in, int iwrap, int iw, int ih, uint8_t *out, int owrap, int ow, int oh,
+                         int h_incr, int v_incr, const int16_t *hf, const int16_t *vf)
+{
+    for (int y = 0; y < oh; y++) {
+        const int src_y = 2 * (1 << RS_POS_BITS) + y * v_incr;      /* (last_src_y + NB_TAPS) * POS_FRAC, :350 */
+        const int y1 = src_y >> RS_POS_BITS;
+        const int16_t *f = vf + rs_phase(src_y) * RS_TAPS;
+        for (int x = 0; x < ow; x++) {
+            int sum = 0;
+            for (int j = 0; j < RS_TAPS; j++) {
+                int line = y1 - 3 + j;                               /* the ring's last four lines, :400 */
+                line = line < 0 ? 0 : (line >= ih ? ih - 1 : line);  /* :361-366 */
+                sum += rs_h(in + (size_t)line * iwrap, iw, x, h_incr, hf) * f[j];
+            }
+            out[(size_t)y * owrap + x] = rs_clip(sum);
+        }
+    }
+}
+
+/* img_resample (:474-495) on tight YUV420P planes: Y iw x ih, then Cb, Cr of (iw >> 1) x (ih >> 1) */
+void amvo_img_resample_yuv420(const uint8_t *in, int iw, int ih, uint8_t *out, int ow, int oh)
+{
+    int16_t hf[64], vf[64];
+    const int h_incr = (iw * (1 << RS_POS_BITS)) / ow, v_incr = (ih * (1 << RS_POS_BITS)) / oh;   /* :465-466 */
+    amvo_build_resample_filter(hf, ow, iw);
+    amvo_build_resample_filter(vf, oh, ih);
+    const size_t iy = (size_t)iw * ih, ic = (size_t)(iw >> 1) * (ih >> 1);
+    const size_t oy = (size_t)ow * oh, oc = (size_t)(ow >> 1) * (oh >> 1);
+    amvo_resample_plane(in, iw, iw, ih, out, ow, ow, oh, h_incr, v_incr, hf, vf);
+    for (int c = 0; c < 2; c++)
+        amvo_resample_plane(in + iy + c * ic, iw >> 1, iw >> 1, ih >> 1, out + oy + c * oc, ow >> 1, ow >> 1, oh >> 1,
+                            h_incr, v_incr, hf, vf);
+}
+
+/* ------------------------------------------------------------------------------------
  * IMA ADPCM
  * ---------------------------------------------------------------------------------- */
 static const int8_t k_index_table[16] = { -1, -1, -1, -1, 2, 4, 6, 8, -1, -1, -1, -1, 2, 4, 6, 8 }; /* AdpcmIma.c:20-23 */

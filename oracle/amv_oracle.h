@@ -85,6 +85,15 @@ uint32_t amvo_yuv420_frame_bytes(uint32_t w, uint32_t h);
 int amvo_decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
                              uint8_t *out, uint32_t *nmcu_ok, uint32_t *status);
 
+/* ---- picture rescale (the sws_scale shim of libavcodec/imgresample.c) ---------------- */
+/* av_build_filter (resample2.c:93-140) as img_resample_full_init calls it (imgresample.c:468-471): 16 phases x 4 taps */
+void amvo_build_resample_filter(int16_t filter[64], int out_size, int in_size);
+/* component_resample (imgresample.c:341-405) of one plane */
+void amvo_resample_plane(const uint8_t *in, int iwrap, int iw, int ih, uint8_t *out, int owrap, int ow, int oh,
+                         int h_incr, int v_incr, const int16_t *hf, const int16_t *vf);
+/* img_resample (:474-495): tight YUV420P frame iw x ih -> ow x oh (chroma planes (w >> 1) x (h >> 1)) */
+void amvo_img_resample_yuv420(const uint8_t *in, int iw, int ih, uint8_t *out, int ow, int oh);
+
 /* ---- IMA ADPCM (AMV layout) ------------------------------------------------------ */
 /* AmvAudioDecode header parse (AMVDec.c:312-320) + AdpcmImaDecodeFrame (AdpcmIma.c:206-242)
  * with AdpcmImaExpandNibble (:170-204).  Writes 2*(len-8) samples (the defined part,

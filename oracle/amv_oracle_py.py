@@ -57,6 +57,8 @@ def lib():
             "amvo_ffmpeg_dequant_block": (None, [_vp, _int, _vp]),
             "amvo_yuv420_frame_bytes": (_u32, [_u32, _u32]),
             "amvo_decode_frame_ffmpeg": (_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+            "amvo_build_resample_filter": (None, [_vp, _int, _int]),
+            "amvo_img_resample_yuv420": (None, [_vp, _int, _int, _vp, _int, _int]),
             "amvo_adpcm_decode_chunk": (_int, [_vp, _u32, _vp, _vp]),
             "amvo_adpcm_encode_chunk": (_int, [_vp, _u32, ctypes.POINTER(_int), _vp]),
             "amvo_adpcm_wav_encode_frame": (_int, [_vp, _int, _vp, _vp]),
@@ -117,6 +119,8 @@ def avcref():
         R.amvref_sp5x_segment.argtypes = [_int, _vp, _int]
         R.amvref_mjpeg_huffman_spec.restype = _int
         R.amvref_mjpeg_huffman_spec.argtypes = [_int, _vp, _vp]
+        R.amvref_img_resample.restype = _int
+        R.amvref_img_resample.argtypes = [_vp, _int, _int, _vp, _int, _int]
         R.amvref_mjpeg_huffman_codes.restype = None
         R.amvref_mjpeg_huffman_codes.argtypes = [_int, _vp, _vp]
         _avcref = R
@@ -181,6 +185,18 @@ def yuv_planes(buf, w, h):
     cw, ch = (w + 1) // 2, (h + 1) // 2
     return (buf[: w * h].reshape(h, w), buf[w * h: w * h + cw * ch].reshape(ch, cw),
             buf[w * h + cw * ch: w * h + 2 * cw * ch].reshape(ch, cw))
+
+
+def yuv420_bytes(w, h):
+    return w * h + 2 * (w // 2) * (h // 2)
+
+
+def img_resample_yuv420(frame, iw, ih, ow, oh):
+    """tight YUV420P frame (uint8 [iw*ih + 2*(iw/2)*(ih/2)]) -> the same at ow x oh (reference img_resample)"""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    out = np.zeros(yuv420_bytes(ow, oh), np.uint8)
+    lib().amvo_img_resample_yuv420(frame.ctypes.data, iw, ih, out.ctypes.data, ow, oh)
+    return out
 
 
 def encode_frame(pix, w, h, bgr=False, qbias=0, want_coef=False):

@@ -13,6 +13,9 @@
  *                           of simple_idct_put :390, which only adds the clip to 0..255)   (row a15)
  *   libavcodec/sp5x.h       sp5x_quant_table[10], [11] = the "Q60" tables sp5xdec.c:60-61 puts into the
  *                           JFIF it hands to the MJPEG decoder, and its DHT/SOF/SOS images  (row a14)
+ *   libavcodec/imgresample.c img_resample_full_init :425, img_resample :474 (component_resample :341, h_resample
+ *                           :312, v_resample :119) -- the rescaler behind the sws_scale shim    (row f3)
+ *   libavcodec/resample2.c  av_build_filter :93, which builds its polyphase filters
  *   libavutil/mem.c, mathematics.c  av_malloc/av_free, ff_log2_tab
  *
  * The structures (MpegEncContext, MJpegContext, PutBitContext) are the reference's, from its own headers.
@@ -36,6 +39,7 @@
 #include "mjpegenc.h"
 #include "simple_idct.h"
 #include "sp5x.h"
+#include "swscale.h"   /* libswscale/swscale.h: what imgresample.c itself includes for its shim */
 
 #define EXPORT __attribute__((visibility("default")))
 
@@ -132,4 +136,28 @@ EXPORT void amvref_mjpeg_huffman_codes(int t, uint8_t size[256], uint16_t code[2
     memset(code, 0, 512);
     amvref_mjpeg_huffman_spec(t, bits, vals);
     ff_mjpeg_build_huffman_codes(size, code, bits, vals);
+}
+
+/* img_resample on tight YUV420P frames: in = Y iw x ih, Cb, Cr (iw/2 x ih/2); out likewise at ow x oh */
+EXPORT int amvref_img_resample(const uint8_t *in, int iw, int ih, uint8_t *out, int ow, int oh)
+{
+    ImgReSampleContext *s = img_resample_init(ow, oh, iw, ih);
+    AVPicture src, dst;
+    if (!s)
+        return -1;
+    memset(&src, 0, sizeof src);
+    memset(&dst, 0, sizeof dst);
+    src.data[0] = (uint8_t *)in;
+    src.data[1] = src.data[0] + iw * ih;
+    src.data[2] = src.data[1] + (iw / 2) * (ih / 2);
+    src.linesize[0] = iw;
+    src.linesize[1] = src.linesize[2] = iw / 2;
+    dst.data[0] = out;
+    dst.data[1] = dst.data[0] + ow * oh;
+    dst.data[2] = dst.data[1] + (ow / 2) * (oh / 2);
+    dst.linesize[0] = ow;
+    dst.linesize[1] = dst.linesize[2] = ow / 2;
+    img_resample(s, &dst, &src);
+    img_resample_close(s);
+    return 0;
 }

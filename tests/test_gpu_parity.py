@@ -1047,3 +1047,48 @@ def test_decode_fallback_rounds(ctx, pkg, orc):
     _gpu_decode(fresh, chunks, w, h)
     assert 0 < fresh.decode_workspace_per_frame() < 16 * 1024
     fresh.close()
+
+
+def test_resample_matches_oracle(ctx, orc):
+    """the rescaler in front of the encoder (imgresample.c img_resample, pinned by the reference's own object in
+    tests/test_oracle_pin.py) on padded device planes, and the one-call rescale + encode == rescale, then encode"""
+    import torch
+    lib_call = ctx.lib.amvhip_resample_yuv420_dev
+    rng = np.random.default_rng(17)
+    for iw, ih, ow, oh, n in ((640, 480, 160, 120, 3), (320, 240, 160, 120, 4), (176, 144, 160, 120, 2), (160, 120, 320, 240, 2),
+                              (130, 98, 64, 48, 3), (162, 122, 160, 120, 2)):
+        icw, ich, ocw, och = iw // 2, ih // 2, ow // 2, oh // 2
+        ys, cs = iw + 16, icw + 8
+        Y = rng.integers(0, 256, (n, ih, ys), dtype=np.uint8)
+        Cb = rng.integers(0, 256, (n, ich, cs), dtype=np.uint8)
+        Cr = rng.integers(0, 256, (n, ich, cs), dtype=np.uint8)
+        dY, dCb, dCr = _t(Y), _t(Cb), _t(Cr)
+        oys, ocs = ow + 4, ocw + 4
+        oY = torch.full((n, oh, oys), 0x5A, dtype=torch.uint8, device="cuda:0")
+        oCb = torch.full((n, och, ocs), 0x5A, dtype=torch.uint8, device="cuda:0")
+        oCr = torch.full((n, och, ocs), 0x5A, dtype=torch.uint8, device="cuda:0")
+        rc = lib_call(ctx.h, dY.data_ptr(), dCb.data_ptr(), dCr.data_ptr(), ys, cs, ih * ys, ich * cs, iw, ih,
+                      oY.data_ptr(), oCb.data_ptr(), oCr.data_ptr(), oys, ocs, oh * oys, och * ocs, ow, oh, n, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        gY, gCb, gCr = oY.cpu().numpy(), oCb.cpu().numpy(), oCr.cpu().numpy()
+        for t in range(n):
+            tight = np.concatenate([Y[t, :, :iw].ravel(), Cb[t, :, :icw].ravel(), Cr[t, :, :icw].ravel()])
+            want = orc.img_resample_yuv420(tight, iw, ih, ow, oh)
+            assert (gY[t, :, :ow].ravel() == want[: ow * oh]).all(), (iw, ih, t)
+            assert (gCb[t, :, :ocw].ravel() == want[ow * oh: ow * oh + ocw * och]).all()
+            assert (gCr[t, :, :ocw].ravel() == want[ow * oh + ocw * och:]).all()
+        assert (gY[:, :, ow:] == 0x5A).all() and (gCb[:, :, ocw:] == 0x5A).all()      # the padding is nobody's
+        if (ow, oh) == (160, 120):   # one call: rescale + encode == encode of the rescaled planes
+            cap = ctx.encode_bound(ow, oh) * n
+            b1, o1, l1 = (torch.zeros(cap, dtype=torch.uint8, device="cuda:0"), torch.zeros(n, dtype=torch.int64, device="cuda:0"),
+                          torch.zeros(n, dtype=torch.int32, device="cuda:0"))
+            b2, o2, l2 = torch.zeros_like(b1), torch.zeros_like(o1), torch.zeros_like(l1)
+            assert ctx.lib.amvhip_encode_yuv420_scaled_batch_dev(ctx.h, dY.data_ptr(), dCb.data_ptr(), dCr.data_ptr(), ys, cs, ih * ys,
+                                                                 ich * cs, iw, ih, n, ow, oh, 0, b1.data_ptr(), cap, o1.data_ptr(),
+                                                                 l1.data_ptr(), None) == 0
+            ctx.encode_yuv420_batch_dev(oY, oCb, oCr, oys, ocs, oh * oys, och * ocs, n, ow, oh, 0, b2, cap, o2, l2)
+            torch.cuda.synchronize()
+            assert torch.equal(l1, l2) and torch.equal(o1, o2) and int(l1.min()) > 4
+            end = int(o1[-1]) + int(l1[-1])
+            assert torch.equal(b1[:end], b2[:end])

@@ -355,3 +355,23 @@ def test_oracle_under_sanitizers(amv1):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "sanitized: 252 video chunks, 252 audio chunks" in out.stdout
+
+
+def test_img_resample_matches_reference_build(orc):
+    """the oracle's restatement of img_resample (the sws_scale shim's rescaler) and of the filter
+    builder behind it against the reference's own imgresample.c / resample2.c objects: down- and up-scaling, odd
+    ratios, sizes whose chroma planes round down, flat and noisy content"""
+    R = _need_avcref(orc)
+    rng = np.random.default_rng(8)
+    for iw, ih, ow, oh in ((640, 480, 160, 120), (320, 240, 160, 120), (352, 288, 160, 120), (176, 144, 160, 120),
+                           (160, 120, 320, 240), (130, 98, 64, 48), (160, 120, 160, 96), (162, 122, 160, 120), (64, 48, 66, 50)):
+        for kind in range(3):
+            n = orc.yuv420_bytes(iw, ih)
+            src = (rng.integers(0, 256, n, dtype=np.uint8) if kind == 0 else
+                   np.full(n, 255 if kind == 1 else 0, np.uint8))
+            if kind == 2:
+                src[: iw * ih] = (np.add.outer(np.arange(ih) * 3, np.arange(iw) * 5) & 255).astype(np.uint8).ravel()
+            mine = orc.img_resample_yuv420(src, iw, ih, ow, oh)
+            ref = np.zeros_like(mine)
+            assert R.amvref_img_resample(src.ctypes.data, iw, ih, ref.ctypes.data, ow, oh) == 0
+            assert (mine == ref).all(), (iw, ih, ow, oh, kind)
