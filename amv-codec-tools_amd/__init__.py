@@ -112,6 +112,8 @@ SYMBOLS = {
     "amvhip_adpcm_decode_batch_async": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _u64, _vp, _vp]),
     "amvhip_adpcm_encode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),
     "amvhip_adpcm_encode_frame": (_int, [_vp, _vp, _u32, ctypes.POINTER(_i32), _vp, _u32]),
+    "amvhip_adpcm_encode_trellis_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "amvhip_adpcm_encode_frame_trellis": (_int, [_vp, _vp, _u32, ctypes.POINTER(_i32), _u32, _vp, _u32]),
     "amvhip_amv_audio_pairs": (_u32, [_u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),
     "amvhip_amv_audio_frame_size": (_u32, [_u32, _u32, _u32]),
     "amvhip_adpcm_wav_encode_frame": (_int, [_vp, _vp, _int, _vp, _vp, _int]),

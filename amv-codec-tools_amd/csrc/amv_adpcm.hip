@@ -17,6 +17,8 @@
 // (chunk, start) pair), the amv_adpcm_chain_* kernels compose the 89-entry maps (256 chunks per
 // workgroup through LDS, then the workgroup maps, then back down), and the real encode runs one
 // lane per chunk from its now-known start.
+#include <atomic>
+
 #include "amv_kernels.h"
 
 namespace amv {
@@ -283,6 +285,157 @@ __global__ __launch_bounds__(64) void amv_adpcm_encode_kernel(
     const uint32_t cnt = pairs << 1;                // :479 le32 sample count
     d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
     encode_run<true>(x, cnt, prev, index, d + 8, s_step);
+}
+
+// The reference's trellis search (adpcm_compress_trellis, adpcm.c:287-443, IMA branch; `-trellis N`): a beam of the
+// 2^N best decoder states (sorted by squared error, at most one per decoded sample value), three candidate nibbles
+// around the plain quantiser's choice for the better half of the beam and one for the rest (:333,373-385), the best
+// path frozen into the output every 128 samples (:405-417).  One lane per chunk; the beam lives in LDS
+// ([field][buffer][slot][lane]: a lane's accesses never meet another lane's bank), the back-pointers
+// (nibble | previous path << 4, 16 bits) in a workspace laid out [64 chunks][path][lane].
+// Chunks are independent: the step index comes in per chunk and goes out per chunk.
+__global__ __launch_bounds__(64) void amv_adpcm_trellis_kernel(
+    const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
+    const int32_t* __restrict__ step_in, uint32_t trellis, uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs,
+    int32_t* __restrict__ step_out, uint16_t* __restrict__ paths) {
+    extern __shared__ uint32_t s_trellis[];
+    __shared__ uint32_t s_step[96];
+    load_steps(s_step);
+    const uint32_t F = 1u << trellis, lane = threadIdx.x;
+    const uint32_t i_chunk = blockIdx.x * 64u + lane;
+    const bool live = i_chunk < n;
+    // node fields: [field 0..3][buffer 0..1][slot][lane]; order of the two frontiers: [buffer][rank][lane]
+    uint32_t* const f_ssd = s_trellis + lane;
+    uint32_t* const f_smp = f_ssd + 2u * F * 64u;
+    uint32_t* const f_stp = f_smp + 2u * F * 64u;
+    uint32_t* const f_pth = f_stp + 2u * F * 64u;
+    uint32_t* const f_ord = f_pth + 2u * F * 64u;
+    auto at = [&](uint32_t* field, uint32_t buf, uint32_t slot) -> uint32_t& { return field[(buf * F + slot) * 64u]; };
+    constexpr uint32_t kNone = 0xffffffffu;
+    uint16_t* const my_paths = paths + (uint64_t)blockIdx.x * (F * 128u) * 64u + lane;   // entry e at my_paths[e * 64]
+
+    const int16_t* x = live ? pcm + pcm_offs[i_chunk] : pcm;
+    const uint32_t cnt = live ? (nsamp[i_chunk] & ~1u) : 0u;
+    uint8_t* d = live ? blob + offs[i_chunk] : blob;
+    const int first = cnt ? x[0] : 0;
+    const int index0 = live ? clip_index(step_in[i_chunk]) : 0;
+    if (live) {
+        d[0] = (uint8_t)(first & 0xff); d[1] = (uint8_t)((first >> 8) & 0xff);       // adpcm.c:465-466,479
+        d[2] = (uint8_t)index0; d[3] = 0;
+        d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
+    }
+    // nodes[0] = {ssd 0, path 0, step, sample1 = the chunk's first sample} in buffer 1 (:309-316)
+    at(f_ssd, 1, 0) = 0u; at(f_smp, 1, 0) = (uint32_t)first; at(f_stp, 1, 0) = (uint32_t)index0; at(f_pth, 1, 0) = 0u;
+    for (uint32_t k = 0; k < F; ++k) { at(f_ord, 0, k) = k ? kNone : 0u; at(f_ord, 1, k) = kNone; }
+    uint32_t cur = 0;          // which order array holds the current frontier (its nodes live in buffer (i & 1) ^ 1)
+    uint32_t pathn = 0;
+    int froze = -1;
+    auto put_nibble = [&](uint32_t k, uint32_t nib) {   // sample k's nibble: high half of its byte first (:485-486)
+        uint8_t* b = d + 8u + (k >> 1);
+        *b = (k & 1u) ? (uint8_t)((*b & 0xf0u) | nib) : (uint8_t)((*b & 0x0fu) | (nib << 4));
+    };
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t nb = i & 1u, ob = nb ^ 1u, nxt = cur ^ 1u;
+        const int sample = x[i];
+        uint32_t made = 0, nn = 0;     // nodes allocated in buffer nb; entries of the next frontier
+        for (uint32_t k = 0; k < F; ++k) at(f_ord, nxt, k) = kNone;
+        for (uint32_t j = 0; j < F; ++j) {
+            const uint32_t src = at(f_ord, cur, j);
+            if (src == kNone) break;
+            const int range = j < F / 2u ? 1 : 0;                                   // :333
+            const int step = (int)at(f_stp, ob, src), st = (int)s_step[step];
+            const int predictor = (int)at(f_smp, ob, src);
+            const uint32_t base_ssd = at(f_ssd, ob, src), src_path = at(f_pth, ob, src);
+            const int div = (sample - predictor) * 4 / st;                         // :376
+            int nmin = min(max(div - range, -7), 6), nmax = min(max(div + range, -6), 7);
+            if (nmin <= 0) --nmin;                                                   // distinguish -0 from +0
+            if (nmax < 0) --nmax;
+            for (int nidx = nmin; nidx <= nmax; ++nidx) {
+                const uint32_t nibble = (uint32_t)(nidx < 0 ? 7 - nidx : nidx);
+                const int look = (nibble & 8u) ? -(int)(2u * (nibble & 7u) + 1u) : (int)(2u * (nibble & 7u) + 1u);
+                const int dec = clip16(predictor + (st * look) / 8);
+                const int diff = sample - dec;
+                const uint32_t ssd = base_ssd + (uint32_t)(diff * diff);
+                if (nn == F && ssd >= at(f_ssd, nb, at(f_ord, nxt, F - 1u))) continue;   // :342
+                bool dup = false;                                                    // one state per decoded value, :347-352
+                for (uint32_t k = 0; k < nn; ++k) dup = dup || (int)at(f_smp, nb, at(f_ord, nxt, k)) == dec;
+                if (dup) continue;
+                uint32_t k = 0;
+                while (k < nn && ssd >= at(f_ssd, nb, at(f_ord, nxt, k))) ++k;       // first rank it beats (:353-354)
+                uint32_t u;
+                if (nn == F) {
+                    u = at(f_ord, nxt, F - 1u);                                      // the worst one makes room, its path id stays
+                } else {
+                    u = made++;
+                    at(f_pth, nb, u) = pathn++;
+                    ++nn;
+                }
+                at(f_ssd, nb, u) = ssd;
+                at(f_stp, nb, u) = (uint32_t)clip_index(step + kImaIndexAdjust[nibble]);
+                at(f_smp, nb, u) = (uint32_t)dec;
+                my_paths[(uint64_t)at(f_pth, nb, u) * 64u] = (uint16_t)(nibble | (src_path << 4));
+                for (uint32_t m = nn - 1u; m > k; --m) at(f_ord, nxt, m) = at(f_ord, nxt, m - 1u);   // memmove, :365
+                at(f_ord, nxt, k) = u;
+            }
+        }
+        cur = nxt;
+        const uint32_t best = at(f_ord, cur, 0);
+        if (at(f_ssd, nb, best) > (1u << 28)) {                                     // :398-402
+            const uint32_t off = at(f_ssd, nb, best);
+            for (uint32_t j = 1; j < F; ++j) {
+                const uint32_t q = at(f_ord, cur, j);
+                if (q == kNone) break;
+                at(f_ssd, nb, q) -= off;
+            }
+            at(f_ssd, nb, best) = 0u;
+        }
+        if ((int)i == froze + 128) {                                                // :405-417
+            uint32_t p = at(f_pth, nb, best);
+            for (int k = (int)i; k > froze; --k) {
+                const uint32_t e = my_paths[(uint64_t)p * 64u];
+                put_nibble((uint32_t)k, e & 15u);
+                p = e >> 4;
+            }
+            froze = (int)i;
+            pathn = 0;
+            for (uint32_t j = 1; j < F; ++j) at(f_ord, cur, j) = kNone;
+        }
+    }
+    if (cnt) {
+        const uint32_t nb = (cnt - 1u) & 1u, best = at(f_ord, cur, 0);
+        uint32_t p = at(f_pth, nb, best);
+        for (int k = (int)cnt - 1; k > froze; --k) {
+            const uint32_t e = my_paths[(uint64_t)p * 64u];
+            put_nibble((uint32_t)k, e & 15u);
+            p = e >> 4;
+        }
+        if (step_out) step_out[i_chunk] = (int32_t)at(f_stp, nb, best);              // :429
+    } else if (live && step_out) {
+        step_out[i_chunk] = index0;
+    }
+}
+
+// workspace of launch_adpcm_trellis: bytes for n chunks
+uint64_t adpcm_trellis_workspace(uint32_t n, uint32_t trellis) {
+    return (uint64_t)((n + 63u) / 64u) * 64u * ((1u << trellis) * 128u) * sizeof(uint16_t);
+}
+
+bool launch_adpcm_trellis(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, const int32_t* step_in,
+                          uint32_t trellis, uint8_t* blob, const uint64_t* offs, int32_t* step_out, uint16_t* paths, hipStream_t s) {
+    if (n == 0) return true;
+    const uint32_t lds = 5u * 2u * (1u << trellis) * 64u * 4u;
+    static std::atomic<uint64_t> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(raised.load() & (1ull << (dev & 63)))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(amv_adpcm_trellis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                5 * 2 * 32 * 64 * 4) != hipSuccess)
+            return false;
+        raised.fetch_or(1ull << (dev & 63));
+    }
+    hipLaunchKernelGGL(amv_adpcm_trellis_kernel, dim3((n + 63) / 64), dim3(64), lds, s, pcm, pcm_offs, nsamp, n, step_in, trellis, blob,
+                       offs, step_out, paths);
+    return true;
 }
 
 void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,

@@ -130,6 +130,12 @@ void launch_adpcm_encode(const int16_t* pcm, const uint64_t* pcm_offs, const uin
                          uint32_t n, const int32_t* step_in, uint8_t* blob, const uint64_t* offs,
                          hipStream_t s);
 
+// the reference's trellis search (adpcm.c:287-443), one lane per independent chunk; paths: adpcm_trellis_workspace bytes.
+// false: the device refused the kernel's LDS size
+uint64_t adpcm_trellis_workspace(uint32_t n, uint32_t trellis);
+bool launch_adpcm_trellis(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, const int32_t* step_in,
+                          uint32_t trellis, uint8_t* blob, const uint64_t* offs, int32_t* step_out, uint16_t* paths, hipStream_t s);
+
 // ---- synthetic sources ----------------------------------------------------------------------
 void launch_synth_frames(uint32_t seed, uint32_t first, uint32_t n, uint32_t w, uint32_t h,
                          uint8_t* rgb, hipStream_t s);

@@ -40,7 +40,7 @@ struct amvhip_ctx {
     HuffDecodeImage* d_dec = nullptr;
     HuffEncodeImage* d_enc = nullptr;
     // workspace
-    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count, scaled;
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count, scaled, trellis_ws;
     bool dense_intermediate = false;   // AMVHIP_DENSE=1: dense coefficient lines between the decode stages (experiments)
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
     uint32_t cus = 256;   // compute units of the device
@@ -249,7 +249,7 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out})
+                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -853,11 +853,44 @@ extern "C" int amvhip_adpcm_encode_batch(amvhip_ctx* c, const int16_t* pcm, uint
     return AMVHIP_OK;
 }
 
+// The reference's `-trellis N` quality mode (adpcm_compress_trellis, adpcm.c:287-443) for independent chunks: every chunk
+// starts from d_step_in[i] and reports the index it ends on in d_step_out[i] (optional).
+extern "C" int amvhip_adpcm_encode_trellis_batch_dev(amvhip_ctx* c, const int16_t* d_pcm, const uint64_t* d_pcm_offs,
+                                                     const uint32_t* d_nsamp, uint32_t n, const int32_t* d_step_in, uint32_t trellis,
+                                                     uint8_t* d_blob, const uint64_t* d_offs, int32_t* d_step_out, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (trellis < 1 || trellis > 5 || (n && (!d_pcm || !d_pcm_offs || !d_nsamp || !d_step_in || !d_blob || !d_offs)))
+        return fail(c, AMVHIP_ERR_ARG, "adpcm_encode_trellis: bad argument (trellis 1..5, start indices required)");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int r = ensure(c, c->trellis_ws, adpcm_trellis_workspace(n, trellis))) return r;
+    Timed t(c, AMVHIP_K_ADPCM_ENC, (hipStream_t)stream);
+    if (!launch_adpcm_trellis(d_pcm, d_pcm_offs, d_nsamp, n, d_step_in, trellis, d_blob, d_offs, d_step_out, (uint16_t*)c->trellis_ws.p,
+                              (hipStream_t)stream))
+        return fail(c, AMVHIP_ERR_DEVICE, "adpcm_encode_trellis: kernel attributes refused");
+    return check_launch(c, "adpcm_trellis");
+}
+
 // One AMV audio chunk with the step index handed in and out: what adpcm_encode_frame (adpcm.c:461-498) does per
 // call with the index it keeps in its context.  The end index is read off a decode of the fresh chunk (the decoder
 // walks the same index chain), one synchronisation for both kernels.
+static int adpcm_encode_frame_impl(amvhip_ctx* c, const int16_t* samples, uint32_t nsamp, int32_t* step_index, uint32_t trellis,
+                                   uint8_t* chunk, uint32_t cap);
+
 extern "C" int amvhip_adpcm_encode_frame(amvhip_ctx* c, const int16_t* samples, uint32_t nsamp, int32_t* step_index,
                                          uint8_t* chunk, uint32_t cap) {
+    return adpcm_encode_frame_impl(c, samples, nsamp, step_index, 0u, chunk, cap);
+}
+
+extern "C" int amvhip_adpcm_encode_frame_trellis(amvhip_ctx* c, const int16_t* samples, uint32_t nsamp, int32_t* step_index,
+                                                 uint32_t trellis, uint8_t* chunk, uint32_t cap) {
+    if (trellis < 1 || trellis > 5) return c ? fail(c, AMVHIP_ERR_ARG, "adpcm_encode_frame_trellis: trellis 1..5") : AMVHIP_ERR_ARG;
+    return adpcm_encode_frame_impl(c, samples, nsamp, step_index, trellis, chunk, cap);
+}
+
+static int adpcm_encode_frame_impl(amvhip_ctx* c, const int16_t* samples, uint32_t nsamp, int32_t* step_index, uint32_t trellis,
+                                   uint8_t* chunk, uint32_t cap) {
     if (!c) return AMVHIP_ERR_ARG;
     const uint32_t len = 8u + (nsamp >> 1);
     if (!samples || !step_index || !chunk || (nsamp & 1u) || nsamp == 0 || *step_index < 0 || *step_index > 88)
@@ -876,9 +909,14 @@ extern "C" int amvhip_adpcm_encode_frame(amvhip_ctx* c, const int16_t* samples, 
     int16_t* d_scratch = (int16_t*)(d_chunk + ((len + 15u) & ~15u));
     HIP_TRY(c, hipMemcpyAsync(c->h_in.p, samples, (size_t)nsamp * 2, hipMemcpyHostToDevice, hs));
     HIP_TRY(c, hipMemcpyAsync(aux, &tab, sizeof tab, hipMemcpyHostToDevice, hs));
-    if (int r = amvhip_adpcm_encode_batch_dev(c, (const int16_t*)c->h_in.p, (const uint64_t*)aux, (const uint32_t*)(aux + 16), 1,
-                                              (const int32_t*)(aux + 24), d_chunk, (const uint64_t*)(aux + 8), hs))
+    if (trellis) {
+        if (int r = amvhip_adpcm_encode_trellis_batch_dev(c, (const int16_t*)c->h_in.p, (const uint64_t*)aux, (const uint32_t*)(aux + 16), 1,
+                                                          (const int32_t*)(aux + 24), trellis, d_chunk, (const uint64_t*)(aux + 8), nullptr, hs))
+            return r;
+    } else if (int r = amvhip_adpcm_encode_batch_dev(c, (const int16_t*)c->h_in.p, (const uint64_t*)aux, (const uint32_t*)(aux + 16), 1,
+                                                     (const int32_t*)(aux + 24), d_chunk, (const uint64_t*)(aux + 8), hs)) {
         return r;
+    }
     if (int r = amvhip_adpcm_decode_batch_dev(c, d_chunk, len, (const uint64_t*)(aux + 8), (const uint32_t*)(aux + 20), 1, d_scratch,
                                               (const uint64_t*)aux, (int32_t*)(aux + 28), hs))
         return r;

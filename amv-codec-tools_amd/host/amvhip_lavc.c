@@ -21,7 +21,7 @@
  *                   documented ones of DESIGN.md section 2 (amvlib's quantiser tables, true level shift): the
  *                   reference's own output does not survive any AMV decoder.
  *   audio           chunk layout, step index carried from call to call, odd-sample carry and 1 Hz resync of
- *                   adpcm.c:461-498; `-trellis` is not implemented (the option is ignored).
+ *                   adpcm.c:461-498; `-trellis N` runs the reference's beam search (:287-443) with N capped at 5.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -249,7 +249,11 @@ static int amvhip_audio_encode_frame(AVCodecContext *avctx, unsigned char *frame
     if (n == 0 || (int)(8 + n) > buf_size)
         return -1;
     /* reads 2n samples like the reference does -- up to frame_size + 1, or more at a second's end (:476-477) */
-    r = amvhip_adpcm_encode_frame(s->ctx, (const int16_t *)data, 2 * n, &s->step_index, frame, (uint32_t)buf_size);
+    if (avctx->trellis > 0)                                         /* adpcm.c:482-487 */
+        r = amvhip_adpcm_encode_frame_trellis(s->ctx, (const int16_t *)data, 2 * n, &s->step_index,
+                                              (uint32_t)(avctx->trellis > 5 ? 5 : avctx->trellis), frame, (uint32_t)buf_size);
+    else
+        r = amvhip_adpcm_encode_frame(s->ctx, (const int16_t *)data, 2 * n, &s->step_index, frame, (uint32_t)buf_size);
     return r < 0 ? -1 : r;
 }
 

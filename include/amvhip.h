@@ -357,6 +357,15 @@ int amvhip_adpcm_encode_batch(amvhip_ctx *ctx, const int16_t *pcm, uint64_t pcm_
  * context between calls, adpcm.c:461-498).  nsamp even and > 0; writes 8 + nsamp/2 bytes, returns that count. */
 int amvhip_adpcm_encode_frame(amvhip_ctx *ctx, const int16_t *samples, uint32_t nsamp, int32_t *step_index,
                               uint8_t *chunk, uint32_t cap);
+/* The reference's `-trellis N` quality mode (adpcm_compress_trellis, adpcm.c:287-443, as the AMV case calls it :482-487):
+ * a beam search over the 2^N best decoder states instead of the plain quantiser, 1 <= N <= 5; same chunk layout, lower
+ * error.  The batch form takes independent chunks (d_step_in required, d_step_out optional: the index each chunk ends
+ * on); the frame form hands the index in and out like amvhip_adpcm_encode_frame. */
+int amvhip_adpcm_encode_trellis_batch_dev(amvhip_ctx *ctx, const int16_t *d_pcm, const uint64_t *d_pcm_offs,
+                                          const uint32_t *d_nsamp, uint32_t n, const int32_t *d_step_in, uint32_t trellis,
+                                          uint8_t *d_blob, const uint64_t *d_offs, int32_t *d_step_out, void *stream);
+int amvhip_adpcm_encode_frame_trellis(amvhip_ctx *ctx, const int16_t *samples, uint32_t nsamp, int32_t *step_index,
+                                      uint32_t trellis, uint8_t *chunk, uint32_t cap);
 /* The framing the reference's AMV audio encoder and muxer apply around the kernel (host arithmetic only):
  * amvhip_amv_audio_pairs      adpcm.c:469-477,497: sample pairs of the next chunk for a nominal frame_size (odd sizes
  *                             alternate, a chunk that would straddle a whole second is stretched to end on it);

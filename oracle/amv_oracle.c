@@ -722,6 +722,111 @@ int amvo_adpcm_encode_chunk(const int16_t *samples, uint32_t nsamp, int *step_in
     return (int)(dst - out);
 }
 
+/* adpcm_compress_trellis lavc/adpcm.c:287-443, the IMA branch (LOOP_NODES :373-385, STORE_NODE :336-369), as the
+ * AMV case of adpcm_encode_frame calls it (:482-487): a beam search over the 2^trellis best decoder states, frozen
+ * into the output every 128 samples.  nodes[] is kept sorted by error; a candidate that decodes to a sample value some
+ * node of the new frontier already has is dropped.  Unpinned restatement: adpcm.c's encoders sit behind
+ * CONFIG_ENCODERS, which only ./configure defines. */
+#define TRELLIS_FREEZE 128
+#define TRELLIS_MAX 5
+typedef struct { uint32_t ssd; int path, sample1, sample2, step; } trellis_node;
+typedef struct { int nibble, prev; } trellis_path;
+
+static void compress_trellis(const int16_t *samples, uint8_t *dst, int n, int trellis, int *prev_sample, int *step_index)
+{
+    const int frontier = 1 << trellis;
+    static const int difflookup[16] = { 1, 3, 5, 7, 9, 11, 13, 15, -1, -3, -5, -7, -9, -11, -13, -15 };   /* :124-127 */
+    trellis_path *paths = malloc(sizeof(trellis_path) * (size_t)frontier * TRELLIS_FREEZE);
+    trellis_node node_buf[2][1 << TRELLIS_MAX];
+    trellis_node *nodep_buf[2][1 << TRELLIS_MAX];
+    trellis_node **nodes = nodep_buf[0], **nodes_next = nodep_buf[1];
+    int pathn = 0, froze = -1;
+    memset(nodep_buf, 0, sizeof nodep_buf);
+    nodes[0] = &node_buf[1][0];                                     /* :309-316 */
+    nodes[0]->ssd = 0; nodes[0]->path = 0; nodes[0]->step = *step_index;
+    nodes[0]->sample1 = *prev_sample; nodes[0]->sample2 = 0;
+    for (int i = 0; i < n; i++) {
+        trellis_node *t = node_buf[i & 1];
+        const int sample = samples[i];
+        memset(nodes_next, 0, (size_t)frontier * sizeof(trellis_node *));
+        for (int j = 0; j < frontier && nodes[j]; j++) {
+            const int range = j < frontier / 2 ? 1 : 0;            /* :333 */
+            const int step = nodes[j]->step, st = k_step_table[step];
+            const int predictor = nodes[j]->sample1;
+            const int div = (sample - predictor) * 4 / st;          /* :376 */
+            int nmin = div - range, nmax = div + range;
+            nmin = nmin < -7 ? -7 : (nmin > 6 ? 6 : nmin);
+            nmax = nmax < -6 ? -6 : (nmax > 7 ? 7 : nmax);
+            if (nmin <= 0) nmin--;                                  /* distinguish -0 from +0 */
+            if (nmax < 0) nmax--;
+            for (int nidx = nmin; nidx <= nmax; nidx++) {
+                const int nibble = nidx < 0 ? 7 - nidx : nidx;
+                int dec = clip_s16(predictor + (st * difflookup[nibble]) / 8);
+                const int d = sample - dec;
+                const uint32_t ssd = nodes[j]->ssd + (uint32_t)(d * d);
+                int k, dup = 0;
+                if (nodes_next[frontier - 1] && ssd >= nodes_next[frontier - 1]->ssd) continue;   /* :342 */
+                for (k = 0; k < frontier && nodes_next[k]; k++)     /* collapse equal previous samples, :347-352 */
+                    if (dec == nodes_next[k]->sample1) { dup = 1; break; }
+                if (dup) continue;
+                for (k = 0; k < frontier; k++) {
+                    if (!nodes_next[k] || ssd < nodes_next[k]->ssd) {
+                        trellis_node *u = nodes_next[frontier - 1];
+                        if (!u) { u = t++; u->path = pathn++; }
+                        u->ssd = ssd;
+                        u->step = clip_idx(step + k_index_table[nibble]);
+                        u->sample2 = nodes[j]->sample1;
+                        u->sample1 = dec;
+                        paths[u->path].nibble = nibble;
+                        paths[u->path].prev = nodes[j]->path;
+                        memmove(&nodes_next[k + 1], &nodes_next[k], (size_t)(frontier - k - 1) * sizeof(trellis_node *));
+                        nodes_next[k] = u;
+                        break;
+                    }
+                }
+            }
+        }
+        { trellis_node **u = nodes; nodes = nodes_next; nodes_next = u; }
+        if (nodes[0]->ssd > (1u << 28)) {                          /* :398-402 */
+            for (int j = 1; j < frontier && nodes[j]; j++) nodes[j]->ssd -= nodes[0]->ssd;
+            nodes[0]->ssd = 0;
+        }
+        if (i == froze + TRELLIS_FREEZE) {                         /* :405-417 */
+            const trellis_path *p = &paths[nodes[0]->path];
+            for (int k = i; k > froze; k--) { dst[k] = (uint8_t)p->nibble; p = &paths[p->prev]; }
+            froze = i;
+            pathn = 0;
+            memset(nodes + 1, 0, (size_t)(frontier - 1) * sizeof(trellis_node *));
+        }
+    }
+    {
+        const trellis_path *p = &paths[nodes[0]->path];
+        for (int i = n - 1; i > froze; i--) { dst[i] = (uint8_t)p->nibble; p = &paths[p->prev]; }
+    }
+    *prev_sample = nodes[0]->sample1;                               /* :426-431 (prev_sample itself is reset per frame, :464) */
+    *step_index = nodes[0]->step;
+    free(paths);
+}
+
+/* the AMV case of adpcm_encode_frame with avctx->trellis > 0 (adpcm.c:461-487): same header, nibbles from the search */
+int amvo_adpcm_encode_chunk_trellis(const int16_t *samples, uint32_t nsamp, int *step_index, int trellis, uint8_t *out)
+{
+    uint8_t *dst = out;
+    int prev = samples[0];
+    const uint32_t n = nsamp >> 1;
+    uint8_t *nib;
+    if (trellis < 1 || trellis > TRELLIS_MAX) return -1;
+    nib = malloc(2 * (size_t)n + 1);
+    *dst++ = (uint8_t)(prev & 0xff); *dst++ = (uint8_t)((prev >> 8) & 0xff);
+    *dst++ = (uint8_t)(*step_index & 0xff); *dst++ = (uint8_t)((*step_index >> 8) & 0xff);
+    *dst++ = (uint8_t)((n << 1) & 0xff); *dst++ = (uint8_t)(((n << 1) >> 8) & 0xff);
+    *dst++ = (uint8_t)(((n << 1) >> 16) & 0xff); *dst++ = (uint8_t)(((n << 1) >> 24) & 0xff);
+    if (n) compress_trellis(samples, nib, (int)(2 * n), trellis, &prev, step_index);
+    for (uint32_t i = 0; i < n; i++) *dst++ = (uint8_t)((nib[2 * i] << 4) | nib[2 * i + 1]);   /* :485-486 */
+    free(nib);
+    return (int)(dst - out);
+}
+
 /* AdpcmImaCompressSample AdpcmIma.c:43-89: the quotient goes through an unsigned char before it
  * is limited to 7 (:62-65) and the predicted delta uses the already updated step (:73) */
 static unsigned wav_compress(int *prev, int *step_index, int sample)

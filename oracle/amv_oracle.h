@@ -106,6 +106,11 @@ int amvo_adpcm_decode_chunk(const uint8_t *chunk, uint32_t len, int16_t *pcm, ui
  * Writes 8 + nsamp/2 bytes; returns that count. */
 int amvo_adpcm_encode_chunk(const int16_t *samples, uint32_t nsamp, int *step_index, uint8_t *out);
 
+/* The same with the reference's trellis search (adpcm.c:287-443, IMA branch; `-trellis N` of the ffmpeg CLI), frontier
+ * 2^trellis, 1 <= trellis <= 5.  Unpinned restatement (adpcm.c's encoders are behind a configure switch).  -1 on a bad
+ * trellis value. */
+int amvo_adpcm_encode_chunk_trellis(const int16_t *samples, uint32_t nsamp, int *step_index, int trellis, uint8_t *out);
+
 /* Per-chunk sample-pair count n of the FFmpeg AMV framing (adpcm.c:469-477):
  * odd frame_size carry and the once-per-second resync.  State is carried in
  * extra (0/1) and samples_written. */

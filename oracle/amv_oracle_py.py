@@ -61,6 +61,7 @@ def lib():
             "amvo_img_resample_yuv420": (None, [_vp, _int, _int, _vp, _int, _int]),
             "amvo_adpcm_decode_chunk": (_int, [_vp, _u32, _vp, _vp]),
             "amvo_adpcm_encode_chunk": (_int, [_vp, _u32, ctypes.POINTER(_int), _vp]),
+            "amvo_adpcm_encode_chunk_trellis": (_int, [_vp, _u32, ctypes.POINTER(_int), _int, _vp]),
             "amvo_adpcm_wav_encode_frame": (_int, [_vp, _int, _vp, _vp]),
             "amvo_adpcm_amv_pairs": (_u32, [_u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),
             "amvo_rgb24_to_yuvj420p": (None, [_vp, _u32, _u32, _u32, _int, _vp, _vp, _vp]),
@@ -238,6 +239,17 @@ def adpcm_encode_chunk(samples, step_index):
     si = _int(step_index)
     n = lib().amvo_adpcm_encode_chunk(samples.ctypes.data, len(samples), ctypes.byref(si), out.ctypes.data)
     return bytes(out[:n]), si.value
+
+
+def adpcm_encode_chunk_trellis(samples, step_index, trellis):
+    """-> (chunk bytes, step index after) with the reference's trellis search, frontier 2**trellis"""
+    samples = np.ascontiguousarray(samples, np.int16)
+    out = np.zeros(8 + samples.size // 2 + 8, np.uint8)
+    idx = ctypes.c_int(step_index)
+    n = lib().amvo_adpcm_encode_chunk_trellis(samples.ctypes.data, samples.size, ctypes.byref(idx), trellis, out.ctypes.data)
+    if n < 0:
+        raise ValueError("trellis must be 1..5")
+    return bytes(out[:n]), idx.value
 
 
 def fnv1a64(h, arr):

@@ -1092,3 +1092,52 @@ def test_resample_matches_oracle(ctx, orc):
             assert torch.equal(l1, l2) and torch.equal(o1, o2) and int(l1.min()) > 4
             end = int(o1[-1]) + int(l1[-1])
             assert torch.equal(b1[:end], b2[:end])
+
+
+def test_adpcm_trellis_matches_oracle(ctx, pkg, orc):
+    """the reference's `-trellis N` search (adpcm.c:287-443): every frontier size, chunks of different lengths (incl. the
+    128-sample freeze boundary +-1, tiny and empty ones), loud / silent / clipping content, start indices 0..88; the
+    end index of every chunk; the decoded error of the set is below the plain quantiser's from a beam of 8 on"""
+    import torch
+    lib = pkg.load_library()
+    rng = np.random.default_rng(31)
+    sizes = [1378, 1380, 128, 130, 126, 256, 258, 2, 0, 4, 640, 1378, 2048, 1376]
+    offs_s = np.cumsum([0] + sizes).astype(np.uint64)
+    pcm = orc.synth_audio(SEED, 4242, int(offs_s[-1]) + 2)
+    pcm[1400:2700] = rng.integers(-32768, 32768, 1300)          # clipping noise
+    pcm[3000:3600] = 0                                          # silence
+    pcm[5000:7000] = (rng.integers(-3000, 3000, 2000)).astype(np.int16)
+    n = len(sizes)
+    step_in = np.array([0, 88, 40, 7, 60, 33, 1, 50, 12, 87, 20, 45, 70, 5], np.int32)
+    coffs = np.cumsum([0] + [8 + s // 2 for s in sizes]).astype(np.uint64)
+    d_pcm, d_po, d_ns, d_si, d_co = _t(pcm), _t(offs_s[:-1].copy()), _t(np.array(sizes, np.uint32)), _t(step_in), _t(coffs[:-1].copy())
+    for trellis in (1, 2, 3, 4, 5):
+        d_blob = torch.zeros(int(coffs[-1]) + 8, dtype=torch.uint8, device="cuda:0")
+        d_so = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+        assert lib.amvhip_adpcm_encode_trellis_batch_dev(ctx.h, d_pcm.data_ptr(), d_po.data_ptr(), d_ns.data_ptr(), n, d_si.data_ptr(),
+                                                         trellis, d_blob.data_ptr(), d_co.data_ptr(), d_so.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        blob, so = d_blob.cpu().numpy(), d_so.cpu().numpy()
+        tot_t = tot_p = 0.0
+        for i, sz in enumerate(sizes):
+            seg = pcm[int(offs_s[i]):int(offs_s[i]) + sz]
+            got = blob[int(coffs[i]):int(coffs[i + 1])].tobytes()
+            if sz == 0:
+                assert got[:8] == bytes([0, 0, int(step_in[i]), 0, 0, 0, 0, 0]) and so[i] == step_in[i]
+                continue
+            want, idx = orc.adpcm_encode_chunk_trellis(seg, int(step_in[i]), trellis)
+            assert got == want and so[i] == idx, (trellis, i)
+            plain, _ = orc.adpcm_encode_chunk(seg, int(step_in[i]))
+            err = lambda c: float(((orc.adpcm_decode_chunk(c)[0][:sz].astype(np.float64) - seg) ** 2).sum())
+            tot_t += err(got)
+            tot_p += err(plain)
+        assert trellis < 3 or tot_t < tot_p       # a beam of 8 or more beats the plain quantiser on the whole set
+    # frame form: index in and out, a stream of chunks
+    idx, want_idx = ctypes.c_int32(0), 0
+    for i in range(8):
+        seg = np.ascontiguousarray(pcm[i * 700: i * 700 + 700])
+        out = np.zeros(8 + 350, np.uint8)
+        m = lib.amvhip_adpcm_encode_frame_trellis(ctx.h, seg.ctypes.data, 700, ctypes.byref(idx), 3, out.ctypes.data, out.size)
+        want, want_idx = orc.adpcm_encode_chunk_trellis(seg, want_idx, 3)
+        assert m == len(want) and out.tobytes() == want and idx.value == want_idx
+    assert lib.amvhip_adpcm_encode_frame_trellis(ctx.h, pcm.ctypes.data, 700, ctypes.byref(idx), 6, out.ctypes.data, out.size) == pkg.ERR_ARG
