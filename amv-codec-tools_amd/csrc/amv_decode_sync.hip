@@ -373,17 +373,17 @@ struct SegGeom {
 constexpr uint32_t kSegMcus = 10;   // = amv_reconstruct.hip's
 
 // The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state.
-// stage: this lane's 16-byte granule of the wave's staging area; record slot q of lane l lives at dword
-// (q / 4) * 256 + l * 4 + q % 4, so that four consecutive records of a lane leave LDS as one 16-byte read
+// stage: this lane's column of the wave's staging area; record slot q of lane l lives at dword q * 64 + l (the
+// bank depends on the lane only, the address is one shift-and-add)
 __device__ __forceinline__ void stage_put(uint32_t* stage, uint32_t pos, uint32_t word) {
-    stage[((pos & (kStageSlots - 1u)) >> 2) * (kWave * 4u) + (pos & 3u)] = word;
+    stage[(pos & (kStageSlots - 1u)) * kWave] = word;
 }
 
 // records [from, from + 8) of this lane -> rec (from is a multiple of 8; rec + from is 32-byte aligned)
 __device__ __forceinline__ void stage_flush(const uint32_t* stage, uint32_t* __restrict__ rec, uint32_t from, uint32_t rec_cap) {
-    const uint32_t g = (from & (kStageSlots - 1u)) >> 2;
-    const uint4 a = *reinterpret_cast<const uint4*>(stage + g * (kWave * 4u));
-    const uint4 b = *reinterpret_cast<const uint4*>(stage + (g + 1u) * (kWave * 4u));
+    const uint32_t* p = stage + (from & (kStageSlots - 1u)) * kWave;
+    const uint4 a = make_uint4(p[0], p[kWave], p[2 * kWave], p[3 * kWave]);
+    const uint4 b = make_uint4(p[4 * kWave], p[5 * kWave], p[6 * kWave], p[7 * kWave]);
     if (from + kFlush <= rec_cap) {   // never past the frame's record space; an overfull frame is redone densely
         *reinterpret_cast<uint4*>(rec + from) = a;
         *reinterpret_cast<uint4*>(rec + from + 4u) = b;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
     const uint32_t nwaves = blockDim.x >> 6;   // the launch sizes the workgroup (and its LDS) to the batch
     uint32_t* ring = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + wave * (kRingWords * kWave) + lane;
-    uint32_t* stage = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + nwaves * (kRingWords * kWave) + wave * (kStageSlots * kWave) + lane * 4u;
+    uint32_t* stage = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + nwaves * (kRingWords * kWave) + wave * (kStageSlots * kWave) + lane;
     if (list) n = *list_count;
     const uint32_t ntasks = (n + kFrames - 1) / kFrames;
     // Tasks (kFrames frames each) are handed out through a counter: a wave that finishes early -- the
@@ -725,8 +725,8 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
 // Lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units.
 // More lanes per frame mean shorter walks (a shorter launch when the chip is not full) but more
 // speculative work per frame: every lane needs ~4 400 bits to fall in step whatever its share of the
-// frame.  Measured on MI355X: a batch that fills the chip with ONE lane per frame (>= ~400 frames per CU: two
-// waves per SIMD) does best with exactly that -- no speculative work at all, 2.7 ms per 160 000 frames of
+// frame.  Measured on MI355X: a batch that fills the chip with ONE lane per frame (>= ~300 frames per CU) does best
+// with exactly that -- no speculative work at all, 2.7 ms per 160 000 frames of
 // 160x120 against 3.1 with two lanes and 4.9 with eight; from ~200 frames per CU two lanes (lane 0 is exact, so
 // lane 1 starts right after one walk); below that the best share is about the synchronisation length (160x120
 // at ~1.5 bits per pixel: 8 lanes; 320x240: 16), and a small batch does best with the most lanes that keep
@@ -734,10 +734,10 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
 // up to 64) overrides.
 int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     if (wanted == 1 || wanted == 2 || wanted == 4 || wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
-    if (n >= cus * 400u) return 1;
+    if (n >= cus * 300u) return 1;                 // measured: 80 000 frames 1 lane 1.98 ms / 2 lanes 2.02; 120 000: 2.04 / 2.58
     if (n >= cus * 200u) return 2;
-    int full = 8;                                  // chip full: a share of ~4 000 bits, i.e. ~4 096 pixels
-    while (full < 64 && (uint64_t)full * 2u * 4096u <= pixels) full *= 2;
+    int full = 8;                                  // chip full: 8 lanes up to 320x240 (32 000 frames: 2.54 ms against 2.67 with 16)
+    while (full < 64 && (uint64_t)full * 25000u <= pixels) full *= 2;
     const uint64_t waves = (uint64_t)cus * 10u;
     int fill = 8;                                  // small batch: as many lanes as keep every task resident
     if (n <= waves) fill = 64;
