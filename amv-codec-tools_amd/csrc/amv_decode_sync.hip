@@ -61,14 +61,15 @@ constexpr int kWave = 64;
 // independent waves per workgroup (they share only the tables) and workgroups per CU.  Dense form: 10 x 2 = 20 waves
 // per CU, what the kernel's VGPR count allows (5 per SIMD).  Records form: every wave also stages its records in LDS
 // (8 KB per wave with the stream window), so one workgroup of 16 waves per CU (137 KB of the 160 KB).
-constexpr int waves_per_group(bool rec) { return rec ? 16 : 10; }
+constexpr int waves_per_group(bool rec, int lanes) { return rec ? (lanes <= 2 ? 10 : 16) : 10; }
 constexpr int groups_per_cu(bool rec) { return rec ? 1 : 2; }
 constexpr uint32_t kRingWords = 16;       // LDS words per lane: the window of its stream a lane works in
 // Records are staged per lane in LDS and leave as whole, aligned 32-byte pieces (a 4-byte store per record from 64
 // lanes into 64 different lines was written back to HBM as partial lines several times over: 9.8 GB of writes per
 // 160 000 frames for 0.7 GB of records, and with one or two lanes per frame those stores were what the walk waited on).
-constexpr uint32_t kStageSlots = 16;      // records a lane can hold
-constexpr uint32_t kFlush = 8;            // records per store burst: 32 bytes
+// records per store burst: 32 bytes, or -- with one or two lanes per frame, where ten waves per CU are all a batch
+// can fill anyway and the LDS is there -- 64.  A lane's staging column holds two bursts.
+constexpr uint32_t flush_records(int lanes) { return lanes <= 2 ? 16u : 8u; }
 constexpr uint32_t kDummyRecord = 0x8000u;    // bit 15: a filler no block owns
 constexpr uint32_t kNever = 0xffffffffu;
 constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + (4u << kM2Bits) * 2u;   // m1 + m2 of HuffDecodeImage, contiguous
@@ -375,18 +376,23 @@ constexpr uint32_t kSegMcus = 10;   // = amv_reconstruct.hip's
 // The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state.
 // stage: this lane's column of the wave's staging area; record slot q of lane l lives at dword q * 64 + l (the
 // bank depends on the lane only, the address is one shift-and-add)
+template <uint32_t kFlush>
 __device__ __forceinline__ void stage_put(uint32_t* stage, uint32_t pos, uint32_t word) {
-    stage[(pos & (kStageSlots - 1u)) * kWave] = word;
+    stage[(pos & (2u * kFlush - 1u)) * kWave] = word;
 }
 
-// records [from, from + 8) of this lane -> rec (from is a multiple of 8; rec + from is 32-byte aligned)
+// records [from, from + kFlush) of this lane -> rec (from is a multiple of kFlush; rec + from is aligned to the burst)
+template <uint32_t kFlush>
 __device__ __forceinline__ void stage_flush(const uint32_t* stage, uint32_t* __restrict__ rec, uint32_t from, uint32_t rec_cap) {
-    const uint32_t* p = stage + (from & (kStageSlots - 1u)) * kWave;
-    const uint4 a = make_uint4(p[0], p[kWave], p[2 * kWave], p[3 * kWave]);
-    const uint4 b = make_uint4(p[4 * kWave], p[5 * kWave], p[6 * kWave], p[7 * kWave]);
+    const uint32_t* p = stage + (from & (2u * kFlush - 1u)) * kWave;
+    uint4 v[kFlush / 4u];
+#pragma unroll
+    for (uint32_t q = 0; q < kFlush / 4u; ++q)
+        v[q] = make_uint4(p[(4u * q) * kWave], p[(4u * q + 1u) * kWave], p[(4u * q + 2u) * kWave], p[(4u * q + 3u) * kWave]);
     if (from + kFlush <= rec_cap) {   // never past the frame's record space; an overfull frame is redone densely
-        *reinterpret_cast<uint4*>(rec + from) = a;
-        *reinterpret_cast<uint4*>(rec + from + 4u) = b;
+        // (plain stores: streaming "nontemporal" ones took 3.96 ms against 2.70 and wrote more, 3.77 GB against 3.35)
+#pragma unroll
+        for (uint32_t q = 0; q < kFlush / 4u; ++q) *reinterpret_cast<uint4*>(rec + from + 4u * q) = v[q];
     }
 }
 
@@ -394,7 +400,7 @@ __device__ __forceinline__ void stage_flush(const uint32_t* stage, uint32_t* __r
 // that has stopped (end of frame, error, end of its share) without moving or emitting -- so that the scheduler can
 // overlap one symbol's table look-up with the bookkeeping of the one before; a record is always written to the next
 // free staging slot and only counted when it is real.  Dense form: the 2-byte stores are conditional.
-template <bool kRec>
+template <bool kRec, uint32_t kFlush>
 __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __restrict__ m1,
                                                   const uint16_t* __restrict__ m2, State s, uint32_t limit,
                                                   uint32_t blk, uint32_t blocks_per_frame, const Sink& out,
@@ -425,7 +431,7 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
     while (__ballot(alive) != 0ull) {
         if (alive) stream_service(w, x.widx);
         if (kRec && r.recpos - flushed >= kFlush) {
-            stage_flush(stage, out.rec, flushed, rec_cap);
+            stage_flush<kFlush>(stage, out.rec, flushed, rec_cap);
             flushed += kFlush;
         }
 #pragma unroll
@@ -461,7 +467,7 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
                 seg_pos = hit ? r.recpos : seg_pos;
                 seg_hit = seg_hit || hit;
                 const uint32_t pos = isdc ? 0u : idx;
-                stage_put(stage, r.recpos, pos | ((blk & 63u) << 6) | ((uint32_t)(isdc ? t : val) << 16));
+                stage_put<kFlush>(stage, r.recpos, pos | ((blk & 63u) << 6) | ((uint32_t)(isdc ? t : val) << 16));
                 r.recpos += (dc || ac) ? 1u : 0u;                // (the slot behind the last record is always free)
             } else {
                 if (dc) coef[(uint64_t)blk * 64u] = (int16_t)t;  // pass 5 adds the base
@@ -493,9 +499,9 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
     r.done = stop == 3u;
     if (kRec) {   // what is still staged leaves padded to a whole piece with records no block owns
         const uint32_t end = (r.recpos + kFlush - 1u) & ~(kFlush - 1u);
-        for (uint32_t q = r.recpos; q < end; ++q) stage_put(stage, q, kDummyRecord);
+        for (uint32_t q = r.recpos; q < end; ++q) stage_put<kFlush>(stage, q, kDummyRecord);
         while (flushed < end) {
-            stage_flush(stage, out.rec, flushed, rec_cap);
+            stage_flush<kFlush>(stage, out.rec, flushed, rec_cap);
             flushed += kFlush;
         }
     }
@@ -546,7 +552,8 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
     const uint32_t nwaves = blockDim.x >> 6;   // the launch sizes the workgroup (and its LDS) to the batch
     uint32_t* ring = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + wave * (kRingWords * kWave) + lane;
-    uint32_t* stage = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + nwaves * (kRingWords * kWave) + wave * (kStageSlots * kWave) + lane;
+    constexpr uint32_t kFlush = flush_records(L);
+    uint32_t* stage = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + nwaves * (kRingWords * kWave) + wave * (2u * kFlush * kWave) + lane;
     if (list) n = *list_count;
     const uint32_t ntasks = (n + kFrames - 1) / kFrames;
     // Tasks (kFrames frames each) are handed out through a counter: a wave that finishes early -- the
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     __builtin_amdgcn_s_waitcnt(0);   // dense form: the zeroing stores have landed before the sparse ones go out
     WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, 0u, 0u};
     if (live && blk0 < blocks_per_frame)
-        wr = walk_write<kRec>(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, sink, rec0, out.cap_rec, stage, out.sg);
+        wr = walk_write<kRec, kFlush>(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, sink, rec0, out.cap_rec, stage, out.sg);
     if (timing) tc[4] = clock64();
     const uint64_t stop_mask = __ballot(wr.done || wr.err != 0u) & seg;
     uint32_t st = 0, good_blocks = blocks_per_frame, rec_total = 0, seg_seen = 0;
@@ -695,8 +702,8 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
                  const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
                  uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
-    constexpr uint32_t kMaxWaves = (uint32_t)waves_per_group(kRec);
-    constexpr uint32_t kPerWave = kRingWords * kWave * 4u + (kRec ? kStageSlots * kWave * 4u : 0u);
+    constexpr uint32_t kMaxWaves = (uint32_t)waves_per_group(kRec, L);
+    constexpr uint32_t kPerWave = kRingWords * kWave * 4u + (kRec ? 2u * flush_records(L) * kWave * 4u : 0u);
     // the attribute belongs to the device's copy of the function: once per device and instantiation
     static std::atomic<uint64_t> raised{0};
     int dev = 0;

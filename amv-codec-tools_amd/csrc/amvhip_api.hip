@@ -403,12 +403,12 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     // Between the two stages coefficients travel as records (one word per DC and per non-zero AC coefficient).
     // Record space per frame: 20 per block is the most the synchronising kernel is given (a frame that needs more
     // goes to the serial kernel); a stream whose chunks are small gets proportionally less -- a record costs at
-    // least 3 bits of scan, in practice ~6 -- but never under 8 per block.  Always a multiple of 8 (32-byte pieces).
-    uint32_t cap_rec = g.blocks * 20u;
+    // least 3 bits of scan, in practice ~6 -- but never under 8 per block.  Always a multiple of 16 (64-byte bursts).
+    uint32_t cap_rec = (g.blocks * 20u + 15u) & ~15u;
     {
         const uint64_t by_stream = (blob_bytes / n) * 2u;                // records, at 4 bits of scan each
         const uint64_t floor_rec = (uint64_t)g.blocks * 8u;
-        if (by_stream < cap_rec) cap_rec = (uint32_t)((by_stream > floor_rec ? by_stream : floor_rec) + 7u) & ~7u;
+        if (by_stream < cap_rec) cap_rec = (uint32_t)((by_stream > floor_rec ? by_stream : floor_rec) + 15u) & ~15u;
     }
     const uint32_t lanes = (uint32_t)huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height);
     const uint32_t segs = ((g.mcu_cols + 9u) / 10u) * g.mcu_rows;
