@@ -125,14 +125,28 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
     uint32_t total = 0;
     if (!retry) {
         uint32_t carry = 0;   // FF flags of the eight bytes in front of the tile, nearest first
-        for (uint32_t t0 = 0; t0 * 4u < end; t0 += kWave) {
-            const uint32_t wi = t0 + lane;
-            uint32_t w = 0;
-            if (wi * 4u < end) {
-                const uint64_t bo = (uint64_t)wi * 4u;
-                if (bo + 4u <= guard) w = *reinterpret_cast<const uint32_t*>(base + bo);
-                else for (uint32_t q = 0; q < 4u; ++q) if (bo + q < guard) w |= (uint32_t)base[bo + q] << (8u * q);
+        // tiles of 64 words, eight at a time: the eight loads go out together, so a frame costs two or three trips
+        // to memory instead of one per tile (the kernel does little else than wait for them)
+        constexpr uint32_t kBurst = 8;
+        for (uint32_t b0 = 0; b0 * 4u < end && !retry; b0 += kBurst * kWave) {
+            uint32_t wv[kBurst];
+#pragma unroll
+            for (uint32_t q = 0; q < kBurst; ++q) {
+                const uint32_t wi = b0 + q * kWave + lane;
+                uint32_t w = 0;
+                if (wi * 4u < end) {
+                    const uint64_t bo = (uint64_t)wi * 4u;
+                    if (bo + 4u <= guard) w = *reinterpret_cast<const uint32_t*>(base + bo);
+                    else for (uint32_t j = 0; j < 4u; ++j) if (bo + j < guard) w |= (uint32_t)base[bo + j] << (8u * j);
+                }
+                wv[q] = w;
             }
+#pragma unroll
+            for (uint32_t q = 0; q < kBurst; ++q) {
+            const uint32_t t0 = b0 + q * kWave;
+            if (t0 * 4u >= end) break;
+            const uint32_t wi = t0 + lane;
+            const uint32_t w = wv[q];
             // which of this lane's four bytes are FF (bytes in front of the data never count)
             uint32_t ff = 0;
 #pragma unroll
@@ -165,6 +179,7 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
             for (uint32_t j = 0; j < 4u; ++j)
                 if (keep & (1u << j)) { out[d ^ 3u] = (uint8_t)(w >> (8u * j)); ++d; }   // big-endian inside the word
             total += tile_total;
+            }
         }
         // zero the tail up to the next 16-byte boundary: the decoder copies whole 16-byte pieces
         if (!retry && lane < ((16u - (total & 15u)) & 15u)) out[(total + lane) ^ 3u] = 0;
