@@ -182,7 +182,10 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     // patch t = lane, lane + 64, ...: row pair i2 = t / groups, group gi = t % groups, kept up by addition
     const uint32_t step_i2 = kWave / groups, step_gi = kWave - step_i2 * groups;
     uint32_t i2 = lane / groups, gi = lane - i2 * groups;
-    uint8_t* const frame = out + (uint64_t)f * g.frame_bytes + (uint64_t)(g.height - 1u - my * 16u) * g.stride + m0 * 48u;
+    // one base per wave (scalar) + 32-bit byte offsets inside the frame: picture row my*16+i is destination row
+    // H-1-(my*16+i) (:800)
+    uint8_t* const frame = out + (uint64_t)f * g.frame_bytes;
+    const uint32_t row0 = (g.height - 1u - my * 16u) * g.stride + m0 * 48u;
     for (; i2 < pairs; i2 += step_i2, gi += step_gi) {
         if (gi >= groups) { gi -= groups; ++i2; if (i2 >= pairs) break; }
         const uint32_t lc = gi * 4u;
@@ -208,8 +211,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
             cb[e] = __builtin_amdgcn_perm(b, b, 0x05040100u);
         }
         if (lc >= px) continue;                                        // right of the picture
-        // picture row my*16+i is destination row H-1-(my*16+i) (:800)
-        uint8_t* d8 = frame - (uint64_t)(2u * i2) * g.stride + lc * 3u;
+        uint32_t off = row0 - 2u * i2 * g.stride + lc * 3u;
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
             const uint2 yy = row ? yb : ya;
@@ -223,13 +225,13 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
             v.w[2] = __builtin_amdgcn_perm(bg, r23, 0x01070500u);          // R2 B3 G3 R3
             if (2u * i2 + (uint32_t)row >= vr) break;                      // odd picture height
             if (lc + 4u <= px) {                                           // rows are 4-byte aligned (AmvJpeg.c:1524), lc*3 is 0 mod 4
-                *reinterpret_cast<Px12*>(d8) = v;
+                *reinterpret_cast<Px12*>(frame + off) = v;
             } else {                                                       // the picture's last 1-3 pixels
 #pragma unroll
                 for (uint32_t q = 0; q < 9u; ++q)
-                    if (q < (px - lc) * 3u) d8[q] = (uint8_t)(v.w[q >> 2] >> (8u * (q & 3u)));
+                    if (q < (px - lc) * 3u) frame[off + q] = (uint8_t)(v.w[q >> 2] >> (8u * (q & 3u)));
             }
-            d8 -= g.stride;
+            off -= g.stride;
         }
     }
     if (!kRound) return;
