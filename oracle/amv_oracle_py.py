@@ -31,7 +31,7 @@ def build(force=False):
         subprocess.run(["make", "-C", HERE, "-s", "libamvoracle.so"], check=True)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(REF) or not os.path.exists(AVCREF)
                                              or os.path.getmtime(AVCREF) < max(os.path.getmtime(os.path.join(HERE, f))
-                                                                               for f in ("ref_harness.c", "Makefile"))):
+                                                                               for f in ("ref_harness.c", "ref_harness_imgconvert.c", "Makefile"))):
         subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
 
 
@@ -120,6 +120,8 @@ def avcref():
         R.amvref_sp5x_segment.argtypes = [_int, _vp, _int]
         R.amvref_mjpeg_huffman_spec.restype = _int
         R.amvref_mjpeg_huffman_spec.argtypes = [_int, _vp, _vp]
+        R.amvref_rgb24_to_yuvj420p.restype = None
+        R.amvref_rgb24_to_yuvj420p.argtypes = [_vp, _int, _int, _int, _vp, _vp, _vp]
         R.amvref_img_resample.restype = _int
         R.amvref_img_resample.argtypes = [_vp, _int, _int, _vp, _int, _int]
         R.amvref_mjpeg_huffman_codes.restype = None

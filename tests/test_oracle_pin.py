@@ -375,3 +375,29 @@ def test_img_resample_matches_reference_build(orc):
             ref = np.zeros_like(mine)
             assert R.amvref_img_resample(src.ctypes.data, iw, ih, ref.ctypes.data, ow, oh) == 0
             assert (mine == ref).all(), (iw, ih, ow, oh, kind)
+
+
+def test_rgb_to_yuvj420p_matches_reference_build(orc):
+    """row a17: the oracle's rgb24_to_yuvj420p against the reference's own (a static function of imgconvert.c, reached by
+    compiling that file into the harness): random, extreme and gradient content, several even sizes, padded source rows"""
+    R = _need_avcref(orc)
+    L = orc.lib()
+    rng = np.random.default_rng(12)
+    for w, h in ((160, 120), (320, 240), (2, 2), (18, 6), (130, 98)):
+        for kind in range(4):
+            stride = w * 3 + (0 if kind % 2 == 0 else 7)
+            src = np.zeros((h, stride), np.uint8)
+            if kind == 0:
+                src[:, : w * 3] = rng.integers(0, 256, (h, w * 3), dtype=np.uint8)
+            elif kind == 1:
+                src[:] = 255
+            elif kind == 2:
+                src[:, : w * 3] = (np.add.outer(np.arange(h) * 7, np.arange(w * 3) * 3) & 255).astype(np.uint8)
+            else:
+                src[:, : w * 3] = rng.integers(0, 2, (h, w * 3), dtype=np.uint8) * 255
+            got = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
+            want = [np.zeros_like(a) for a in got]
+            L.amvo_rgb24_to_yuvj420p(src.ctypes.data, stride, w, h, 0, *[a.ctypes.data for a in got])
+            R.amvref_rgb24_to_yuvj420p(src.ctypes.data, stride, w, h, *[a.ctypes.data for a in want])
+            for a, b in zip(got, want):
+                assert (a == b).all(), (w, h, kind)
