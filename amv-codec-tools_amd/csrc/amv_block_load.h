@@ -37,10 +37,13 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
     // memory, not three in a row): form of the frame, the segment's record range
     uint32_t rc = 0xffffffffu, r0 = 0u, r1 = 0u;
     if (in.rec != nullptr && !dense_only) {
-        const uint32_t* ss = in.seg_start + (uint64_t)f * (nsegs + 1u) + segidx;
+        // a segment's records lie in [from of its own entry, to of the next one) -- bounds, not exact positions: the range
+        // may begin with records of the (<= 4) blocks before the segment and end with records of the (<= 4) blocks behind
+        // it, which the block test below drops
+        const uint32_t* ss = in.seg_start + ((uint64_t)f * (nsegs + 1u) + segidx) * 2u;
         rc = in.rec_count[f];
         r0 = ss[0];
-        r1 = ss[1];
+        r1 = ss[3];
     }
     const bool records = rc != 0xffffffffu;
     skip = !records && in.rec != nullptr && !dense_only;   // a round launch reconstructs this frame
@@ -54,7 +57,7 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
         if (!cnt_ok) r1 = r0;
         const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec;
         int16_t* img = reinterpret_cast<int16_t*>(s_img);
-        const uint32_t b0 = (mcu0 * 6u) & 63u;
+        const uint32_t b0 = (mcu0 * 6u - g.blocks) & 63u;   // the block field counts from the frame's end
         for (uint32_t r = r0 + lane; r < r1; r += kWave) {
             const uint32_t w = rec[r];
             const uint32_t b = (((w >> 6) & 63u) - b0) & 63u, k = w & 63u;   // the segment's <= 60 blocks are consecutive

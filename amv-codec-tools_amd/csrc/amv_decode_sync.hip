@@ -45,6 +45,9 @@
 //      the frame's lane table and the reader adds them; dense form, the lane adds them to the DC values
 //      it stored itself.
 //
+//   amv_huffman_fast_kernel (one lane per frame, records form: what a batch that fills the chip that way gets)
+//      passes 1-3 and 5 fall away and pass 4 is a different walk, built on arithmetic instead of selects (below).
+//
 // Statuses equal the serial kernel's bit for bit (tests): the first error on the true path stops
 // the frame, nmcu_ok counts whole MCUs before it, TRUNCATED compares consumed with stored bits.
 // Chunks larger than the per-frame workspace window, or with a run of FF bytes longer than the 8-byte
@@ -371,7 +374,8 @@ struct WriteResult {
 
 // Where the strict pass puts its output.  Dense: the frame's coefficient lines (zeroed before).
 // Records: one 32-bit word per DC coefficient and per non-zero AC coefficient, in stream order -- bits 0-5 index
-// in block (0 = DC), bits 6-11 block modulo 64 (a reader works on <= 60 consecutive blocks), bit 15 "no block owns
+// in block (0 = DC), bits 6-11 (block - blocks per frame) modulo 64 (a reader works on <= 60 consecutive blocks; counting
+// from the frame's end suits the one-lane walk, whose block counter runs up to 0), bit 15 "no block owns
 // this record" (filler), bits 16-31 value; a DC value is the sum of the DC differences from the lane's first block
 // on, the reader adds the lane's base (lane table) -- plus the record index at which every MCU-row segment starts.
 struct Sink {
@@ -482,7 +486,7 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
                 seg_pos = hit ? r.recpos : seg_pos;
                 seg_hit = seg_hit || hit;
                 const uint32_t pos = isdc ? 0u : idx;
-                stage_put<kFlush>(stage, r.recpos, pos | ((blk & 63u) << 6) | ((uint32_t)(isdc ? t : val) << 16));
+                stage_put<kFlush>(stage, r.recpos, pos | (((blk - blocks_per_frame) & 63u) << 6) | ((uint32_t)(isdc ? t : val) << 16));
                 r.recpos += (dc || ac) ? 1u : 0u;                // (the slot behind the last record is always free)
             } else {
                 if (dc) coef[(uint64_t)blk * 64u] = (int16_t)t;  // pass 5 adds the base
@@ -500,7 +504,7 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
             alive = alive && !why && p < limit;
         }
         if (kRec && seg_hit) {   // once per <= 60 blocks
-            out.seg_start[r.seg_next++] = seg_pos;
+            reinterpret_cast<uint2*>(out.seg_start)[r.seg_next++] = make_uint2(seg_pos, seg_pos);   // exact: from == to
             const bool last = seg_col + 1u == sg.per_row;
             seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
             seg_col = last ? 0u : seg_col + 1u;
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     Sink sink;
     sink.coef = kRec ? nullptr : out.coef + (uint64_t)fsafe * blocks_per_frame * 64u;
     sink.rec = kRec ? out.rec + (uint64_t)fsafe * out.cap_rec : nullptr;
-    sink.seg_start = kRec ? out.seg_start + (uint64_t)fsafe * (out.sg.count + 1u) : nullptr;
+    sink.seg_start = kRec ? out.seg_start + (uint64_t)fsafe * (out.sg.count + 1u) * 2u : nullptr;
     const uint32_t valid_bits = live ? total * 8u : 0u;
     if (!kRec && live) {   // dense form: the frame's coefficient lines start as zeros
         uint4* z = reinterpret_cast<uint4*>(sink.coef);
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
             uint4 ent = make_uint4(real ? wr.dc_first : kNever, (uint32_t)by, (uint32_t)bu, (uint32_t)bv);
             reinterpret_cast<uint4*>(out.lane_tab)[(uint64_t)frame * L + sub] = ent;
             // segments the decoder never started begin (and end) at the total; so does the end of the last one
-            for (uint32_t m = seg_seen + sub; m <= out.sg.count; m += L) sink.seg_start[m] = rec_total;
+            for (uint32_t m = seg_seen + sub; m <= out.sg.count; m += L) reinterpret_cast<uint2*>(sink.seg_start)[m] = make_uint2(rec_total, rec_total);
         }
     } else {
         __builtin_amdgcn_s_waitcnt(0);
@@ -710,6 +714,305 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     }   // next task
 }
 
+// =============================================================================================
+// One lane per frame (a batch that fills the chip that way: no speculation, no lane table).  The symbol step of
+// walk_write spends most of its ~90 instructions on selects -- which table, which component's DC sum, is the lane
+// alive, did the block end, did a segment start -- and the kernel is bound by VALU issue.  Here the step is
+// arithmetic on a state chosen for it, under half as many instructions:
+//   * bit position: t = bits consumed - 1.  The window's two words are read from the lane's ring at (t >> 5) (slot 16
+//     mirrors slot 0, so the pair is one ds_read2) and the next 32 bits are alignbit(hi, lo, ~t): no window registers
+//     to shift along, no "did we cross a word";
+//   * tables: 32-bit entries (HuffDecodeImage::fast) in four 8 KB regions; the region's address bits come from the
+//     state with shifts and ANDs, both levels are read and OR-ed; the entry's fields sit in bytes of their own, so
+//     adding "bits used" to the position or "advance" to the index is one instruction on a byte of the entry;
+//   * end of block: bit 6 of (index + advance) -- the end-of-block symbol advances by 192 --, as a mask dc = -bit: the
+//     index is ANDed with ~dc, the blocks-to-go counter, the block-in-MCU counter (counting down, wrapping through an
+//     unsigned min) and the table choice move by it;
+//   * DC prediction: the three running sums live in LDS, the component's slot address follows from the block-in-MCU
+//     counter, every step adds (value AND "this is a DC symbol");
+//   * a record is written to the next staging slot at every step and counted by adding the entry's "carries a value"
+//     bit (which sits at the stride of a staging slot);
+//   * the frame's end: once the blocks-to-go counter reaches 0 the looked-up entry is ANDed to zero: the lane stands
+//     still, consuming and emitting nothing, until the wave's slowest lane is done;
+//   * errors: "no such code" advances the index by 80, so that like an over-long run it lands in 65..143, which one
+//     unsigned compare per symbol (folded into a running minimum) notices; a stride of eight symbols that raised the flag
+//     is walked again from its saved start state, one symbol at a time, to find where the walk stops (fast_replay);
+//   * where an MCU-row segment starts is looked at once per stride: its entry gets the record counts before and after
+//     the stride in which its first DC symbol came (SyncSinks::seg_start: bounds, which the reader's block test tightens).
+// LDS addresses are formed with OR where the layout allows (regions aligned to their size).
+// =============================================================================================
+
+namespace {
+
+constexpr uint32_t kFastRegion = kFastWords * 4u;            // bytes per table in LDS
+constexpr uint32_t kFastTableBytes = 4u * kFastRegion;
+constexpr uint32_t kSlot = kWave * 4u;                       // bytes between a lane's consecutive slots
+constexpr uint32_t kFastRingBytes = (kRingWords + 1u) * kSlot;   // slot 16 mirrors slot 0
+constexpr uint32_t kFastSumBytes = 4u * kSlot;                   // three sums; aligned to its size
+constexpr uint32_t fast_stage_bytes(uint32_t flush) { return 2u * flush * kSlot; }
+constexpr uint32_t fast_per_wave(uint32_t flush) { return fast_stage_bytes(flush) + kFastSumBytes + kFastRingBytes; }
+constexpr uint32_t fast_waves(uint32_t flush) {
+    const uint32_t w = (160u * 1024u - kFastTableBytes) / fast_per_wave(flush);
+    return w > 16u ? 16u : w;
+}
+
+struct FastState {
+    uint32_t t;      // bits consumed - 1
+    uint32_t k;      // next coefficient index, 0 = the DC symbol comes next
+    uint32_t j;      // 5 - block inside the MCU
+    uint32_t togo6;  // (block - blocks per frame) << 6: negative until the frame's last block is done (a record's block
+                     // field is bits 6-11 of it: the reader knows the frame's block count)
+    uint32_t rp8;    // next free record << 8 (a staging slot is 256 bytes)
+    uint32_t dc;     // ~0 when the next symbol is a DC symbol, else 0
+};
+
+// LDS by byte address: the kernel's dynamic LDS is all the LDS it has, so it starts at 0 (checked on entry) and the
+// addresses the walk computes go to the instruction as they are
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_load(uint32_t a) { return *(const lds_u32*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_store(uint32_t a, uint32_t v) { *(lds_u32*)(uintptr_t)a = v; }
+// (x << 3) + y in one instruction (left alone the compiler forms the shift, an AND and an add)
+__device__ __forceinline__ uint32_t shl3_add(uint32_t x, uint32_t y) {
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+
+__device__ __forceinline__ void fast_ring_put(const Stream& s, uint32_t x, const uint4& v) {   // x: multiple of 4
+    uint32_t* d = s.ring + (x & (kRingWords - 1u)) * kWave;
+    d[0] = v.x; d[kWave] = v.y; d[2 * kWave] = v.z; d[3 * kWave] = v.w;
+    if ((x & (kRingWords - 1u)) == 0u) s.ring[kRingWords * kWave] = v.x;
+}
+
+__device__ __forceinline__ void fast_open(Stream& s) {   // the ring holds words [0, 16)
+    const uint4 a = stream_piece(s, 0u), b = stream_piece(s, 4u), c = stream_piece(s, 8u), d = stream_piece(s, 12u);
+    fast_ring_put(s, 0u, a);
+    fast_ring_put(s, 4u, b);
+    fast_ring_put(s, 8u, c);
+    fast_ring_put(s, 12u, d);
+    s.hi = kRingWords;
+    stream_request(s);
+}
+
+// before a stride: eight symbols of <= 27 bits starting in word w read words w .. w + 7 (and the one before w, whose
+// bits are all behind the position, at a word boundary: any content will do)
+__device__ __forceinline__ void fast_service(Stream& s, uint32_t w) {
+    while (w + 9u > s.hi) {
+        fast_ring_put(s, s.hi, s.pf0);
+        fast_ring_put(s, s.hi + 4u, s.pf1);
+        s.hi += 8u;
+        stream_request(s);
+    }
+}
+
+// the next 32 bits
+__device__ __forceinline__ uint32_t fast_window(uint32_t ringb, uint32_t t) {
+    const uint32_t ra = shl3_add(t & 0x1e0u, ringb);
+    return __builtin_amdgcn_alignbit(lds_load(ra), lds_load(ra + kSlot), ~t);
+}
+
+// the entry they select: m1 at the region's start, m2 kFastM2Word words in, both read, OR-ed
+__device__ __forceinline__ uint32_t fast_lookup(const FastState& s, uint32_t v) {
+    // chroma (j = 0, 1) -> + one region; AC -> + two
+    const uint32_t toff = (((3u * kFastRegion) >> s.j) & kFastRegion) | (~s.dc & (2u * kFastRegion));
+    const uint32_t e1 = lds_load(((v >> 21) & 0x7fcu) | toff);
+    const uint32_t x2 = max(v >> 16, kFastLongFirst - 1u);
+    const uint32_t e2 = lds_load((x2 << 2) + (toff + (kFastM2Word * 4u - 4u * (kFastLongFirst - 1u))));
+    return e1 | e2;
+}
+
+// eight symbols, every lane, straight-line.  worst: the smallest (index + advance - 65) seen: < 79 = a symbol that
+// no decoder accepts (an over-long run, or no such code).
+template <uint32_t kFlush>
+__device__ __forceinline__ void fast_stride(uint32_t ringb, uint32_t stageb, uint32_t sumb, FastState& s, uint32_t& worst) {
+#pragma unroll
+    for (int it = 0; it < kStrideWrite; ++it) {
+        // issued together, ahead of the table look-up: the component's DC sum (j = 1 Cb, j = 0 Cr, else Y) and the window
+        const uint32_t ca = (((2u * kSlot) >> s.j) & (3u * kSlot)) | sumb;
+        const uint32_t sum = lds_load(ca);
+        const uint32_t v = fast_window(ringb, s.t);
+        __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the sum's read behind the look-up and waits twice)
+        const uint32_t run = (uint32_t)((int32_t)s.togo6 >> 31);   // 0 once the frame's last block is done
+        const uint32_t e = fast_lookup(s, v) & run;
+        // magnitude bits -> value (AmvJpeg.c:924-933): sign-extended, x >= 0 means "leading 0 bit": value = x - (2^size - 1);
+        // x < 0: value = x + 2^size.  Both are x - (full ^ (x >> 31)).  The width operand takes bits 0-4 of e (the size).
+        const uint32_t used = e >> 24;
+        const int x = __builtin_amdgcn_sbfe((int)v, 0u - used, e);
+        const uint32_t full = __builtin_amdgcn_ubfe(0xffffffffu, 0u, e);
+        const uint32_t val = (uint32_t)x - (full ^ (uint32_t)(x >> 31));
+        s.t += used;
+        const uint32_t kn = s.k + ((e >> 16) & 255u);
+        worst = min(worst, kn - 65u);
+        const uint32_t dcn = (uint32_t)__builtin_amdgcn_sbfe((int)kn, 6u, 1u);   // ~0: the block ends with this symbol
+        // DC difference (:945-951) joins its component's sum (:1200-1221)
+        lds_store(ca, sum + (val & s.dc));
+        const uint32_t rv = val + (sum & s.dc);
+        lds_store((s.rp8 & ((2u * kFlush - 1u) << 8)) | stageb, (rv << 16) | (s.togo6 & 0xfc0u) | (kn - 1u));
+        s.rp8 += e & kFastEmit;
+        s.k = kn & ~dcn;
+        s.togo6 += kn & 64u;
+        s.j = min(s.j + dcn, 5u);   // 0 - 1 wraps to 5
+        s.dc = dcn;
+    }
+}
+
+// A stride that raised the flag, once more from its start state, without writing: where does the walk stop?
+// why: 1 no such code (AmvJpeg.c:887), 2 index past 63 (:967-969); the state is the one the strict walk stops in.
+__device__ __forceinline__ uint32_t fast_replay(uint32_t ringb, FastState& s) {
+    for (int it = 0; it < kStrideWrite; ++it) {
+        if (s.togo6 == 0u) break;
+        const uint32_t e = fast_lookup(s, fast_window(ringb, s.t));
+        if (e & kFastInvalid) return 1u;
+        const uint32_t kn = s.k + ((e >> 16) & 255u);
+        s.t += e >> 24;                      // an over-long run is consumed before the walk gives up
+        if (kn - 65u < 15u) return 2u;
+        const bool end = (kn & 64u) != 0u;
+        s.rp8 += e & kFastEmit;
+        s.k = end ? 0u : kn;
+        s.togo6 += kn & 64u;
+        s.j = end ? (s.j == 0u ? 5u : s.j - 1u) : s.j;
+        s.dc = end ? ~0u : 0u;
+    }
+    return 0u;
+}
+
+}  // namespace
+
+// dynamic LDS: [ the four tables, 32 KB | staged records, 2 * kFlush slots per wave | DC sums, 4 slots per wave |
+//                rings, 17 slots per wave ]
+template <uint32_t kFlush>
+__global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
+    const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+    uint32_t blocks_per_frame, uint32_t cap_words,
+    const HuffDecodeImage* __restrict__ img, SyncOut out, int32_t* __restrict__ status,
+    uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
+    {   // tables, shared by the waves of the workgroup
+        const uint4* src = reinterpret_cast<const uint4*>(&img->fast[0][0]);
+        uint4* dst = reinterpret_cast<uint4*>(s_mem);
+        for (uint32_t i = threadIdx.x; i < kFastTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_mem != 0u) __builtin_trap();   // see lds_load
+    const uint32_t stageb = kFastTableBytes + wave * fast_stage_bytes(kFlush) + lane * 4u;
+    const uint32_t sumb = kFastTableBytes + nwaves * fast_stage_bytes(kFlush) + wave * kFastSumBytes + lane * 4u;
+    const uint32_t ringb = kFastTableBytes + nwaves * (fast_stage_bytes(kFlush) + kFastSumBytes) + wave * kFastRingBytes + lane * 4u;
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(s_mem + stageb);
+    if (list) n = *list_count;
+    const uint32_t ntasks = (n + kWave - 1) / kWave;
+    const SegGeom sg = out.sg;
+    for (;;) {
+        uint32_t task = 0;
+        if (lane == 0) task = atomicAdd(queue, 1u);
+        task = __shfl(task, 0);
+        if (task >= ntasks) return;
+        const uint32_t idx = task * kWave + lane;
+        const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
+        const uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+        if (frame != kNever && total == kNever) out.rec_count[frame] = kNever;
+        const bool live = total != kNever;
+        const uint32_t fsafe = live ? frame : 0u;
+        uint32_t* const rec = out.rec + (uint64_t)fsafe * out.cap_rec;
+        uint2* const seg_out = reinterpret_cast<uint2*>(out.seg_start) + (uint64_t)fsafe * (sg.count + 1u);
+        const uint32_t valid_bits = live ? total * 8u : 0u;
+        Stream win{ws + (uint64_t)fsafe * cap_words, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
+                   make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        fast_open(win);
+        for (uint32_t c = 0; c < 3u; ++c) lds_store(sumb + c * kSlot, 0u);
+
+        // a lane without a frame stands still from the start
+        FastState s{0xffffffffu, 0u, 5u, live ? 0u - (blocks_per_frame << 6) : 0u, 0u, ~0u};
+        bool alive = live;
+        uint32_t stop = 0;           // 1 no such code, 2 index past 63, 3 the frame's last block is done
+        uint32_t flushed = 0;        // records before this one have left for memory (a multiple of kFlush)
+        uint32_t seg_next = 0, seg_col = 0, seg_blk = 0;   // the next MCU-row segment whose first DC symbol has not come yet
+        uint32_t end_blocks = 0;     // whole blocks when the walk stopped
+        // records [flushed, flushed + 8) leave the staging area: the first three quarters of a 128-byte line wait in
+        // registers for the fourth, so that memory sees whole lines (a lane's staging column holds two bursts of 8)
+        uint4 held[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) held[q] = make_uint4(0, 0, 0, 0);
+        auto flush = [&]() {
+            const uint32_t* p = stage + (flushed & (2u * kFlush - 1u)) * kWave;
+            const uint4 v0 = make_uint4(p[0], p[kWave], p[2 * kWave], p[3 * kWave]);
+            const uint4 v1 = make_uint4(p[4 * kWave], p[5 * kWave], p[6 * kWave], p[7 * kWave]);
+            const uint32_t quarter = (flushed >> 3) & 3u;
+            if (quarter == 3u) {
+                if (flushed + 8u <= out.cap_rec) {   // never past the frame's record space (a multiple of 32); an overfull frame is redone densely
+                    uint4* d = reinterpret_cast<uint4*>(rec + flushed - 24u);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) d[q] = held[q];
+                    d[6] = v0; d[7] = v1;
+                }
+            } else if (quarter == 0u) { held[0] = v0; held[1] = v1; }
+            else if (quarter == 1u) { held[2] = v0; held[3] = v1; }
+            else { held[4] = v0; held[5] = v1; }
+            flushed += 8u;
+        };
+        while (__ballot(alive) != 0ull) {
+            if (alive) fast_service(win, (s.t + 1u) >> 5);
+            if ((s.rp8 >> 8) - flushed >= 8u) flush();
+            const bool running = alive;
+            const FastState start = s;
+            uint32_t worst = ~0u;
+            fast_stride<kFlush>(ringb, stageb, sumb, s, worst);
+            const bool trouble = alive && worst < 79u;
+            if (__ballot(trouble) != 0ull) {   // a damaged stream
+                if (trouble) {
+                    s = start;
+                    stop = fast_replay(ringb, s);
+                    alive = false;
+                }
+            }
+            if (alive && s.togo6 == 0u) { stop = 3u; alive = false; }
+            bool hit = false;
+            uint32_t blocks = 0;
+            if (running) {
+                blocks = blocks_per_frame + (uint32_t)((int32_t)s.togo6 >> 6);   // whole blocks so far
+                // blocks whose DC symbol is out: did the next segment's first one come in this stride?  (At most one
+                // does: a segment is >= 6 blocks = 12 symbols.)
+                hit = seg_next < sg.count && blocks + (s.k ? 1u : 0u) > seg_blk;
+                if (!alive) { end_blocks = blocks; s.togo6 = 0u; }   // stands still from here on
+            }
+            if (__ballot(hit) != 0ull) {
+                if (hit) {
+                    seg_out[seg_next++] = make_uint2(start.rp8 >> 8, s.rp8 >> 8);
+                    const bool last = seg_col + 1u == sg.per_row;
+                    seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
+                    seg_col = last ? 0u : seg_col + 1u;
+                }
+            }
+        }
+        const uint32_t recpos = s.rp8 >> 8;
+        {   // what is still staged leaves padded to a whole line with records no block owns
+            const uint32_t end = (recpos + 31u) & ~31u;
+            while (flushed < end) {
+                for (uint32_t q = flushed < recpos ? recpos : flushed; q < flushed + 8u; ++q) stage_put<kFlush>(stage, q, kDummyRecord);
+                flush();
+            }
+        }
+        if (live) {
+            const uint32_t bits = s.t + 1u + (stop == 1u ? 17u : 0u);   // FORMAT: the reference has read 17 bits by then
+            uint32_t st = stop == 1u ? kStFormat : (stop == 2u ? kStOverrun : 0u);
+            if (bits > valid_bits) st |= kStTruncated;
+            reinterpret_cast<uint4*>(out.lane_tab)[frame] = make_uint4(0u, 0u, 0u, 0u);
+            // segments the decoder never started begin (and end) at the total; so does the end of the last one
+            for (uint32_t m = seg_next; m <= sg.count; ++m) seg_out[m] = make_uint2(recpos, recpos);
+            if (stats) atomicAdd(&stats[0], 1ull);
+            if (recpos > out.cap_rec) {   // more non-zero coefficients than the record space holds
+                out.rec_count[frame] = kNever;
+                out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
+            } else {
+                status[frame] = (int32_t)st;
+                nmcu_ok[frame] = end_blocks / 6u;
+                out.rec_count[frame] = recpos;
+            }
+        }
+    }   // next task
+}
+
 namespace {
 
 template <int L, bool kRec>
@@ -740,6 +1043,31 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
     if (grid > groups) grid = groups;
     hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * waves), kTableBytes + waves * kPerWave, s, ws,
                        ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
+}
+
+template <uint32_t kFlush>
+void launch_fast(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
+                 const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
+                 const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
+                 uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
+    constexpr uint32_t kMaxWaves = fast_waves(kFlush);
+    static std::atomic<uint64_t> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_fast_kernel<kFlush>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFastTableBytes + kMaxWaves * fast_per_wave(kFlush)));
+        raised.fetch_or(bit, std::memory_order_relaxed);
+    }
+    const uint32_t tasks = (n + (uint32_t)kWave - 1u) / (uint32_t)kWave;
+    uint32_t waves = (tasks + cus - 1u) / cus;
+    if (waves < 4u) waves = 4u;
+    if (waves > kMaxWaves) waves = kMaxWaves;
+    uint32_t grid = (tasks + waves - 1u) / waves;
+    if (grid > cus) grid = cus;
+    hipLaunchKernelGGL((amv_huffman_fast_kernel<kFlush>), dim3(grid), dim3(kWave * waves), kFastTableBytes + waves * fast_per_wave(kFlush), s,
+                       ws, ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
 }
 
 }  // namespace
@@ -792,7 +1120,7 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
             case 8: launch_sync<8, true>(AMV_SYNC_ARGS); break;
             case 4: launch_sync<4, true>(AMV_SYNC_ARGS); break;
             case 2: launch_sync<2, true>(AMV_SYNC_ARGS); break;
-            case 1: launch_sync<1, true>(AMV_SYNC_ARGS); break;
+            case 1: launch_fast<8>(AMV_SYNC_ARGS); break;
             default: launch_sync<16, true>(AMV_SYNC_ARGS); break;
         }
     } else {

@@ -30,9 +30,12 @@ void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
 int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels);
 // Where the entropy stage puts its result.  rec == nullptr: dense coefficient lines in coef
 // ([n][blocks][64] int16).  Otherwise the records form, per frame: rec[cap_rec] (one word per DC coefficient and
-// per non-zero AC coefficient, stream order: bits 0-5 index in block (0 = DC), 6-11 block modulo 64, bit 15 filler,
-// 16-31 value; a DC value counts from the decoding lane's first block), seg_start[segs + 1] first record of each
-// MCU-row segment of kSegMcus MCUs (what one wave of the reconstruction takes), lane_tab[lanes] = {first block,
+// per non-zero AC coefficient, stream order: bits 0-5 index in block (0 = DC), 6-11 (block - blocks per frame) modulo 64, bit 15 filler,
+// 16-31 value; a DC value counts from the decoding lane's first block), seg_start[segs + 1][2] = {from, to} for each
+// MCU-row segment of kSegMcus MCUs (what one wave of the reconstruction takes): the segment's first record is at or
+// after `from` with only records of the <= 4 blocks before it in between, and the records of the segment before end
+// ahead of `to`, with only records of this segment's first <= 4 blocks in between (the exact position twice, or the
+// record counts around the eight symbols in which the segment began), lane_tab[lanes] = {first block,
 // DC base Y, Cb, Cr} of each of the `lanes` lanes that decoded the frame, rec_count (total, or ~0 = this frame is in
 // dense form in coef because it went through amv_huffman_kernel).
 struct SyncSinks {

@@ -107,11 +107,25 @@ static constexpr int kLut2Pages = 16;
 // the 512: they all begin with six one-bits), so m2 is indexed by the 10 bits behind those six.
 static constexpr int kLut2PagesPerTable = 5;
 static constexpr int kM2Bits = 10;
+// fast[t] is table t once more, for the one-lane-per-frame walk (amv_huffman_fast_kernel), as 32-bit entries laid out
+// so that a symbol step is arithmetic, not selects: words 0-511 are indexed by the next 9 bits; words 512-1536 by
+// max(next 16 bits, 0xfbff) - 0xfbff, i.e. word 512 (always 0) for every stream that does not begin with six one-bits
+// and the code's entry for one that does -- the two reads are OR-ed, the entry of a 9-bit prefix that only long codes
+// share is 0.  Entry: bits 0-3 magnitude bits (bit 4 is 0: the whole word can serve as a bit-field width operand),
+// bit 5 "no such code", bit 8 "carries a value" (a record's stride in the staging area), byte 2 how far the
+// coefficient index moves (run + 1; 1 for a DC symbol; 192 for end-of-block: bit 6 of index + 192 is set for every
+// index 1..63; 80 for "no such code", so that index + 80 falls into 65..143 like an over-long run, 65..79, and unlike
+// anything a decoder accepts), byte 3 code length + magnitude bits.
+static constexpr uint32_t kFastWords = 2048;          // per table: 8 KB, a power of two (the table is chosen by OR-ing address bits)
+static constexpr uint32_t kFastM2Word = 512;
+static constexpr uint32_t kFastLongFirst = 0xfc00u;   // 16-bit windows from here on begin with six one-bits
+static constexpr uint32_t kFastInvalid = 1u << 5, kFastEmit = 1u << 8, kFastEobAdvance = 192u, kFastInvalidAdvance = 80u;
 struct HuffDecodeImage {
     uint16_t l1[4][1 << kLut1Bits];
     uint16_t l2[kLut2Pages][1 << kLut2Bits];
     uint16_t m1[4][1 << kLut1Bits];
     uint16_t m2[4][1 << kM2Bits];
+    uint32_t fast[4][kFastWords];
 };
 
 // Encoder code book: for symbol s of table t, code | (length << 16)

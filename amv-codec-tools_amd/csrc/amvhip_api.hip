@@ -150,6 +150,26 @@ void build_images(HuffDecodeImage& dec, HuffEncodeImage& enc) {
             if (e1 & 0x8000u) dec.m2[t][x] = merged(dec.l2[e1 & 0xffu][(w16 >> (16 - kLut1Bits - kLut2Bits)) & ((1u << kLut2Bits) - 1u)], t);
         }
     }
+    // the one-lane-per-frame walk's form (amv_tables.h)
+    auto fast = [](uint16_t e, int t) -> uint32_t {
+        const uint32_t len = (e >> 8) & 31u, sym = e & 0xffu, size = sym & 15u;
+        if (len == 0) return kFastInvalid | (kFastInvalidAdvance << 16);
+        const bool dc = t < 2;
+        const uint32_t adv = dc ? 1u : (sym == 0 ? kFastEobAdvance : (sym >> 4) + 1u);
+        return size | ((dc || size) ? kFastEmit : 0u) | (adv << 16) | ((len + size) << 24);
+    };
+    for (int t = 0; t < 4; ++t) {
+        for (int i = 0; i < (1 << kLut1Bits); ++i) {
+            const uint16_t e = dec.l1[t][i];
+            dec.fast[t][i] = (e & 0x8000u) ? 0u : fast(e, t);
+        }
+        for (uint32_t w16 = kFastLongFirst; w16 < 0x10000u; ++w16) {
+            const uint16_t e1 = dec.l1[t][w16 >> (16 - kLut1Bits)];
+            if (e1 & 0x8000u)
+                dec.fast[t][kFastM2Word + 1u + (w16 - kFastLongFirst)] =
+                    fast(dec.l2[e1 & 0xffu][(w16 >> (16 - kLut1Bits - kLut2Bits)) & ((1u << kLut2Bits) - 1u)], t);
+        }
+    }
 }
 
 // ---- timing ---------------------------------------------------------------------------------
@@ -403,12 +423,12 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     // Between the two stages coefficients travel as records (one word per DC and per non-zero AC coefficient).
     // Record space per frame: 20 per block is the most the synchronising kernel is given (a frame that needs more
     // goes to the serial kernel); a stream whose chunks are small gets proportionally less -- a record costs at
-    // least 3 bits of scan, in practice ~6 -- but never under 8 per block.  Always a multiple of 16 (64-byte bursts).
-    uint32_t cap_rec = (g.blocks * 20u + 15u) & ~15u;
+    // least 3 bits of scan, in practice ~6 -- but never under 8 per block.  Always a multiple of 32 (whole 128-byte lines).
+    uint32_t cap_rec = (g.blocks * 20u + 31u) & ~31u;
     {
         const uint64_t by_stream = (blob_bytes / n) * 2u;                // records, at 4 bits of scan each
         const uint64_t floor_rec = (uint64_t)g.blocks * 8u;
-        if (by_stream < cap_rec) cap_rec = (uint32_t)((by_stream > floor_rec ? by_stream : floor_rec) + 15u) & ~15u;
+        if (by_stream < cap_rec) cap_rec = (uint32_t)((by_stream > floor_rec ? by_stream : floor_rec) + 31u) & ~31u;
     }
     const uint32_t lanes = (uint32_t)huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height);
     const uint32_t segs = ((g.mcu_cols + 9u) / 10u) * g.mcu_rows;
@@ -416,7 +436,7 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     if (int r = ensure(c, c->coef, (size_t)round * g.blocks * 128)) return r;
     if (int r = ensure(c, c->nmcu, (size_t)n * 4)) return r;
     if (int r = ensure(c, c->rec, (size_t)n * cap_rec * 4)) return r;
-    if (int r = ensure(c, c->seg_start, (size_t)n * (segs + 1) * 4)) return r;
+    if (int r = ensure(c, c->seg_start, (size_t)n * (segs + 1) * 8)) return r;
     if (int r = ensure(c, c->lane_tab, (size_t)n * lanes * 16)) return r;
     if (int r = ensure(c, c->rec_count, (size_t)n * 4)) return r;
     SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)c->rec.p, cap_rec, (uint32_t*)c->seg_start.p, (uint32_t*)c->lane_tab.p, lanes,

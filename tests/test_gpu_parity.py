@@ -1141,3 +1141,49 @@ def test_adpcm_trellis_matches_oracle(ctx, pkg, orc):
         want, want_idx = orc.adpcm_encode_chunk_trellis(seg, want_idx, 3)
         assert m == len(want) and out.tobytes() == want and idx.value == want_idx
     assert lib.amvhip_adpcm_encode_frame_trellis(ctx.h, pcm.ctypes.data, 700, ctypes.byref(idx), 6, out.ctypes.data, out.size) == pkg.ERR_ARG
+
+
+def test_one_lane_per_frame_walk(pkg, orc, amv1):
+    """the entropy kernel a chip-filling batch gets (one lane per frame, amv_huffman_fast_kernel) on batches small enough
+    to check every byte: a context created with AMVHIP_SYNC_LANES=1 decodes the reference's clip, geometries with one,
+    two and "ten plus one" MCU-row segments per row, damaged / truncated / garbage chunks (the stride that raised the
+    flag is walked again: status, first bad MCU), frames with more coefficients than the record space holds and frames
+    the unstuffer hands to the serial kernel -- status and pixels equal the oracle's, in both output modes"""
+    import os
+    old = os.environ.get("AMVHIP_SYNC_LANES")
+    os.environ["AMVHIP_SYNC_LANES"] = "1"
+    try:
+        one = pkg.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("AMVHIP_SYNC_LANES", None)
+        else:
+            os.environ["AMVHIP_SYNC_LANES"] = old
+    try:
+        rng = np.random.default_rng(2024)
+        got, st = _gpu_decode(one, amv1["video"], amv1["info"]["width"], amv1["info"]["height"])
+        want, wst = _oracle_decode(orc, amv1["video"], amv1["info"]["width"], amv1["info"]["height"])
+        assert (st == wst).all() and (got == want).all()
+        for w, h, n in ((160, 120, 130), (320, 240, 7), (176, 144, 9), (16, 16, 70), (336, 32, 5), (130, 98, 66)):
+            chunks = _synth_chunks(orc, n, w, h)
+            noise = orc.encode_frame(rng.integers(0, 256, (h, w, 3)).astype(np.uint8), w, h)   # fills the record space
+            flat = orc.encode_frame(np.full((h, w, 3), 128, np.uint8), w, h)                    # DC + EOB only
+            chunks += [noise, flat, noise[: len(noise) // 2], flat[:3], b"", b"\xff\xd8" + b"\xff" * 300]
+            for k in range(10):   # damage at random places, early and late
+                b = bytearray(chunks[k % n])
+                for _ in range(1 + k % 3):
+                    b[int(rng.integers(2, len(b) - 2))] ^= 1 << int(rng.integers(0, 8))
+                chunks.append(bytes(b))
+            c = chunks[1]
+            chunks.append(c[:12] + b"\xff" * 12 + c[12:])   # a run of FF bytes past the unstuffer's look-back: serial kernel
+            for flags in (0, 1):
+                got, st = _gpu_decode(one, chunks, w, h, flags, pad_front=flags)
+                want, wst = _oracle_decode(orc, chunks, w, h, flags)
+                assert (st == wst).all(), (w, h, flags, st, wst)
+                assert (got == want).all(), (w, h, flags)
+            assert (wst != 0).sum() >= 4
+            got, st = _gpu_decode_ffmpeg(one, pkg, chunks, w, h)
+            want, wst = _oracle_decode_ffmpeg(orc, chunks, w, h)
+            assert (st == wst).all() and (got == want).all(), (w, h)
+    finally:
+        one.close()
