@@ -26,6 +26,7 @@ namespace amv {
 namespace {
 
 struct __attribute__((aligned(4))) Px12 { uint32_t w[3]; };   // four BGR pixels
+typedef short short2v __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
 constexpr int kSegMcus = 10;   // MCUs per wave: 60 of 64 lanes busy in the transform
@@ -85,6 +86,19 @@ __device__ __forceinline__ void idct8(int& v0, int& v1, int& v2, int& v3, int& v
     v7 = (a7 - a1) >> kOut;
 }
 
+// the quantiser steps, scan order, four to a dword: [0] luma, [1] chroma.  A lane reads its component's sixteen dwords
+// once and multiplies by bytes of them (a select between two literals per coefficient cost 40 instructions a block).
+struct QuantWords { uint32_t w[2][16]; };
+constexpr QuantWords pack_quant() {
+    QuantWords q{};
+    for (int i = 0; i < 64; ++i) {
+        q.w[0][i >> 2] |= (uint32_t)kQuantLuma[i] << (8 * (i & 3));
+        q.w[1][i >> 2] |= (uint32_t)kQuantChroma[i] << (8 * (i & 3));
+    }
+    return q;
+}
+__device__ const QuantWords kQuantWords = pack_quant();
+
 // iclp[] of AmvJpeg.c:1073-1080 (table spans -512..511; beyond it the reference reads out of
 // bounds, defined here as saturation)
 __device__ __forceinline__ int clamp_iclp(int x) { return min(max(x, -256), 255); }
@@ -114,6 +128,15 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
 
     const uint32_t lane = threadIdx.x;
     const uint32_t my = blockIdx.y, seg = blockIdx.z;   // no integer division to find them
+    uint32_t qw[16];   // this lane's quantiser steps (blocks 4 and 5 of an MCU are chroma), on their way while stage A runs
+    {
+        const uint4* q4 = reinterpret_cast<const uint4*>(kQuantWords.w[lane % 6u >= 4u ? 1 : 0]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 q = q4[i];
+            qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
+        }
+    }
     for (uint32_t item = blockIdx.x;; item += gridDim.x) {
     uint32_t f, slot;
     if (!select_frame(sel, n, item, f, slot)) return;
@@ -134,13 +157,10 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
 #pragma unroll
         for (int nat = 0; nat < 64; ++nat) {
             const int scan = kScanOfNatural[nat];
-            const int step = chroma ? (int)kQuantChroma[scan] : (int)kQuantLuma[scan];
-            v[nat] = coef_at(c, scan) * step;
+            v[nat] = coef_at(c, scan) * (int)((qw[scan >> 2] >> (8 * (scan & 3))) & 255u);
         }
-        if (!(flags & kFlagZigzagFixed)) {   // amvlib's table reads scan position 37 at natural (3,4)
-            const int step = chroma ? (int)kQuantChroma[kAmvlibQuirkScan] : (int)kQuantLuma[kAmvlibQuirkScan];
-            v[kAmvlibQuirkNatural] = coef_at(c, kAmvlibQuirkScan) * step;
-        }
+        if (!(flags & kFlagZigzagFixed))     // amvlib's table reads scan position 37 at natural (3,4)
+            v[kAmvlibQuirkNatural] = coef_at(c, kAmvlibQuirkScan) * (int)((qw[kAmvlibQuirkScan >> 2] >> (8 * (kAmvlibQuirkScan & 3))) & 255u);
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             idct8<false>(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
@@ -201,14 +221,15 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
         uint32_t cr[2], cg[2], cb[2];                                  // the chroma term of both pixels of a pair
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int u = e ? ((int)uu >> 16) : (int)(int16_t)(uu & 0xffffu);
-            const int w = e ? ((int)vv >> 16) : (int)(int16_t)(vv & 0xffffu);
-            const uint32_t r = (uint32_t)((18 * u + 367 * w + 32768) >> 8);     // :808-810, +128
-            const uint32_t gg = (uint32_t)((-159 * u - 220 * w + 32768) >> 8);
-            const uint32_t b = (uint32_t)((411 * u - 29 * w + 32768) >> 8);
-            cr[e] = __builtin_amdgcn_perm(r, r, 0x05040100u);
-            cg[e] = __builtin_amdgcn_perm(gg, gg, 0x05040100u);
-            cb[e] = __builtin_amdgcn_perm(b, b, 0x05040100u);
+            // (u, v) of chroma sample e as one pair of int16; each term (:808-810, +128) is one two-element dot product,
+            // and bytes 1-2 of it -- the term >> 8 -- go into both halves of a dword with one byte permute
+            const short2v uv = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(vv, uu, e ? 0x07060302u : 0x05040100u));
+            const uint32_t r = (uint32_t)__builtin_amdgcn_sdot2(uv, short2v{18, 367}, 32768, false);
+            const uint32_t gg = (uint32_t)__builtin_amdgcn_sdot2(uv, short2v{-159, -220}, 32768, false);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_sdot2(uv, short2v{411, -29}, 32768, false);
+            cr[e] = __builtin_amdgcn_perm(r, r, 0x02010201u);
+            cg[e] = __builtin_amdgcn_perm(gg, gg, 0x02010201u);
+            cb[e] = __builtin_amdgcn_perm(b, b, 0x02010201u);
         }
         if (lc >= px) continue;                                        // right of the picture
         uint32_t off = row0 - 2u * i2 * g.stride + lc * 3u;
