@@ -10,6 +10,8 @@
 
 namespace amv {
 
+constexpr uint32_t kDummyRecordWord = 0x8000u;   // bit 15: a filler no block owns (amv_decode_sync.hip's kDummyRecord)
+
 // s_img: >= cnt * 6 * 128 bytes of LDS, 16-byte aligned; the caller may reuse it after a __syncthreads().
 // segidx: this segment's number in the frame (mcu_row * segments_per_row + segment).
 // Returns true when this lane holds a block (lane < cnt * 6).
@@ -50,18 +52,46 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
     if (skip) return false;
     int dc_base = 0;
     if (records) {   // records -> dense image of the segment's blocks in LDS
+        const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
+        if (!cnt_ok) r1 = r0;
+        // The segment's records are asked for all at once, four consecutive ones per lane and instruction (a loop of
+        // one 4-byte load per lane and trip waited for memory eight times in a row: 1.6 of the kernel's 4.4 ms); the
+        // image is zeroed while they are on their way.
+        struct __attribute__((packed, aligned(4))) Rec4 { uint32_t w[4]; };
+        constexpr uint32_t kAhead = 3;                                   // 768 records per trip; a segment has ~500
+        const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec + r0;
+        const uint32_t nrec = r1 - r0;
+        Rec4 q[kAhead];
+#pragma unroll
+        for (uint32_t j = 0; j < kAhead; ++j) {
+            const uint32_t i = j * 4u * kWave + lane * 4u;
+            q[j] = Rec4{{kDummyRecordWord, kDummyRecordWord, kDummyRecordWord, kDummyRecordWord}};
+            if (i < nrec) q[j] = *reinterpret_cast<const Rec4*>(rec + i);   // (may read up to 3 words past r1: see ensure())
+        }
         uint4* img16 = reinterpret_cast<uint4*>(s_img);
         for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
-        if (!cnt_ok) r1 = r0;
-        const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec;
         int16_t* img = reinterpret_cast<int16_t*>(s_img);
         const uint32_t b0 = (mcu0 * 6u - g.blocks) & 63u;   // the block field counts from the frame's end
-        for (uint32_t r = r0 + lane; r < r1; r += kWave) {
-            const uint32_t w = rec[r];
-            const uint32_t b = (((w >> 6) & 63u) - b0) & 63u, k = w & 63u;   // the segment's <= 60 blocks are consecutive
-            if (!(w & 0x8000u) && b < cnt_ok * 6u) img[b * 64u + ((((k >> 3) ^ b) & 7u) << 3) + (k & 7u)] = (int16_t)((int)w >> 16);
+        const uint32_t nb_ok = cnt_ok * 6u;
+        for (uint32_t base = 0;;) {
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; ++j) {
+                const uint32_t i = base + j * 4u * kWave + lane * 4u;
+#pragma unroll
+                for (uint32_t e = 0; e < 4u; ++e) {
+                    const uint32_t w = q[j].w[e];
+                    const uint32_t b = (((w >> 6) & 63u) - b0) & 63u, k = w & 63u;   // the segment's <= 60 blocks are consecutive
+                    if (i + e < nrec && !(w & 0x8000u) && b < nb_ok) img[b * 64u + ((((k >> 3) ^ b) & 7u) << 3) + (k & 7u)] = (int16_t)((int)w >> 16);
+                }
+            }
+            base += kAhead * 4u * kWave;
+            if (base >= nrec) break;
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; ++j) {   // a segment with more records than one trip holds
+                const uint32_t i = base + j * 4u * kWave + lane * 4u;
+                if (i < nrec) q[j] = *reinterpret_cast<const Rec4*>(rec + i);
+            }
         }
         // a DC record counts from its lane's first block: the base of the lane that decoded this block's DC
         if (in.lanes > 1u) {

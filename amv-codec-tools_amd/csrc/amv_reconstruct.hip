@@ -26,7 +26,6 @@ namespace amv {
 namespace {
 
 struct __attribute__((aligned(4))) Px12 { uint32_t w[3]; };   // four BGR pixels
-typedef short short2v __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
 constexpr int kSegMcus = 10;   // MCUs per wave: 60 of 64 lanes busy in the transform
@@ -102,6 +101,15 @@ __device__ const QuantWords kQuantWords = pack_quant();
 // iclp[] of AmvJpeg.c:1073-1080 (table spans -512..511; beyond it the reference reads out of
 // bounds, defined here as saturation)
 __device__ __forceinline__ int clamp_iclp(int x) { return min(max(x, -256), 255); }
+
+// a.lo * w.lo + a.hi * w.hi + 32768 (16-bit signed halves): the three-operand form, so that the bias stays in its
+// register (the builtin becomes the accumulating form plus a move to reload the accumulator)
+constexpr uint32_t pair16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ uint32_t dot2_bias(uint32_t a, uint32_t w) {
+    uint32_t d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(w), "v"(32768u));
+    return d;
+}
 
 // two pixels of one channel: (y0 + c, y1 + c) clamped to 0..255, in bytes 0 and 1
 __device__ __forceinline__ uint32_t sat_pair(uint32_t yy, uint32_t cc) {
@@ -223,10 +231,10 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
         for (int e = 0; e < 2; ++e) {
             // (u, v) of chroma sample e as one pair of int16; each term (:808-810, +128) is one two-element dot product,
             // and bytes 1-2 of it -- the term >> 8 -- go into both halves of a dword with one byte permute
-            const short2v uv = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(vv, uu, e ? 0x07060302u : 0x05040100u));
-            const uint32_t r = (uint32_t)__builtin_amdgcn_sdot2(uv, short2v{18, 367}, 32768, false);
-            const uint32_t gg = (uint32_t)__builtin_amdgcn_sdot2(uv, short2v{-159, -220}, 32768, false);
-            const uint32_t b = (uint32_t)__builtin_amdgcn_sdot2(uv, short2v{411, -29}, 32768, false);
+            const uint32_t uv = __builtin_amdgcn_perm(vv, uu, e ? 0x07060302u : 0x05040100u);
+            const uint32_t r = dot2_bias(uv, pair16(18, 367));
+            const uint32_t gg = dot2_bias(uv, pair16(-159, -220));
+            const uint32_t b = dot2_bias(uv, pair16(411, -29));
             cr[e] = __builtin_amdgcn_perm(r, r, 0x02010201u);
             cg[e] = __builtin_amdgcn_perm(gg, gg, 0x02010201u);
             cb[e] = __builtin_amdgcn_perm(b, b, 0x02010201u);

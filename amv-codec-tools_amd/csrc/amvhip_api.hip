@@ -435,7 +435,7 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     const uint32_t round = dense_round(n);
     if (int r = ensure(c, c->coef, (size_t)round * g.blocks * 128)) return r;
     if (int r = ensure(c, c->nmcu, (size_t)n * 4)) return r;
-    if (int r = ensure(c, c->rec, (size_t)n * cap_rec * 4)) return r;
+    if (int r = ensure(c, c->rec, (size_t)n * cap_rec * 4 + 16)) return r;   // + what a 16-byte read of a frame's last records may overshoot
     if (int r = ensure(c, c->seg_start, (size_t)n * (segs + 1) * 8)) return r;
     if (int r = ensure(c, c->lane_tab, (size_t)n * lanes * 16)) return r;
     if (int r = ensure(c, c->rec_count, (size_t)n * 4)) return r;
