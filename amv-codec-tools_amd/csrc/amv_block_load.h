@@ -10,9 +10,10 @@
 
 namespace amv {
 
+constexpr uint32_t kSegImageBytes = 60u * 128u;   // the LDS image of a segment's <= 60 blocks; 128 spare bytes follow it
 constexpr uint32_t kDummyRecordWord = 0x8000u;   // bit 15: a filler no block owns (amv_decode_sync.hip's kDummyRecord)
 
-// s_img: >= cnt * 6 * 128 bytes of LDS, 16-byte aligned; the caller may reuse it after a __syncthreads().
+// s_img: kSegImageBytes + 128 bytes of LDS, 16-byte aligned; the caller may reuse it after a __syncthreads().
 // segidx: this segment's number in the frame (mcu_row * segments_per_row + segment).
 // Returns true when this lane holds a block (lane < cnt * 6).
 // Which frame this workgroup works on: work item `item` of the launch (FrameSel); false when there is none (past
@@ -71,18 +72,27 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
         uint4* img16 = reinterpret_cast<uint4*>(s_img);
         for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        int16_t* img = reinterpret_cast<int16_t*>(s_img);
-        const uint32_t b0 = (mcu0 * 6u - g.blocks) & 63u;   // the block field counts from the frame's end
-        const uint32_t nb_ok = cnt_ok * 6u;
+        // Scatter, without a branch per record: the word shifted left by one holds 2 * index in bits 1-6, the block field
+        // in bits 7-12 and the filler flag in bit 16.  Adding (64 - first block) << 7 turns the field into the block's
+        // number in the segment (modulo 64, carry into bit 13); with bit 16 kept, one unsigned compare against
+        // "blocks decoded << 7" rejects fillers and other segments' blocks alike, and a record past the range's end
+        // compares against 0.  A rejected record goes to the lane's spare slot behind the image.
+        const uint32_t first7 = (64u - ((mcu0 * 6u - g.blocks) & 63u)) << 7;   // the block field counts from the frame's end
+        const uint32_t ok7 = cnt_ok * 6u << 7;
+        const uint32_t spare = kSegImageBytes + lane * 2u;
         for (uint32_t base = 0;;) {
 #pragma unroll
             for (uint32_t j = 0; j < kAhead; ++j) {
-                const uint32_t i = base + j * 4u * kWave + lane * 4u;
+                if (base + j * 4u * kWave >= nrec) break;                   // (wave-uniform) nothing of this piece is in range
+                const int32_t left = (int32_t)(nrec - base - j * 4u * kWave) - (int32_t)(lane * 4u);   // records from this lane's first on
 #pragma unroll
                 for (uint32_t e = 0; e < 4u; ++e) {
-                    const uint32_t w = q[j].w[e];
-                    const uint32_t b = (((w >> 6) & 63u) - b0) & 63u, k = w & 63u;   // the segment's <= 60 blocks are consecutive
-                    if (i + e < nrec && !(w & 0x8000u) && b < nb_ok) img[b * 64u + ((((k >> 3) ^ b) & 7u) << 3) + (k & 7u)] = (int16_t)((int)w >> 16);
+                    const uint32_t u = q[j].w[e] << 1;
+                    const uint32_t t = u + first7;
+                    const uint32_t b7 = t & 0x11f80u;                                    // block in segment << 7, filler flag
+                    const uint32_t at = b7 | ((u & 0x7eu) ^ ((t >> 3) & 0x70u));         // 16-byte granule XOR block, as the reader expects
+                    const bool take = b7 < (left > (int32_t)e ? ok7 : 0u);
+                    *reinterpret_cast<int16_t*>(s_img + (take ? at : spare)) = (int16_t)(q[j].w[e] >> 16);
                 }
             }
             base += kAhead * 4u * kWave;

@@ -127,8 +127,9 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
     SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameSel sel,
     FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
     constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;   // int16 units
-    // 7 680 bytes: first the records' image of the 60 blocks (128 bytes each), then the three planes
-    __shared__ __attribute__((aligned(16))) int16_t s_mem[16 * kPitchY + 2 * 8 * kPitchC];
+    // 7 680 bytes (+ the scatter's spare slots): first the records' image of the 60 blocks (128 bytes each), then the three planes
+    __shared__ __attribute__((aligned(16))) int16_t s_mem[16 * kPitchY + 2 * 8 * kPitchC + 64];
+    static_assert((16 * kPitchY + 2 * 8 * kPitchC) * 2 == kSegImageBytes, "the planes reuse the image");
     int16_t* const s_y = s_mem;
     int16_t* const s_u = s_mem + 16 * kPitchY;
     int16_t* const s_v = s_u + 8 * kPitchC;

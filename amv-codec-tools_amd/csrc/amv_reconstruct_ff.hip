@@ -70,7 +70,7 @@ template <bool kRound>
 __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
     SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameSel sel, FrameGeom g, uint64_t yuv_frame_bytes,
     uint8_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[kSegMcus * 6 * 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[kSegImageBytes + 128];   // + a spare slot per lane (load_segment_blocks)
     const uint32_t lane = threadIdx.x;
     const uint32_t my = blockIdx.y, seg = blockIdx.z;
     for (uint32_t item = blockIdx.x;; item += gridDim.x) {
