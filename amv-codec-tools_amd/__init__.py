@@ -91,6 +91,8 @@ SYMBOLS = {
     "amvhip_encode_bound": (_u32, [_u32, _u32]),
     "amvhip_jpeg_header": (_u32, [ctypes.c_ushort, ctypes.c_ushort, _vp, _u32]),
     "amvhip_decode_batch_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "amvhip_decode_submit_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "amvhip_decode_collect_dev": (_int, [_vp, _vp]),
     "amvhip_decode_workspace_per_frame": (ctypes.c_double, [_vp]),
     "amvhip_decode_batch": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "amvhip_decode_batch_async": (_int, [_vp, _vp, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
@@ -220,6 +222,15 @@ class Context:
     def decode_batch_dev(self, blob, blob_bytes, offs, lens, n, w, h, flags, out, status, stream=None):
         return self._check(self.lib.amvhip_decode_batch_dev(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens), n,
                                                             w, h, flags, _ptr(out), _ptr(status), stream), "decode_batch_dev")
+
+    def decode_submit_dev(self, blob, blob_bytes, offs, lens, n, w, h, flags, out, status, stream=None):
+        """queue a batch on the context's own streams; `stream` marks where the inputs are ready and does not wait"""
+        return self._check(self.lib.amvhip_decode_submit_dev(self.h, _ptr(blob), blob_bytes, _ptr(offs), _ptr(lens), n,
+                                                             w, h, flags, _ptr(out), _ptr(status), stream), "decode_submit_dev")
+
+    def decode_collect_dev(self, stream=None):
+        """`stream` waits for the oldest submitted batch"""
+        return self._check(self.lib.amvhip_decode_collect_dev(self.h, stream), "decode_collect_dev")
 
     def decode_workspace_per_frame(self):
         return self.lib.amvhip_decode_workspace_per_frame(self.h)

@@ -41,6 +41,12 @@ struct amvhip_ctx {
     HuffEncodeImage* d_enc = nullptr;
     // workspace
     DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count, scaled, trellis_ws;
+    // amvhip_decode_submit_dev / _collect_dev: what the entropy stage hands to the reconstruction exists twice, so that
+    // the entropy stage of one batch can run (stream `front`) beside the reconstruction of the batch before (`back`)
+    struct DecodeSet { DevBuf nmcu, retry, rec, seg_start, lane_tab, rec_count; } second;
+    hipStream_t front = nullptr, back = nullptr;
+    hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done[2] = {nullptr, nullptr};
+    uint64_t submitted = 0, collected = 0;
     bool dense_intermediate = false;   // AMVHIP_DENSE=1: dense coefficient lines between the decode stages (experiments)
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
     uint32_t cus = 256;   // compute units of the device
@@ -81,6 +87,10 @@ int fail(amvhip_ctx* c, int code, const char* fmt, ...) {
 
 int ensure(amvhip_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return AMVHIP_OK;
+    if (c->front) {   // a submitted batch may still be using the buffer
+        HIP_TRY(c, hipStreamSynchronize(c->front));
+        HIP_TRY(c, hipStreamSynchronize(c->back));
+    }
     if (b.p) HIP_TRY(c, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -214,8 +224,19 @@ int check_launch(amvhip_ctx* c, const char* what) {
     return AMVHIP_OK;
 }
 
-int use_device(amvhip_ctx* c) {
+int select_device(amvhip_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
+    return AMVHIP_OK;
+}
+
+// Every entry point but amvhip_decode_submit_dev / _collect_dev: batches submitted earlier share the context's
+// workspace with what is about to be queued, so they finish first (nothing to wait for when none is in flight).
+int use_device(amvhip_ctx* c) {
+    if (int r = select_device(c)) return r;
+    if (c->front && c->submitted != 0) {
+        HIP_TRY(c, hipStreamSynchronize(c->front));
+        HIP_TRY(c, hipStreamSynchronize(c->back));
+    }
     return AMVHIP_OK;
 }
 
@@ -268,8 +289,13 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     drain(c);
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
+    for (hipStream_t q : {c->front, c->back})
+        if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    for (hipEvent_t e : {c->ev_in, c->ev_front, c->ev_done[0], c->ev_done[1]})
+        if (e) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out})
+                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out,
+                      &c->second.nmcu, &c->second.retry, &c->second.rec, &c->second.seg_start, &c->second.lane_tab, &c->second.rec_count})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -309,7 +335,7 @@ struct Fallback {
 // what is left for the serial kernel
 static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offs,
                          const uint32_t* d_lens, uint32_t n, const FrameGeom& g, SyncSinks sinks, int32_t* d_status,
-                         uint32_t* d_nmcu_ok, hipStream_t st, Fallback& fb) {
+                         uint32_t* d_nmcu_ok, DevBuf& retry, hipStream_t st, Fallback& fb) {
     // window per frame for the unstuffed scan in the global workspace: ~1.6x the 0.2 B/pixel AMV streams
     // run at; larger chunks take the serial kernel
     uint32_t cap_bytes = ((g.width * g.height * 5u / 16u) + 1023u) & ~1023u;
@@ -320,10 +346,10 @@ static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
         fb = Fallback{nullptr, nullptr, n};
         return AMVHIP_OK;
     }
-    if (int r = ensure(c, c->retry, ((size_t)n + 8) * 4)) return r;   // [retry count, task counter, 6 spare | retry list n]
+    if (int r = ensure(c, retry, ((size_t)n + 8) * 4)) return r;   // [retry count, task counter, 6 spare | retry list n]
     if (int r = ensure(c, c->ws, (size_t)n * cap_bytes)) return r;
     if (int r = ensure(c, c->ws_bytes, (size_t)n * 4)) return r;
-    uint32_t* retry_count = (uint32_t*)c->retry.p;
+    uint32_t* retry_count = (uint32_t*)retry.p;
     uint32_t* retry_list = retry_count + 8;
     sinks.retry_list = retry_list;
     sinks.retry_count = retry_count;
@@ -360,7 +386,7 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     hipStream_t st = (hipStream_t)stream;
     SyncSinks sinks{d_coef, nullptr, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr};
     Fallback fb;
-    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu_ok, st, fb)) return r;
+    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu_ok, c->retry, st, fb)) return r;
     {   // the caller's array has a place for every frame: one launch, lines at the frames' own places
         Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
         launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, fb.list, fb.count, 0u,
@@ -407,19 +433,26 @@ extern "C" int amvhip_reconstruct_dev(amvhip_ctx* c, const int16_t* d_coef, cons
 // dense coefficient lines the context keeps for frames that go through the serial kernel: a round's worth
 static uint32_t dense_round(uint32_t n) { return n <= 4096u ? n : (n / 4u > 4096u ? (n + 3u) / 4u : 4096u); }
 
-extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
-                                       const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
-                                       uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out,
-                                       int32_t* d_status, void* stream) {
-    if (!c) return AMVHIP_ERR_ARG;
+// What one decode call hands from the entropy stage to the reconstruction (the context has two such sets).
+struct DecodeBufs {
+    DevBuf &nmcu, &retry, &rec, &seg_start, &lane_tab, &rec_count;
+};
+
+static int decode_args_ok(amvhip_ctx* c, const uint8_t* d_blob, const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n, uint32_t w,
+                          uint32_t h, const uint8_t* d_out, const int32_t* d_status) {
     if (!size_ok(w, h)) return fail(c, AMVHIP_ERR_ARG, "decode: bad size %ux%u", w, h);
     if (n == 0) return AMVHIP_OK;
     if (!d_blob || !d_offs || !d_lens || !d_out || !d_status) return fail(c, AMVHIP_ERR_ARG, "decode: null argument");
     if (((uintptr_t)d_blob & 3u) || ((uintptr_t)d_out & 3u)) return fail(c, AMVHIP_ERR_ARG, "decode: blob and out must be 4-byte aligned");
-    if (int r = use_device(c)) return r;
+    return AMVHIP_OK;
+}
+
+// The entropy stage goes to stream `front`, everything that writes d_out to `back` (the same stream, or two of the
+// context's own with `back` waiting for `front`).  Caller holds the lock.
+static int decode_core(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offs, const uint32_t* d_lens,
+                       uint32_t n, uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out, int32_t* d_status, DecodeBufs b,
+                       hipStream_t front, hipStream_t back) {
     const FrameGeom g = make_geom(w, h);
-    hipStream_t st = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lk(c->mu);
     // Between the two stages coefficients travel as records (one word per DC and per non-zero AC coefficient).
     // Record space per frame: 20 per block is the most the synchronising kernel is given (a frame that needs more
     // goes to the serial kernel); a stream whose chunks are small gets proportionally less -- a record costs at
@@ -434,17 +467,22 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     const uint32_t segs = ((g.mcu_cols + 9u) / 10u) * g.mcu_rows;
     const uint32_t round = dense_round(n);
     if (int r = ensure(c, c->coef, (size_t)round * g.blocks * 128)) return r;
-    if (int r = ensure(c, c->nmcu, (size_t)n * 4)) return r;
-    if (int r = ensure(c, c->rec, (size_t)n * cap_rec * 4 + 16)) return r;   // + what a 16-byte read of a frame's last records may overshoot
-    if (int r = ensure(c, c->seg_start, (size_t)n * (segs + 1) * 8)) return r;
-    if (int r = ensure(c, c->lane_tab, (size_t)n * lanes * 16)) return r;
-    if (int r = ensure(c, c->rec_count, (size_t)n * 4)) return r;
-    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)c->rec.p, cap_rec, (uint32_t*)c->seg_start.p, (uint32_t*)c->lane_tab.p, lanes,
-                    (uint32_t*)c->rec_count.p, nullptr, nullptr};
-    uint32_t* d_nmcu = (uint32_t*)c->nmcu.p;
+    if (int r = ensure(c, b.nmcu, (size_t)n * 4)) return r;
+    if (int r = ensure(c, b.rec, (size_t)n * cap_rec * 4 + 16)) return r;   // + what a 16-byte read of a frame's last records may overshoot
+    if (int r = ensure(c, b.seg_start, (size_t)n * (segs + 1) * 8)) return r;
+    if (int r = ensure(c, b.lane_tab, (size_t)n * lanes * 16)) return r;
+    if (int r = ensure(c, b.rec_count, (size_t)n * 4)) return r;
+    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)b.rec.p, cap_rec, (uint32_t*)b.seg_start.p, (uint32_t*)b.lane_tab.p, lanes,
+                    (uint32_t*)b.rec_count.p, nullptr, nullptr};
+    uint32_t* d_nmcu = (uint32_t*)b.nmcu.p;
     Fallback fb;
+    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu, b.retry, front, fb)) return r;
+    if (back != front) {
+        HIP_TRY(c, hipEventRecord(c->ev_front, front));
+        HIP_TRY(c, hipStreamWaitEvent(back, c->ev_front, 0));
+    }
+    hipStream_t st = back;
     if (int r = clear_unwritten(c, n, g, flags, d_out, st)) return r;
-    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu, st, fb)) return r;
     if (fb.list)   // the frames in records form (a launch that skips the others)
         if (int r = reconstruct_launch(c, sinks, d_nmcu, n, FrameSel{nullptr, nullptr, 0u, 0u}, n, g, flags, d_out, st)) return r;
     // The others, a round of dense lines at a time.  With a list the count is on the device: the rounds past it find
@@ -459,8 +497,76 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
         if (int r = check_launch(c, "huffman")) return r;
         if (int r = reconstruct_launch(c, sinks, d_nmcu, n, FrameSel{fb.list, fb.count, base, items}, items, g, flags, d_out, st)) return r;
     }
-    c->ws_bytes_per_frame = (double)(c->ws.cap + c->rec.cap + c->coef.cap + c->seg_start.cap + c->lane_tab.cap + c->rec_count.cap +
-                                     c->nmcu.cap + c->retry.cap + c->ws_bytes.cap) / n;
+    c->ws_bytes_per_frame = (double)(c->ws.cap + c->coef.cap + c->ws_bytes.cap + c->rec.cap + c->seg_start.cap + c->lane_tab.cap +
+                                     c->rec_count.cap + c->nmcu.cap + c->retry.cap + c->second.rec.cap + c->second.seg_start.cap +
+                                     c->second.lane_tab.cap + c->second.rec_count.cap + c->second.nmcu.cap + c->second.retry.cap) / n;
+    return AMVHIP_OK;
+}
+
+extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
+                                       const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
+                                       uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out,
+                                       int32_t* d_status, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (int r = decode_args_ok(c, d_blob, d_offs, d_lens, n, w, h, d_out, d_status)) return r;
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return decode_core(c, d_blob, blob_bytes, d_offs, d_lens, n, w, h, flags, d_out, d_status,
+                       DecodeBufs{c->nmcu, c->retry, c->rec, c->seg_start, c->lane_tab, c->rec_count}, (hipStream_t)stream,
+                       (hipStream_t)stream);
+}
+
+// ---- the same in two halves, for a caller with more than one batch in hand ---------------------------------------
+// submit: the batch's inputs are ready where `stream` stands now (an event is recorded there); the entropy stage is
+// queued on the context's `front` stream, the reconstruction on its `back` stream, and `stream` is NOT made to wait.
+// collect: `stream` waits for the oldest batch submitted and not yet collected.  With submit(k+1) called before
+// collect(k), the entropy stage of batch k+1 runs beside the reconstruction of batch k -- the two are limited by
+// different things (amv_huffman_fast_kernel by memory latency and scattered stores, amv_reconstruct_kernel by VALU
+// issue).  At most two batches between submit and collect: the hand-over buffers exist twice.
+extern "C" int amvhip_decode_submit_dev(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes,
+                                        const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n,
+                                        uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out,
+                                        int32_t* d_status, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (int r = decode_args_ok(c, d_blob, d_offs, d_lens, n, w, h, d_out, d_status)) return r;
+    if (int r = select_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->submitted - c->collected >= 2) return fail(c, AMVHIP_ERR_ARG, "decode_submit: two batches are in flight, collect one first");
+    if (!c->front) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->front, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->back, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&c->ev_in, &c->ev_front, &c->ev_done[0], &c->ev_done[1]})
+            HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    const int which = (int)(c->submitted & 1u);
+    HIP_TRY(c, hipEventRecord(c->ev_in, (hipStream_t)stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->front, c->ev_in, 0));
+    // (the hand-over set this batch writes was last read by the reconstruction of the batch two before: on `back`,
+    // ahead of the batch before this one -- whose entropy stage `front` has already gone through -- but not of `front`)
+    if (c->submitted >= 2) HIP_TRY(c, hipStreamWaitEvent(c->front, c->ev_done[which], 0));
+    if (n != 0) {
+        DecodeBufs first{c->nmcu, c->retry, c->rec, c->seg_start, c->lane_tab, c->rec_count};
+        DecodeBufs second{c->second.nmcu, c->second.retry, c->second.rec, c->second.seg_start, c->second.lane_tab, c->second.rec_count};
+        if (int r = decode_core(c, d_blob, blob_bytes, d_offs, d_lens, n, w, h, flags, d_out, d_status, which ? second : first, c->front,
+                                c->back))
+            return r;
+    } else {   // nothing to decode: `back` still has to pass the point where the inputs are ready
+        HIP_TRY(c, hipEventRecord(c->ev_front, c->front));
+        HIP_TRY(c, hipStreamWaitEvent(c->back, c->ev_front, 0));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_done[which], c->back));
+    ++c->submitted;
+    return AMVHIP_OK;
+}
+
+extern "C" int amvhip_decode_collect_dev(amvhip_ctx* c, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (int r = select_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->collected == c->submitted) return fail(c, AMVHIP_ERR_ARG, "decode_collect: nothing submitted");
+    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_done[c->collected & 1u], 0));
+    ++c->collected;
     return AMVHIP_OK;
 }
 

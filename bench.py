@@ -82,9 +82,12 @@ def make_video_stream(E, first, n, w, h):
     return d_blob, pos, d_offs, d_lens, int(d_lens.sum().item())   # pos: the bytes of the blob the stream occupies
 
 
-def timed(E, step, steps, warmup):
+def timed(E, step, steps, warmup, finish=None):
+    """finish: what a pipelined step loop still owes after its last step (inside the timed region)"""
     for _ in range(warmup):
         step()
+    if finish:
+        finish()
     torch.cuda.synchronize()
     for c in [E.ctx] + getattr(E, "extra_ctx", []):
         c.prof_enable(True)
@@ -95,6 +98,8 @@ def timed(E, step, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if finish:
+        finish()
     torch.cuda.synchronize()
     if E.world > 1:
         dist.barrier()
@@ -194,8 +199,48 @@ def run_decode(E, args):
         if ch != orc.encode_frame(orc.synth_frame(SEED, first + i, w, h), w, h):
             raise SystemExit("device-made stream differs from the oracle's encoder at frame %d" % (first + i))
 
-    elapsed = timed(E, step, args.steps, args.warmup)
-    kern = kernel_times(E, (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON), steps=args.steps)
+    ids = (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON)
+    one_call = None
+    if not args.pipelined:
+        elapsed = timed(E, step, args.steps, args.warmup)
+        kern = kernel_times(E, ids, steps=args.steps)
+    else:
+        # The step loop of a caller with the next batch in hand (a player or transcoder going through windows of frames):
+        # batch k + 1 is submitted before batch k is collected, so its entropy stage runs beside batch k's reconstruction.
+        # Every batch is decoded in full into buffers of its own (two sets, used in turn); K steps = K batches, the
+        # pipeline's fill and drain are inside the timed region.
+        few = max(3, args.steps // 4)
+        t1 = timed(E, step, few, 1)                    # for comparison: the one-call form, a batch at a time
+        one_call = {"ms_per_step": 1e3 * t1 / few, "steps": few, "kernels": kernel_times(E, ids, steps=few)}
+        outs = [(d_out, d_st), (torch.empty_like(d_out), torch.empty_like(d_st))]
+        fly = {"k": 0, "open": 0}
+
+        def step_pipelined():
+            o, s = outs[fly["k"] & 1]
+            ctx.decode_submit_dev(d_blob, cap, d_offs, d_lens, n, w, h, 0, o, s, stream)
+            if fly["open"]:
+                ctx.decode_collect_dev(stream)         # the batch before this one
+            fly["open"] = 1
+            fly["k"] += 1
+
+        def finish():
+            if fly["open"]:
+                ctx.decode_collect_dev(stream)
+            fly["open"] = 0
+
+        for o, s in outs:
+            o.fill_(0x5A)
+            s.fill_(-1)
+        elapsed = timed(E, step_pipelined, args.steps, args.warmup, finish)
+        kern = kernel_times(E, ids, steps=args.steps)
+        # both buffer sets hold the batch, bit for bit what the one-call form (checked against the oracle above) wrote
+        if int((outs[1][1] != 0).sum().item()) or int((outs[0][1] != 0).sum().item()) or not torch.equal(outs[0][0], outs[1][0]):
+            raise SystemExit("pipelined decode: the two buffer sets differ")
+        step()
+        torch.cuda.synchronize()
+        if not torch.equal(d_out, outs[1][0]):
+            raise SystemExit("pipelined decode differs from the one-call form")
+        del outs
     workspace = ctx.decode_workspace_per_frame()     # device bytes the context holds per frame of this batch
     ctx.entropy_stats(True)          # one extra, untimed step: how many synchronisation rounds the frames needed
     step()
@@ -206,6 +251,10 @@ def run_decode(E, args):
                         "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % E.world,
                         "per_gpu_frames_per_s": result["value"] / E.world}
     result["config"]["decode_workspace_bytes_per_frame"] = workspace
+    if one_call:
+        result["config"]["calls"] = ("amvhip_decode_submit_dev / _collect_dev, batch k+1 submitted before batch k is collected "
+                                     "(entropy stage of one batch beside the reconstruction of the one before), two sets of output buffers")
+        result["config"]["one_call_form"] = one_call   # amvhip_decode_batch_dev, one batch at a time, same stream
     result["roofline"] = roofline(
         kern, stream_bytes + n * 3 * w * h, elapsed / args.steps,
         (lambda dom: profiled_traffic("", dom)) if (w, h, n) == (160, 120, DECODE_FRAMES) else None,
@@ -581,6 +630,9 @@ def main():
                          "encoder in tests/test_oracle_pin.py::test_encode_round_trip_quality (26.6 at 320x240, 25.4 below: "
                          "amvlib's colour matrix is not the inverse of the encoder's, which bounds the figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="decode workload: time the amvhip_decode_submit_dev / _collect_dev loop (batch k+1 submitted before "
+                         "batch k is collected) instead of amvhip_decode_batch_dev, a batch at a time")
     ap.add_argument("--strong", action="store_true",
                     help="decode: also run configs[3] as stated (one 10 000-frame stream scattered from rank 0, decoded, gathered "
                          "back) and report it under config.config4_strong_10k; always on when WORLD_SIZE > 1")

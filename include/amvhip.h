@@ -209,6 +209,26 @@ int amvhip_decode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64_t blo
                             uint32_t width, uint32_t height, uint32_t flags,
                             uint8_t *d_out, int32_t *d_status, void *stream);
 
+/*
+ * The same decode in two halves, for a caller that has the next batch in hand before it needs the last one's pixels
+ * (a player or transcoder working through windows of frames): the entropy stage of batch k+1 then runs beside the
+ * reconstruction of batch k -- the first waits on memory, the second on the vector ALUs.
+ *   amvhip_decode_submit_dev : arguments as amvhip_decode_batch_dev.  The inputs must be ready where `stream` stands
+ *       at the call (that point is recorded); the work is queued on streams the context owns and `stream` is NOT made
+ *       to wait.  d_blob/d_offs/d_lens must stay untouched and d_out/d_status belong to the batch until it has been
+ *       collected and `stream` has passed that point: a batch submitted meanwhile needs buffers of its own.
+ *   amvhip_decode_collect_dev: `stream` waits for the oldest batch submitted and not yet collected; work queued on
+ *       `stream` afterwards sees its d_out and d_status.
+ * At most two batches between submit and collect (a third submit returns AMVHIP_ERR_ARG): what the entropy stage hands
+ * to the reconstruction exists twice in the context.  Any other entry point of the context first waits for the batches
+ * submitted so far.  Results are those of amvhip_decode_batch_dev, byte for byte.
+ */
+int amvhip_decode_submit_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_bytes,
+                             const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n,
+                             uint32_t width, uint32_t height, uint32_t flags,
+                             uint8_t *d_out, int32_t *d_status, void *stream);
+int amvhip_decode_collect_dev(amvhip_ctx *ctx, void *stream);
+
 /* device workspace the context held for the last amvhip_decode_batch_dev call, in bytes per frame of that call */
 double amvhip_decode_workspace_per_frame(const amvhip_ctx *ctx);
 

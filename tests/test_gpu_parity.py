@@ -1187,3 +1187,61 @@ def test_one_lane_per_frame_walk(pkg, orc, amv1):
             assert (st == wst).all() and (got == want).all(), (w, h)
     finally:
         one.close()
+
+
+def test_decode_submit_collect_pipeline(pkg, orc, amv1):
+    """amvhip_decode_submit_dev / _collect_dev: batches of different sizes, geometries and flags (damaged chunks among
+    them), the next one submitted before the last one is collected, every batch with buffers of its own -- status and
+    pixels equal the oracle's; a third submit without a collect is refused; another entry point of the context in
+    between waits for what is in flight; an empty batch goes through"""
+    import torch
+    ctx = pkg.Context(0)
+    try:
+        rng = np.random.default_rng(31)
+        stream = torch.cuda.Stream()
+        sid = stream.cuda_stream
+        jobs = []
+        for k, (w, h, n, flags) in enumerate(((160, 120, 90, 0), (320, 240, 6, 1), (16, 16, 300, 0), (176, 144, 5, 0), (160, 120, 33, 0),
+                                              (130, 98, 4, 1))):
+            chunks = _synth_chunks(orc, n, w, h, first=10 * k)
+            b = bytearray(chunks[n // 2]); b[len(b) // 2] ^= 0x40; chunks[n // 2] = bytes(b)       # damage
+            chunks[-1] = chunks[-1][: len(chunks[-1]) // 2]                                        # truncation
+            blob, offs, lens, nbytes = _blob_of(chunks, pad_front=k % 3)
+            jobs.append({"w": w, "h": h, "n": n, "flags": flags, "chunks": chunks, "nbytes": nbytes, "blob": _t(blob), "offs": _t(offs),
+                         "lens": _t(lens), "out": torch.full((n, h, ctx.stride(w)), 0x5A, dtype=torch.uint8, device="cuda:0"),
+                         "st": torch.full((n,), -1, dtype=torch.int32, device="cuda:0")})
+        torch.cuda.synchronize()
+
+        def submit(j):
+            ctx.decode_submit_dev(j["blob"], j["nbytes"], j["offs"], j["lens"], j["n"], j["w"], j["h"], j["flags"], j["out"], j["st"], sid)
+
+        submit(jobs[0])
+        for k in range(1, len(jobs)):
+            submit(jobs[k])               # the entropy stage of batch k beside the reconstruction of batch k - 1
+            if k == 2:
+                with pytest.raises(pkg.AmvHipError):
+                    submit(jobs[0])       # two in flight
+            ctx.decode_collect_dev(sid)   # batch k - 1
+        ctx.decode_collect_dev(sid)
+        with pytest.raises(pkg.AmvHipError):
+            ctx.decode_collect_dev(sid)   # nothing left
+        stream.synchronize()
+        for j in jobs:
+            want, wst = _oracle_decode(orc, j["chunks"], j["w"], j["h"], j["flags"])
+            assert (j["st"].cpu().numpy() == wst).all(), (j["w"], j["h"])
+            assert (j["out"].cpu().numpy() == want).all(), (j["w"], j["h"])
+        # a batch in flight, then the one-call form on the same context (which waits for it), then an empty batch
+        for j in jobs[:2]:
+            j["out"].fill_(0x5A); j["st"].fill_(-1)
+        submit(jobs[0])
+        j = jobs[1]
+        ctx.decode_batch_dev(j["blob"], j["nbytes"], j["offs"], j["lens"], j["n"], j["w"], j["h"], j["flags"], j["out"], j["st"], sid)
+        ctx.decode_submit_dev(j["blob"], 0, j["offs"], j["lens"], 0, j["w"], j["h"], 0, j["out"], j["st"], sid)
+        ctx.decode_collect_dev(sid)
+        ctx.decode_collect_dev(sid)
+        stream.synchronize()
+        for j in jobs[:2]:
+            want, wst = _oracle_decode(orc, j["chunks"], j["w"], j["h"], j["flags"])
+            assert (j["st"].cpu().numpy() == wst).all() and (j["out"].cpu().numpy() == want).all()
+    finally:
+        ctx.close()
