@@ -843,7 +843,8 @@ __device__ __forceinline__ void fast_stride(uint32_t ringb, uint32_t stageb, uin
         s.t += used;
         const uint32_t kn = s.k + ((e >> 16) & 255u);
         worst = min(worst, kn - 65u);
-        const uint32_t dcn = (uint32_t)__builtin_amdgcn_sbfe((int)kn, 6u, 1u);   // ~0: the block ends with this symbol
+        uint32_t dcn = (uint32_t)__builtin_amdgcn_sbfe((int)kn, 6u, 1u);   // ~0: the block ends with this symbol
+        asm("" : "+v"(dcn));   // (knowing where it comes from, the compiler builds kn & ~dcn from a shift, a compare and a select)
         // DC difference (:945-951) joins its component's sum (:1200-1221)
         lds_store(ca, sum + (val & s.dc));
         const uint32_t rv = val + (sum & s.dc);
