@@ -53,6 +53,7 @@
 // Chunks larger than the per-frame workspace window, or with a run of FF bytes longer than the 8-byte
 // look-back of the unstuffer (never in a valid stream), are queued for amv_huffman_kernel.
 #include <atomic>
+#include <cstdlib>
 
 #include "amv_kernels.h"
 
@@ -734,9 +735,9 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
 //     bit (which sits at the stride of a staging slot);
 //   * the frame's end: once the blocks-to-go counter reaches 0 the looked-up entry is ANDed to zero: the lane stands
 //     still, consuming and emitting nothing, until the wave's slowest lane is done;
-//   * errors: "no such code" advances the index by 80, so that like an over-long run it lands in 65..143, which one
-//     unsigned compare per symbol (folded into a running minimum) notices; a stride of eight symbols that raised the flag
-//     is walked again from its saved start state, one symbol at a time, to find where the walk stops (fast_replay);
+//   * errors raise no branch: the entries are OR-ed along (one of their bits says "no such code") and a running unsigned
+//     minimum of (index + advance - 65) notices an over-long run; a stride of eight symbols that raised a flag is walked
+//     again from its saved start state, one symbol at a time, to find where the walk stops (fast_replay);
 //   * where an MCU-row segment starts is looked at once per stride: its entry gets the record counts before and after
 //     the stride in which its first DC symbol came (SyncSinks::seg_start: bounds, which the reader's block test tightens).
 // LDS addresses are formed with OR where the layout allows (regions aligned to their size).
@@ -821,10 +822,12 @@ __device__ __forceinline__ uint32_t fast_lookup(const FastState& s, uint32_t v) 
     return e1 | e2;
 }
 
-// eight symbols, every lane, straight-line.  worst: the smallest (index + advance - 65) seen: < 79 = a symbol that
-// no decoder accepts (an over-long run, or no such code).
-template <uint32_t kFlush>
-__device__ __forceinline__ void fast_stride(uint32_t ringb, uint32_t stageb, uint32_t sumb, FastState& s, uint32_t& worst) {
+// eight symbols, every lane, straight-line.  seen: OR of the entries (kFastInvalid: no such code); worst: the smallest
+// (index + advance - 65): < 15 = an AC symbol moved the index past 63.  kLimit: the lane's share of the frame ends at
+// bit lim1 + 1 (several lanes per frame): a symbol that would start there or later is not looked at.
+template <uint32_t kFlush, bool kLimit>
+__device__ __forceinline__ void fast_stride(uint32_t ringb, uint32_t stageb, uint32_t sumb, uint32_t lim1, FastState& s, uint32_t& seen,
+                                            uint32_t& worst) {
 #pragma unroll
     for (int it = 0; it < kStrideWrite; ++it) {
         // issued together, ahead of the table look-up: the component's DC sum (j = 1 Cb, j = 0 Cr, else Y) and the window
@@ -832,8 +835,10 @@ __device__ __forceinline__ void fast_stride(uint32_t ringb, uint32_t stageb, uin
         const uint32_t sum = lds_load(ca);
         const uint32_t v = fast_window(ringb, s.t);
         __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the sum's read behind the look-up and waits twice)
-        const uint32_t run = (uint32_t)((int32_t)s.togo6 >> 31);   // 0 once the frame's last block is done
+        uint32_t run = (uint32_t)((int32_t)s.togo6 >> 31);   // 0 once the frame's last block is done
+        if (kLimit) run &= (uint32_t)((int32_t)(s.t - lim1) >> 31);
         const uint32_t e = fast_lookup(s, v) & run;
+        seen |= e;
         // magnitude bits -> value (AmvJpeg.c:924-933): sign-extended, x >= 0 means "leading 0 bit": value = x - (2^size - 1);
         // x < 0: value = x + 2^size.  Both are x - (full ^ (x >> 31)).  The width operand takes bits 0-4 of e (the size).
         const uint32_t used = e >> 24;
@@ -857,11 +862,13 @@ __device__ __forceinline__ void fast_stride(uint32_t ringb, uint32_t stageb, uin
     }
 }
 
-// A stride that raised the flag, once more from its start state, without writing: where does the walk stop?
+// A stride that raised a flag, once more from its start state, without writing: where does the walk stop?
 // why: 1 no such code (AmvJpeg.c:887), 2 index past 63 (:967-969); the state is the one the strict walk stops in.
-__device__ __forceinline__ uint32_t fast_replay(uint32_t ringb, FastState& s) {
+template <bool kLimit>
+__device__ __forceinline__ uint32_t fast_replay(uint32_t ringb, uint32_t lim1, FastState& s) {
     for (int it = 0; it < kStrideWrite; ++it) {
         if (s.togo6 == 0u) break;
+        if (kLimit && (int32_t)(s.t - lim1) >= 0) break;
         const uint32_t e = fast_lookup(s, fast_window(ringb, s.t));
         if (e & kFastInvalid) return 1u;
         const uint32_t kn = s.k + ((e >> 16) & 255u);
@@ -875,6 +882,47 @@ __device__ __forceinline__ uint32_t fast_replay(uint32_t ringb, FastState& s) {
         s.dc = end ? ~0u : 0u;
     }
     return 0u;
+}
+
+// the window of a walk that starts in stream word w: the ring holds words [w & ~7, + 16)
+__device__ __forceinline__ void fast_open_at(Stream& s, uint32_t w) {
+    const uint32_t lo = w & ~7u;
+    const uint4 a = stream_piece(s, lo), b = stream_piece(s, lo + 4u), c = stream_piece(s, lo + 8u), d = stream_piece(s, lo + 12u);
+    fast_ring_put(s, lo, a);
+    fast_ring_put(s, lo + 4u, b);
+    fast_ring_put(s, lo + 8u, c);
+    fast_ring_put(s, lo + 12u, d);
+    s.hi = lo + kRingWords;
+    stream_request(s);
+}
+
+// The speculative walk in the same arithmetic: from (t, k, j, dc) while fewer than lim1 + 1 bits are consumed; where
+// symbols start and how the block position moves, nothing else.  "No such code" (a guessed start) slips one bit and
+// leaves the index alone: the entry says so (one bit used, no advance); an over-long run closes the block.
+// nblk6: blocks finished << 6; nrec8: symbols that carry a value << 8.
+__device__ __forceinline__ void fast_skip(Stream& win, uint32_t ringb, FastState& s, uint32_t lim1, uint32_t& nblk6, uint32_t& nrec8) {
+    nblk6 = nrec8 = 0u;
+    bool active = (int32_t)(s.t - lim1) < 0;
+    if (!__ballot(active)) return;
+    fast_open_at(win, active ? (s.t + 1u) >> 5 : 0u);
+    while (__ballot(active) != 0ull) {
+        if (active) fast_service(win, (s.t + 1u) >> 5);
+#pragma unroll
+        for (int it = 0; it < kStrideWrite; ++it) {
+            const uint32_t v = fast_window(ringb, s.t);
+            const uint32_t e = fast_lookup(s, v) & (uint32_t)((int32_t)(s.t - lim1) >> 31);
+            s.t += e >> 24;
+            const uint32_t kn = s.k + ((e >> 16) & 255u);
+            uint32_t dcn = (uint32_t)__builtin_amdgcn_sbfe((int)kn, 6u, 1u);
+            asm("" : "+v"(dcn));
+            nrec8 += e & kFastEmit;
+            nblk6 += kn & 64u;
+            s.k = kn & ~dcn;
+            s.j = min(s.j + dcn, 5u);
+            s.dc = dcn;
+        }
+        active = (int32_t)(s.t - lim1) < 0;
+    }
 }
 
 }  // namespace
@@ -957,13 +1005,13 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
             if ((s.rp8 >> 8) - flushed >= 8u) flush();
             const bool running = alive;
             const FastState start = s;
-            uint32_t worst = ~0u;
-            fast_stride<kFlush>(ringb, stageb, sumb, s, worst);
-            const bool trouble = alive && worst < 79u;
+            uint32_t worst = ~0u, seen = 0u;
+            fast_stride<kFlush, false>(ringb, stageb, sumb, 0u, s, seen, worst);
+            const bool trouble = alive && (worst < 15u || (seen & kFastInvalid) != 0u);
             if (__ballot(trouble) != 0ull) {   // a damaged stream
                 if (trouble) {
                     s = start;
-                    stop = fast_replay(ringb, s);
+                    stop = fast_replay<false>(ringb, 0u, s);
                     alive = false;
                 }
             }
@@ -1009,6 +1057,226 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
                 status[frame] = (int32_t)st;
                 nmcu_ok[frame] = end_blocks / 6u;
                 out.rec_count[frame] = recpos;
+            }
+        }
+    }   // next task
+}
+
+// =============================================================================================
+// Several lanes per frame, records form, in the same arithmetic (amv_huffman_sync_kernel<L, true>'s passes 1-5 with
+// fast_skip as the speculative walk and fast_stride as the strict one; the dense form keeps the kernel above).
+// A lane's share ends at bit `limit`: the strict walk looks at no symbol that starts there or later, so the lanes'
+// records partition the frame's; every lane's records start on a piece of kFlush of them (fillers behind its last).
+// dynamic LDS as amv_huffman_fast_kernel's.
+// =============================================================================================
+template <int L>
+__global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
+    const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
+    const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+    uint32_t blocks_per_frame, uint32_t cap_words,
+    const HuffDecodeImage* __restrict__ img, SyncOut out, int32_t* __restrict__ status,
+    uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
+    constexpr int kFrames = kWave / L;   // frames per wave
+    constexpr uint32_t kFlush = 8u;
+    constexpr uint32_t kNoLimit = 0x7ffffffeu;   // as lim1: no position reaches it
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
+    const uint32_t slot = lane / L, sub = lane % L;
+    {   // tables, shared by the waves of the workgroup
+        const uint4* src = reinterpret_cast<const uint4*>(&img->fast[0][0]);
+        uint4* dst = reinterpret_cast<uint4*>(s_mem);
+        for (uint32_t i = threadIdx.x; i < kFastTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_mem != 0u) __builtin_trap();   // see lds_load
+    const uint32_t stageb = kFastTableBytes + wave * fast_stage_bytes(kFlush) + lane * 4u;
+    const uint32_t sumb = kFastTableBytes + nwaves * fast_stage_bytes(kFlush) + wave * kFastSumBytes + lane * 4u;
+    const uint32_t ringb = kFastTableBytes + nwaves * (fast_stage_bytes(kFlush) + kFastSumBytes) + wave * kFastRingBytes + lane * 4u;
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(s_mem + stageb);
+    if (list) n = *list_count;
+    const uint32_t ntasks = (n + kFrames - 1) / kFrames;
+    const SegGeom sg = out.sg;
+    for (;;) {
+        uint32_t task = 0;
+        if (lane == 0) task = atomicAdd(queue, 1u);
+        task = __shfl(task, 0);
+        if (task >= ntasks) return;
+
+        const bool timing = stats != nullptr && lane == 0;   // optional phase clock (amvhip_entropy_stats)
+        unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
+        if (timing) tc[0] = tc[1] = clock64();
+
+        const uint32_t idx = task * kFrames + slot;
+        const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
+        const uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+        if (frame != kNever && total == kNever && sub == 0) out.rec_count[frame] = kNever;
+        const bool live = total != kNever;
+        const uint32_t fsafe = live ? frame : 0u;
+        uint32_t* const rec = out.rec + (uint64_t)fsafe * out.cap_rec;
+        uint2* const seg_out = reinterpret_cast<uint2*>(out.seg_start) + (uint64_t)fsafe * (sg.count + 1u);
+        const uint32_t valid_bits = live ? total * 8u : 0u;
+        Stream win{ws + (uint64_t)fsafe * cap_words, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
+                   make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+
+        // ---- 1/2. speculative walks until every lane's start state equals its neighbour's arrival
+        uint32_t S = ((valid_bits + L - 1) / L + 31u) & ~31u;   // bits per lane, a whole number of words
+        if (S < 64u) S = 64u;
+        // the last lane of a frame has no right neighbour to feed: it only runs in pass 4
+        const bool walks = live && sub != L - 1;
+        const uint32_t lim1 = walks ? (sub + 1u) * S - 1u : 0u;
+        // position sub * S, "the DC symbol of block 0 comes next"; a lane that does not walk starts past its (empty) share
+        FastState entry{sub * S - 1u, 0u, 5u, 0u, 0u, ~0u};
+        if (!walks) entry.t = lim1;
+        FastState arrive = entry;
+        uint32_t my_blocks6, my_recs8;
+        fast_skip(win, ringb, arrive, lim1, my_blocks6, my_recs8);
+        if (timing) tc[2] = clock64();
+        uint32_t rounds = 0;
+        const uint64_t seg = L == 64 ? ~0ull : (((1ull << (L & 63)) - 1ull) << (slot * L));
+        for (int round = 0; round < L; ++round) {
+            const uint32_t lt = __shfl_up(arrive.t, 1, L), lk = __shfl_up(arrive.k, 1, L), lj = __shfl_up(arrive.j, 1, L);
+            const bool changed = live && sub != 0 && (lt != entry.t || lk != entry.k || lj != entry.j);
+            const uint64_t who = __ballot(changed);
+            if (!who) break;
+            if (who & seg) ++rounds;
+            if (changed) {
+                entry.t = lt; entry.k = lk; entry.j = lj; entry.dc = lk ? 0u : ~0u;
+                arrive = entry;
+                if (!walks) arrive.t = max(arrive.t, lim1);   // (the last lane: nothing to walk, its entry is all that counts)
+            }
+            // (every lane goes in: the walk's ballots are wave-wide; an unchanged lane is past its limit and stands still)
+            uint32_t b6 = 0, r8 = 0;
+            FastState again = changed ? arrive : FastState{lim1, 0u, 5u, 0u, 0u, ~0u};
+            fast_skip(win, ringb, again, lim1, b6, r8);
+            if (changed) { arrive = again; my_blocks6 = b6; my_recs8 = r8; }
+        }
+        if (timing) tc[3] = clock64();
+
+        // ---- 3. first block and first record of every lane (the last lane has not walked: its counts are 0, it is last)
+        uint32_t all_blocks, all_recs;
+        const uint32_t blk0 = seg_excl_sum<L>(my_blocks6 >> 6, sub, all_blocks);
+        const uint32_t rec0 = seg_excl_sum<L>(((my_recs8 >> 8) + kFlush - 1u) & ~(kFlush - 1u), sub, all_recs);
+
+        // ---- 4. the strict, writing pass.  Lanes left of the frame's end (or first error) are exact; whatever a lane to
+        // the right of it does is ignored below.
+        for (uint32_t c = 0; c < 3u; ++c) lds_store(sumb + c * kSlot, 0u);
+        FastState s = entry;
+        s.togo6 = (blk0 - blocks_per_frame) << 6;
+        s.rp8 = rec0 << 8;
+        bool alive = live && blk0 < blocks_per_frame;
+        if (!alive) s.togo6 = 0u;                       // stands still from the start
+        const uint32_t wlim1 = sub == L - 1 ? kNoLimit : (sub + 1u) * S - 1u;
+        const uint32_t dc_first = blk0 + (s.k ? 1u : 0u);
+        uint32_t stop = 0;           // 1 no such code, 2 index past 63, 3 the frame's last block is done
+        uint32_t flushed = rec0;     // records before this one have left for memory (a multiple of kFlush)
+        uint32_t end_blocks = 0;     // whole blocks when the walk stopped
+        // the first segment start this lane can meet: the first MCU at or after its first DC block
+        uint32_t seg_next, seg_col, seg_blk;
+        {
+            const uint32_t m_first = (dc_first + 5u) / 6u;
+            uint32_t row = m_first / sg.mcu_cols;
+            const uint32_t col = m_first - row * sg.mcu_cols;
+            seg_col = (col + kSegMcus - 1u) / kSegMcus;
+            if (seg_col >= sg.per_row) { ++row; seg_col = 0u; }
+            seg_next = row * sg.per_row + seg_col;
+            seg_blk = (row * sg.mcu_cols + seg_col * kSegMcus) * 6u;
+        }
+        if (__ballot(alive) != 0ull) fast_open_at(win, alive ? (s.t + 1u) >> 5 : 0u);
+        while (__ballot(alive) != 0ull) {
+            if (alive) fast_service(win, (s.t + 1u) >> 5);
+            if ((s.rp8 >> 8) - flushed >= kFlush) {
+                stage_flush<kFlush>(stage, rec, flushed, out.cap_rec);
+                flushed += kFlush;
+            }
+            const bool running = alive;
+            const FastState start = s;
+            uint32_t worst = ~0u, seen = 0u;
+            fast_stride<kFlush, true>(ringb, stageb, sumb, wlim1, s, seen, worst);
+            const bool trouble = alive && (worst < 15u || (seen & kFastInvalid) != 0u);
+            if (__ballot(trouble) != 0ull) {   // a damaged stream (or a lane right of the true path's end)
+                if (trouble) {
+                    s = start;
+                    stop = fast_replay<true>(ringb, wlim1, s);
+                    alive = false;
+                }
+            }
+            if (alive && s.togo6 == 0u) { stop = 3u; alive = false; }
+            if (alive && (int32_t)(s.t - wlim1) >= 0) alive = false;   // the end of the lane's share
+            bool hit = false;
+            if (running) {
+                const uint32_t blocks = blocks_per_frame + (uint32_t)((int32_t)s.togo6 >> 6);   // whole blocks so far
+                hit = seg_next < sg.count && blocks + (s.k ? 1u : 0u) > seg_blk;
+                if (!alive) { end_blocks = blocks; s.togo6 = 0u; }   // stands still from here on
+            }
+            if (__ballot(hit) != 0ull) {
+                if (hit) {
+                    seg_out[seg_next++] = make_uint2(start.rp8 >> 8, s.rp8 >> 8);
+                    const bool last = seg_col + 1u == sg.per_row;
+                    seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
+                    seg_col = last ? 0u : seg_col + 1u;
+                }
+            }
+        }
+        const uint32_t recpos = s.rp8 >> 8;
+        {   // what is still staged leaves padded to a whole piece with records no block owns
+            const uint32_t end = (recpos + kFlush - 1u) & ~(kFlush - 1u);
+            for (uint32_t q = recpos; q < end; ++q) stage_put<kFlush>(stage, q, kDummyRecord);
+            while (flushed < end) {
+                stage_flush<kFlush>(stage, rec, flushed, out.cap_rec);
+                flushed += kFlush;
+            }
+        }
+        if (timing) tc[4] = clock64();
+        const uint32_t err = stop == 1u ? kStFormat : (stop == 2u ? kStOverrun : 0u);
+        const uint32_t stop_p = s.t + 1u + (stop == 1u ? 17u : 0u);   // FORMAT: the reference has read 17 bits by then
+        const uint64_t stop_mask = __ballot(stop != 0u) & seg;
+        uint32_t st = 0, good_blocks = blocks_per_frame, rec_total = 0, seg_seen = 0;
+        int stop_lane = 0;
+        if (stop_mask) {
+            stop_lane = __builtin_ctzll(stop_mask);   // leftmost = the true path
+            const uint32_t e = __shfl(err, stop_lane);
+            const uint32_t eb = __shfl(end_blocks, stop_lane);
+            const uint32_t sp = __shfl(stop_p, stop_lane);
+            rec_total = __shfl(recpos, stop_lane);
+            seg_seen = __shfl(seg_next, stop_lane);
+            st = e;
+            if (e) good_blocks = eb;
+            if (sp > valid_bits) st |= kStTruncated;
+        } else {
+            st = kStFormat; good_blocks = 0;   // unreachable: the last lane runs until the frame ends or fails
+        }
+
+        // ---- 5. DC prediction: the sums of the lanes to the left are a lane's base; it goes into the frame's lane table
+        // and the reader adds it
+        uint32_t tot;
+        const uint32_t by = seg_excl_sum<L>(lds_load(sumb), sub, tot);
+        const uint32_t bu = seg_excl_sum<L>(lds_load(sumb + kSlot), sub, tot);
+        const uint32_t bv = seg_excl_sum<L>(lds_load(sumb + 2u * kSlot), sub, tot);
+        if (live) {
+            // lanes right of the one that met the end (or the first error) walked from states no decoder reaches
+            const bool real = (int)lane <= stop_lane && blk0 < blocks_per_frame;
+            reinterpret_cast<uint4*>(out.lane_tab)[(uint64_t)frame * L + sub] = make_uint4(real ? dc_first : kNever, by, bu, bv);
+            // segments the decoder never started begin (and end) at the total; so does the end of the last one
+            for (uint32_t m = seg_seen + sub; m <= sg.count; m += L) seg_out[m] = make_uint2(rec_total, rec_total);
+        }
+        if (timing) {
+            tc[5] = clock64();
+            for (int q = 0; q < 5; ++q) atomicAdd(&stats[4 + q], tc[q + 1] - tc[q]);
+            atomicAdd(&stats[9], 1ull);
+        }
+        if (live && sub == 0) {
+            if (stats) {   // optional: how hard the synchronisation worked (amvhip_entropy_stats)
+                atomicAdd(&stats[0], 1ull);
+                atomicAdd(&stats[1], (unsigned long long)rounds);
+                atomicMax(&stats[2], (unsigned long long)rounds);
+            }
+            if (rec_total > out.cap_rec) {   // more non-zero coefficients than the record space holds
+                out.rec_count[frame] = kNever;
+                out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
+            } else {
+                status[frame] = (int32_t)st;
+                nmcu_ok[frame] = good_blocks / 6u;
+                out.rec_count[frame] = rec_total;
             }
         }
     }   // next task
@@ -1071,6 +1339,32 @@ void launch_fast(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
                        ws, ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
 }
 
+template <int L>
+void launch_sync2(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
+                  const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
+                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
+                  uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
+    constexpr uint32_t kMaxWaves = fast_waves(8u);
+    static std::atomic<uint64_t> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync2_kernel<L>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFastTableBytes + kMaxWaves * fast_per_wave(8u)));
+        raised.fetch_or(bit, std::memory_order_relaxed);
+    }
+    // as launch_sync: as many workgroups as the chip holds, smaller ones for a batch that does not fill them
+    const uint32_t tasks = (n + (uint32_t)(kWave / L) - 1u) / (uint32_t)(kWave / L);
+    uint32_t waves = (tasks + cus - 1u) / cus;
+    if (waves < 4u) waves = 4u;
+    if (waves > kMaxWaves) waves = kMaxWaves;
+    uint32_t grid = (tasks + waves - 1u) / waves;
+    if (grid > cus) grid = cus;
+    hipLaunchKernelGGL((amv_huffman_sync2_kernel<L>), dim3(grid), dim3(kWave * waves), kFastTableBytes + waves * fast_per_wave(8u), s, ws,
+                       ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
+}
+
 }  // namespace
 
 // Lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units.
@@ -1114,7 +1408,7 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
     SyncOut out{sinks.coef, sinks.rec, sinks.cap_rec, sinks.seg_start, sinks.lane_tab, SegGeom{g.mcu_cols, per_row, per_row * g.mcu_rows},
                 sinks.rec_count, sinks.retry_list, sinks.retry_count};
 #define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, d_img, out, status, nmcu_ok, queue, stats, cus, s
-    if (sinks.rec) {
+    if (sinks.rec && getenv("AMVHIP_SYNC_OLD")) {
         switch (lanes_per_frame) {
             case 64: launch_sync<64, true>(AMV_SYNC_ARGS); break;
             case 32: launch_sync<32, true>(AMV_SYNC_ARGS); break;
@@ -1123,6 +1417,16 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
             case 2: launch_sync<2, true>(AMV_SYNC_ARGS); break;
             case 1: launch_fast<8>(AMV_SYNC_ARGS); break;
             default: launch_sync<16, true>(AMV_SYNC_ARGS); break;
+        }
+    } else if (sinks.rec) {
+        switch (lanes_per_frame) {
+            case 64: launch_sync2<64>(AMV_SYNC_ARGS); break;
+            case 32: launch_sync2<32>(AMV_SYNC_ARGS); break;
+            case 8: launch_sync2<8>(AMV_SYNC_ARGS); break;
+            case 4: launch_sync2<4>(AMV_SYNC_ARGS); break;
+            case 2: launch_sync2<2>(AMV_SYNC_ARGS); break;
+            case 1: launch_fast<8>(AMV_SYNC_ARGS); break;
+            default: launch_sync2<16>(AMV_SYNC_ARGS); break;
         }
     } else {
         switch (lanes_per_frame) {

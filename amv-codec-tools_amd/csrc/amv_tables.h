@@ -114,12 +114,12 @@ static constexpr int kM2Bits = 10;
 // share is 0.  Entry: bits 0-3 magnitude bits (bit 4 is 0: the whole word can serve as a bit-field width operand),
 // bit 5 "no such code", bit 8 "carries a value" (a record's stride in the staging area), byte 2 how far the
 // coefficient index moves (run + 1; 1 for a DC symbol; 192 for end-of-block: bit 6 of index + 192 is set for every
-// index 1..63; 80 for "no such code", so that index + 80 falls into 65..143 like an over-long run, 65..79, and unlike
-// anything a decoder accepts), byte 3 code length + magnitude bits.
+// index 1..63 and the sum stays clear of 65..79, an over-long run; 0 for "no such code"), byte 3 code length +
+// magnitude bits (1 for "no such code": a walk from a guessed start slips one bit there, the strict walk stops).
 static constexpr uint32_t kFastWords = 2048;          // per table: 8 KB, a power of two (the table is chosen by OR-ing address bits)
 static constexpr uint32_t kFastM2Word = 512;
 static constexpr uint32_t kFastLongFirst = 0xfc00u;   // 16-bit windows from here on begin with six one-bits
-static constexpr uint32_t kFastInvalid = 1u << 5, kFastEmit = 1u << 8, kFastEobAdvance = 192u, kFastInvalidAdvance = 80u;
+static constexpr uint32_t kFastInvalid = 1u << 5, kFastEmit = 1u << 8, kFastEobAdvance = 192u;
 struct HuffDecodeImage {
     uint16_t l1[4][1 << kLut1Bits];
     uint16_t l2[kLut2Pages][1 << kLut2Bits];

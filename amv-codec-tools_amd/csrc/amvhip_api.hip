@@ -163,7 +163,7 @@ void build_images(HuffDecodeImage& dec, HuffEncodeImage& enc) {
     // the one-lane-per-frame walk's form (amv_tables.h)
     auto fast = [](uint16_t e, int t) -> uint32_t {
         const uint32_t len = (e >> 8) & 31u, sym = e & 0xffu, size = sym & 15u;
-        if (len == 0) return kFastInvalid | (kFastInvalidAdvance << 16);
+        if (len == 0) return kFastInvalid | (1u << 24);   // one bit used, no advance: what a guessed start does with it
         const bool dc = t < 2;
         const uint32_t adv = dc ? 1u : (sym == 0 ? kFastEobAdvance : (sym >> 4) + 1u);
         return size | ((dc || size) ? kFastEmit : 0u) | (adv << 16) | ((len + size) << 24);
