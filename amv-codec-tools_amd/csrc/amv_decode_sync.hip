@@ -10,9 +10,9 @@
 //      copies the scan into a workspace as big-endian words with the byte after every FF removed
 //      (ReadByte, AmvJpeg.c:1061-1071), so that a decoder state is just a bit index.
 //
-//   amv_huffman_sync_kernel<L, records> (independent waves sharing the tables: up to 16 per workgroup, one
-//   workgroup per CU, in the records form, 10 x 2 in the dense form; L lanes per frame, 64/L frames per
-//   wave; waves take tasks of 64/L frames from an atomic queue)
+//   amv_huffman_sync2_kernel<L> (records form) and amv_huffman_sync_kernel<L> (dense form: coefficient lines)
+//   (independent waves sharing the tables, up to 13 per workgroup, one workgroup per CU -- dense: 10 x 2; L lanes per
+//   frame, 64/L frames per wave; waves take tasks of 64/L frames from an atomic queue)
 //   0. a lane reads its part of the stream through a 16-word window in LDS that it refills from the
 //      workspace (L2) with 16-byte loads whenever any lane of the wave has used its window up, so a
 //      wave needs 4 KB of LDS whatever the frame size (dense form: the frames' coefficient lines are
@@ -28,32 +28,31 @@
 //      that changed.  Lane 0's start is exact, so after round r lanes 0..r are exact; in practice
 //      wrong starts fall into step with the true decoder after ~4 400 bits (the slow part is the
 //      luma/chroma phase of the MCU, a 1-in-6 guess) and the loop ends early (worst case L-1
-//      rounds: still correct).  These walks only look at symbol lengths and index advances, in a
-//      branch-free loop whose three LDS reads (two table levels, next stream word) go out together;
+//      rounds: still correct).  These walks only look at symbol lengths and index advances;
 //      the number of lanes per frame follows the batch size (huffman_sync_lanes): as many as keep
 //      every task resident at once, because the launch lasts as long as one task does;
 //   3. a prefix sum of "blocks finished per lane" gives every lane its first block number;
-//   3'. records form: a prefix sum of "value-carrying AC symbols per lane" gives every lane its first
-//      record;
+//   3'. records form: a prefix sum of "value-carrying symbols per lane" gives every lane its first record;
 //   4. one strict pass decodes values and writes them: records form, one 32-bit word per DC coefficient
 //      and per non-zero AC coefficient (index, block modulo 64, value) in stream order, staged per lane
-//      in LDS and stored as aligned 32-byte pieces, + the first record of every MCU-row segment -- what
+//      in LDS and stored as aligned 32-byte pieces, + where the records of every MCU-row segment lie -- what
 //      amv_reconstruct_kernel scatters into LDS; dense form, 2-byte stores into the frame's zeroed
 //      coefficient lines.  DC prediction (ycoef/ucoef/vcoef, AmvJpeg.c:1200-1221) is a running sum per
 //      component: each lane's sums count from its own start,
 //   5. a prefix sum over the lanes' totals gives every lane its three bases: records form, they go into
 //      the frame's lane table and the reader adds them; dense form, the lane adds them to the DC values
 //      it stored itself.
+//   The records form walks in arithmetic on a state chosen for it (fast_skip, fast_stride: "One lane per frame"
+//   below says how); the dense form keeps the select-based walks (walk_skip, walk_write).
 //
 //   amv_huffman_fast_kernel (one lane per frame, records form: what a batch that fills the chip that way gets)
-//      passes 1-3 and 5 fall away and pass 4 is a different walk, built on arithmetic instead of selects (below).
+//      passes 1-3 and 5 fall away, pass 4 is fast_stride without a share limit; records leave as whole lines.
 //
 // Statuses equal the serial kernel's bit for bit (tests): the first error on the true path stops
 // the frame, nmcu_ok counts whole MCUs before it, TRUNCATED compares consumed with stored bits.
 // Chunks larger than the per-frame workspace window, or with a run of FF bytes longer than the 8-byte
 // look-back of the unstuffer (never in a valid stream), are queued for amv_huffman_kernel.
 #include <atomic>
-#include <cstdlib>
 
 #include "amv_kernels.h"
 
@@ -62,18 +61,11 @@ namespace amv {
 namespace {
 
 constexpr int kWave = 64;
-// independent waves per workgroup (they share only the tables) and workgroups per CU.  Dense form: 10 x 2 = 20 waves
-// per CU, what the kernel's VGPR count allows (5 per SIMD).  Records form: every wave also stages its records in LDS
-// (8 KB per wave with the stream window), so one workgroup of 16 waves per CU (137 KB of the 160 KB).
-constexpr int waves_per_group(bool rec, int lanes) { return rec ? (lanes <= 2 ? 10 : 16) : 10; }
-constexpr int groups_per_cu(bool rec) { return rec ? 1 : 2; }
 constexpr uint32_t kRingWords = 16;       // LDS words per lane: the window of its stream a lane works in
-// Records are staged per lane in LDS and leave as whole, aligned 32-byte pieces (a 4-byte store per record from 64
+// Records are staged per lane in LDS and leave as whole, aligned pieces of eight (a 4-byte store per record from 64
 // lanes into 64 different lines was written back to HBM as partial lines several times over: 9.8 GB of writes per
-// 160 000 frames for 0.7 GB of records, and with one or two lanes per frame those stores were what the walk waited on).
-// records per store burst: 32 bytes, or -- with one or two lanes per frame, where ten waves per CU are all a batch
-// can fill anyway and the LDS is there -- 64.  A lane's staging column holds two bursts.
-constexpr uint32_t flush_records(int lanes) { return lanes <= 2 ? 16u : 8u; }
+// 160 000 frames for 0.7 GB of records, and those stores were what the walk waited on).  A lane's staging column holds
+// two pieces.
 constexpr uint32_t kDummyRecord = 0x8000u;    // bit 15: a filler no block owns
 constexpr uint32_t kNever = 0xffffffffu;
 constexpr uint32_t kTableBytes = (4u << kLut1Bits) * 2u + (4u << kM2Bits) * 2u;   // m1 + m2 of HuffDecodeImage, contiguous
@@ -329,10 +321,8 @@ __device__ __forceinline__ void window_consume(Window& x, uint32_t used, uint32_
 // (a lane that is past its limit goes through the motions without moving), so that the scheduler can overlap the
 // table look-up of one symbol with the bookkeeping of the one before.
 __device__ __forceinline__ uint32_t walk_skip(Stream& w, const uint16_t* __restrict__ m1,
-                                              const uint16_t* __restrict__ m2, State& s, uint32_t limit,
-                                              uint32_t& nrec_out) {
-    uint32_t p = s.p, k = s.k, k6 = s.k6, nblk = 0, nrec = 0;
-    nrec_out = 0u;
+                                              const uint16_t* __restrict__ m2, State& s, uint32_t limit) {
+    uint32_t p = s.p, k = s.k, k6 = s.k6, nblk = 0;
     bool active = p < limit;
     if (!__ballot(active)) return 0u;
     Window x = window_open(w, active ? p : 0u);
@@ -345,7 +335,6 @@ __device__ __forceinline__ uint32_t walk_skip(Stream& w, const uint16_t* __restr
             const uint32_t e = lookup(m1, m2, tab, window_bits(x));
             const uint32_t used = active ? max(e & 31u, 1u) : 0u;   // nonsense under a guessed start: slip one bit
             const uint32_t kn = k + (active ? (e >> 5) & 63u : 0u);
-            nrec += (active && (k == 0u || (e & 0x7800u) != 0u)) ? 1u : 0u;   // a DC symbol, or an AC symbol that carries a value
             p += used;
             window_consume(x, used, cand);
             const bool end = kn >= 64u;                        // end of block, a full block, or an over-long run
@@ -357,7 +346,6 @@ __device__ __forceinline__ uint32_t walk_skip(Stream& w, const uint16_t* __restr
         }
     }
     s.p = p; s.k = k; s.k6 = k6;
-    nrec_out = nrec;
     return nblk;
 }
 
@@ -369,20 +357,6 @@ struct WriteResult {
     uint32_t dc_first;   // first block whose DC symbol this lane decoded, and how many follow
     uint32_t dc_count;
     int sum[3];          // the lane's DC differences added up per component (Y, Cb, Cr)
-    uint32_t recpos;     // records mode: next free record when the walk ended
-    uint32_t seg_next;   // records mode: index of the next MCU-row segment whose start this path has not seen yet
-};
-
-// Where the strict pass puts its output.  Dense: the frame's coefficient lines (zeroed before).
-// Records: one 32-bit word per DC coefficient and per non-zero AC coefficient, in stream order -- bits 0-5 index
-// in block (0 = DC), bits 6-11 (block - blocks per frame) modulo 64 (a reader works on <= 60 consecutive blocks; counting
-// from the frame's end suits the one-lane walk, whose block counter runs up to 0), bit 15 "no block owns
-// this record" (filler), bits 16-31 value; a DC value is the sum of the DC differences from the lane's first block
-// on, the reader adds the lane's base (lane table) -- plus the record index at which every MCU-row segment starts.
-struct Sink {
-    int16_t* coef;        // dense
-    uint32_t* rec;        // records
-    uint32_t* seg_start;
 };
 
 // The MCU-row segments amv_reconstruct_kernel works in: kSegMcus MCUs, the last one of a row shorter.
@@ -393,7 +367,6 @@ struct SegGeom {
 };
 constexpr uint32_t kSegMcus = 10;   // = amv_reconstruct.hip's
 
-// The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state.
 // stage: this lane's column of the wave's staging area; record slot q of lane l lives at dword q * 64 + l (the
 // bank depends on the lane only, the address is one shift-and-add)
 template <uint32_t kFlush>
@@ -416,46 +389,25 @@ __device__ __forceinline__ void stage_flush(const uint32_t* stage, uint32_t* __r
     }
 }
 
-// Records form: a stride of kStrideWrite symbols is straight-line code -- every lane goes through every step, a lane
-// that has stopped (end of frame, error, end of its share) without moving or emitting -- so that the scheduler can
-// overlap one symbol's table look-up with the bookkeeping of the one before; a record is always written to the next
-// free staging slot and only counted when it is real.  Dense form: the 2-byte stores are conditional.
-template <bool kRec, uint32_t kFlush>
+// The strict, writing walk (HufBlock / DecodeElement, AmvJpeg.c:842-974) from an exact state into the frame's
+// (zeroed) coefficient lines: the dense form.  A stride of kStride symbols is straight-line code -- every lane goes
+// through every step, a lane that has stopped (end of frame, error, end of its share) without moving -- with
+// conditional 2-byte stores.  (The records form has walks of its own: fast_stride, below.)
 __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __restrict__ m1,
                                                   const uint16_t* __restrict__ m2, State s, uint32_t limit,
-                                                  uint32_t blk, uint32_t blocks_per_frame, const Sink& out,
-                                                  uint32_t recpos, uint32_t rec_cap, uint32_t* stage, const SegGeom& sg) {
-    WriteResult r{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, recpos, 0u};
-    // the first segment start this lane can meet: the first MCU at or after its first DC block
-    uint32_t seg_col = 0, seg_blk = 0;   // that segment's place in its row, and its first block
-    if (kRec) {
-        const uint32_t m_first = (blk + (s.k ? 1u : 0u) + 5u) / 6u;
-        uint32_t row = m_first / sg.mcu_cols;
-        const uint32_t col = m_first - row * sg.mcu_cols;
-        seg_col = (col + kSegMcus - 1u) / kSegMcus;
-        if (seg_col >= sg.per_row) { ++row; seg_col = 0u; }
-        r.seg_next = row * sg.per_row + seg_col;
-        seg_blk = (row * sg.mcu_cols + seg_col * kSegMcus) * 6u;
-    }
-    int16_t* __restrict__ coef = out.coef;
+                                                  uint32_t blk, uint32_t blocks_per_frame, int16_t* __restrict__ coef) {
+    WriteResult r{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}};
     uint32_t p = s.p, k = s.k, k6 = s.k6;
     r.dc_first = blk + (k ? 1u : 0u);
     int s0 = 0, s1 = 0, s2 = 0;
     bool alive = p < limit;
     uint32_t stop = 0;           // why the lane stopped: 1 invalid code, 2 index past 63, 3 the frame's last block is done
-    uint32_t flushed = recpos;   // records before this one have left for memory (a multiple of kFlush)
-    uint32_t seg_pos = 0;        // where the segment that starts inside the current stride starts (at most one does:
-    bool seg_hit = false;        // a segment is >= 6 blocks = 12 symbols, a stride 8)
     Window x = window_open(w, p);
     uint32_t tab = table_of(k, k6);
     while (__ballot(alive) != 0ull) {
         if (alive) stream_service(w, x.widx);
-        if (kRec && r.recpos - flushed >= kFlush) {
-            stage_flush<kFlush>(stage, out.rec, flushed, rec_cap);
-            flushed += kFlush;
-        }
 #pragma unroll
-        for (int it = 0; it < (kRec ? kStrideWrite : kStride); ++it) {
+        for (int it = 0; it < kStride; ++it) {
             const uint32_t cand = ring_word(w, x.widx);
             const uint32_t v = window_bits(x);
             const uint32_t e = lookup(m1, m2, tab, v);
@@ -481,18 +433,8 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
             s2 = (dc && k6 == 5u) ? t : s2;
             r.dc_count += dc ? 1u : 0u;
             const bool ac = good && !isdc && !iseob && size != 0u;
-            if (kRec) {
-                // the sum counts from this lane's start; the reader adds the lane's base
-                const bool hit = dc && blk == seg_blk;           // an MCU-row segment starts with this block
-                seg_pos = hit ? r.recpos : seg_pos;
-                seg_hit = seg_hit || hit;
-                const uint32_t pos = isdc ? 0u : idx;
-                stage_put<kFlush>(stage, r.recpos, pos | (((blk - blocks_per_frame) & 63u) << 6) | ((uint32_t)(isdc ? t : val) << 16));
-                r.recpos += (dc || ac) ? 1u : 0u;                // (the slot behind the last record is always free)
-            } else {
-                if (dc) coef[(uint64_t)blk * 64u] = (int16_t)t;  // pass 5 adds the base
-                if (ac) coef[(uint64_t)blk * 64u + idx] = (int16_t)val;
-            }
+            if (dc) coef[(uint64_t)blk * 64u] = (int16_t)t;      // the sum counts from this lane's start; pass 5 adds the base
+            if (ac) coef[(uint64_t)blk * 64u + idx] = (int16_t)val;
             const uint32_t newk = isdc ? 1u : idx + 1u;
             const bool block_end = good && (iseob || (!isdc && newk == 64u));
             k = good ? (block_end ? 0u : newk) : k;
@@ -504,36 +446,21 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
             stop = (alive && why) ? why : stop;
             alive = alive && !why && p < limit;
         }
-        if (kRec && seg_hit) {   // once per <= 60 blocks
-            reinterpret_cast<uint2*>(out.seg_start)[r.seg_next++] = make_uint2(seg_pos, seg_pos);   // exact: from == to
-            const bool last = seg_col + 1u == sg.per_row;
-            seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
-            seg_col = last ? 0u : seg_col + 1u;
-            seg_hit = false;
-        }
     }
     // the state froze where the lane stopped
     r.err = stop == 1u ? kStFormat : (stop == 2u ? kStOverrun : 0u);
     r.err_blk = blk;
     r.stop_p = stop == 1u ? p + 17u : p;
     r.done = stop == 3u;
-    if (kRec) {   // what is still staged leaves padded to a whole piece with records no block owns
-        const uint32_t end = (r.recpos + kFlush - 1u) & ~(kFlush - 1u);
-        for (uint32_t q = r.recpos; q < end; ++q) stage_put<kFlush>(stage, q, kDummyRecord);
-        while (flushed < end) {
-            stage_flush<kFlush>(stage, out.rec, flushed, rec_cap);
-            flushed += kFlush;
-        }
-    }
     r.sum[0] = s0; r.sum[1] = s1; r.sum[2] = s2;
     return r;
 }
 
 }  // namespace
 
-// Outputs of the records form (SyncOut::rec != nullptr), all per frame: rec[cap_rec] records, seg_start[segs + 1]
-// record index at which each MCU-row segment starts (entries of segments the decoder never reached, and the last
-// one, hold the total), lane_tab[L] = {first block whose DC the lane decoded, DC base Y, Cb, Cr} (lanes right of the
+// Outputs of the records form (SyncOut::rec != nullptr), all per frame: rec[cap_rec] records, seg_start[segs + 1][2]
+// {from, to} bounds of each MCU-row segment's records (SyncSinks; entries of segments the decoder never reached, and
+// the last one, hold the total twice), lane_tab[L] = {first block whose DC the lane decoded, DC base Y, Cb, Cr} (lanes right of the
 // one that met the frame's end or first error: first block ~0), rec_count = total, or ~0 when the frame was handed to
 // the serial kernel, whose output is dense coefficient lines.
 struct SyncOut {
@@ -548,9 +475,10 @@ struct SyncOut {
     uint32_t* retry_count;
 };
 
-// dynamic LDS: [ m1 4 KB | m2 8 KB | per wave: ring of kRingWords words per lane | records form, per wave: staged records ]
+// The dense form (coefficient lines: amvhip_huffman_decode_dev's output).
+// dynamic LDS: [ m1 4 KB | m2 8 KB | per wave: ring of kRingWords words per lane ]
 // With a list, the kernel decodes frames list[0 .. *list_count) (surplus waves do nothing).
-template <int L, bool kRec>
+template <int L>
 __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
@@ -570,10 +498,7 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
-    const uint32_t nwaves = blockDim.x >> 6;   // the launch sizes the workgroup (and its LDS) to the batch
     uint32_t* ring = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + wave * (kRingWords * kWave) + lane;
-    constexpr uint32_t kFlush = flush_records(L);
-    uint32_t* stage = reinterpret_cast<uint32_t*>(s_mem + kTableBytes) + nwaves * (kRingWords * kWave) + wave * (2u * kFlush * kWave) + lane;
     if (list) n = *list_count;
     const uint32_t ntasks = (n + kFrames - 1) / kFrames;
     // Tasks (kFrames frames each) are handed out through a counter: a wave that finishes early -- the
@@ -592,16 +517,12 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     const uint32_t idx = task * kFrames + slot;
     const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
     const uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
-    if (kRec && frame != kNever && total == kNever && sub == 0) out.rec_count[frame] = kNever;
     const bool live = total != kNever;
     const uint32_t fsafe = live ? frame : 0u;
-    Sink sink;
-    sink.coef = kRec ? nullptr : out.coef + (uint64_t)fsafe * blocks_per_frame * 64u;
-    sink.rec = kRec ? out.rec + (uint64_t)fsafe * out.cap_rec : nullptr;
-    sink.seg_start = kRec ? out.seg_start + (uint64_t)fsafe * (out.sg.count + 1u) * 2u : nullptr;
+    int16_t* const coef = out.coef + (uint64_t)fsafe * blocks_per_frame * 64u;
     const uint32_t valid_bits = live ? total * 8u : 0u;
-    if (!kRec && live) {   // dense form: the frame's coefficient lines start as zeros
-        uint4* z = reinterpret_cast<uint4*>(sink.coef);
+    if (live) {   // the frame's coefficient lines start as zeros
+        uint4* z = reinterpret_cast<uint4*>(coef);
         for (uint32_t i = sub; i < blocks_per_frame * 8u; i += L) z[i] = make_uint4(0, 0, 0, 0);
     }
     Stream win{ws + (uint64_t)fsafe * cap_words, live ? ((total + 15u) >> 4) * 4u : 0u, ring, 0u, make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
@@ -613,8 +534,7 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     const uint32_t limit = (!live || sub == L - 1) ? 0u : (sub + 1u) * S;
     State entry{sub * S, 0u, 0u}, arrive = entry;
     if (timing) tc[1] = clock64();
-    uint32_t my_recs;
-    uint32_t my_blocks = walk_skip(win, m1, m2, arrive, limit, my_recs);
+    uint32_t my_blocks = walk_skip(win, m1, m2, arrive, limit);
     if (timing) tc[2] = clock64();
     uint32_t rounds = 0;
     const uint64_t seg = L == 64 ? ~0ull : (((1ull << (L & 63)) - 1ull) << (slot * L));
@@ -630,36 +550,29 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
         if (changed) {
             entry = left;
             arrive = left;
-            my_blocks = walk_skip(win, m1, m2, arrive, limit, my_recs);
+            my_blocks = walk_skip(win, m1, m2, arrive, limit);
         }
     }
     if (timing) tc[3] = clock64();
 
-    // ---- 3. first block (and first record) of every lane
-    uint32_t all_blocks, all_recs = 0;
+    // ---- 3. first block of every lane (the last lane has not walked: its count is 0, it is last)
+    uint32_t all_blocks;
     const uint32_t blk0 = seg_excl_sum<L>(my_blocks, sub, all_blocks);
-    uint32_t rec0 = 0;
-    // every lane's records start on a 32-byte piece (the gap behind its last record is filled with dummies);
-    // (the last lane has not walked: its count is 0, it is last)
-    if (kRec) rec0 = seg_excl_sum<L>((my_recs + kFlush - 1u) & ~(kFlush - 1u), sub, all_recs);
 
     // ---- 4. the strict, writing pass.  Lanes left of the frame's end (or first error) are exact;
     // whatever a lane to the right of it does is ignored below.
-    __builtin_amdgcn_s_waitcnt(0);   // dense form: the zeroing stores have landed before the sparse ones go out
-    WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}, 0u, 0u};
+    __builtin_amdgcn_s_waitcnt(0);   // the zeroing stores have landed before the sparse ones go out
+    WriteResult wr{0u, 0u, 0u, false, 0u, 0u, {0, 0, 0}};
     if (live && blk0 < blocks_per_frame)
-        wr = walk_write<kRec, kFlush>(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, sink, rec0, out.cap_rec, stage, out.sg);
+        wr = walk_write(win, m1, m2, entry, sub == L - 1 ? kNever : limit, blk0, blocks_per_frame, coef);
     if (timing) tc[4] = clock64();
     const uint64_t stop_mask = __ballot(wr.done || wr.err != 0u) & seg;
-    uint32_t st = 0, good_blocks = blocks_per_frame, rec_total = 0, seg_seen = 0;
-    int stop_lane = 0;
+    uint32_t st = 0, good_blocks = blocks_per_frame;
     if (stop_mask) {
-        stop_lane = __builtin_ctzll(stop_mask);   // leftmost = the true path
+        const int stop_lane = __builtin_ctzll(stop_mask);   // leftmost = the true path
         const uint32_t e = __shfl(wr.err, stop_lane);
         const uint32_t eb = __shfl(wr.err_blk, stop_lane);
         const uint32_t sp = __shfl(wr.stop_p, stop_lane);
-        rec_total = __shfl(wr.recpos, stop_lane);
-        seg_seen = __shfl(wr.seg_next, stop_lane);
         st = e;
         if (e) good_blocks = eb;
         if (sp > valid_bits) st |= kStTruncated;
@@ -667,30 +580,18 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
         st = kStFormat; good_blocks = 0;   // unreachable: the last lane runs until the frame ends or fails
     }
 
-    // ---- 5. DC prediction: the sums of the lanes to the left are a lane's base.  Records form: the base goes into
-    // the frame's lane table and the reader adds it.  Dense form: every lane adds it to the DCs it stored (a lane
-    // reads back only its own stores -- same thread, ordered by the wait -- so no cache is in play).
+    // ---- 5. DC prediction: the sums of the lanes to the left are a lane's base, which it adds to the DCs it stored (a
+    // lane reads back only its own stores -- same thread, ordered by the wait -- so no cache is in play).
     uint32_t tot;
     const int by = (int)seg_excl_sum<L>((uint32_t)wr.sum[0], sub, tot);
     const int bu = (int)seg_excl_sum<L>((uint32_t)wr.sum[1], sub, tot);
     const int bv = (int)seg_excl_sum<L>((uint32_t)wr.sum[2], sub, tot);
-    if (kRec) {
-        if (live) {
-            // lanes right of the one that met the end (or the first error) walked from states no decoder reaches
-            const bool real = (int)lane <= stop_lane && blk0 < blocks_per_frame;
-            uint4 ent = make_uint4(real ? wr.dc_first : kNever, (uint32_t)by, (uint32_t)bu, (uint32_t)bv);
-            reinterpret_cast<uint4*>(out.lane_tab)[(uint64_t)frame * L + sub] = ent;
-            // segments the decoder never started begin (and end) at the total; so does the end of the last one
-            for (uint32_t m = seg_seen + sub; m <= out.sg.count; m += L) reinterpret_cast<uint2*>(sink.seg_start)[m] = make_uint2(rec_total, rec_total);
-        }
-    } else {
-        __builtin_amdgcn_s_waitcnt(0);
-        for (uint32_t j = 0; j < wr.dc_count; ++j) {
-            const uint32_t b = wr.dc_first + j, c6 = b % 6u;
-            const int base = c6 < 4u ? by : (c6 == 4u ? bu : bv);
-            int16_t* q = sink.coef + (uint64_t)b * 64u;
-            *q = (int16_t)(*q + base);
-        }
+    __builtin_amdgcn_s_waitcnt(0);
+    for (uint32_t j = 0; j < wr.dc_count; ++j) {
+        const uint32_t b = wr.dc_first + j, c6 = b % 6u;
+        const int base = c6 < 4u ? by : (c6 == 4u ? bu : bv);
+        int16_t* q = coef + (uint64_t)b * 64u;
+        *q = (int16_t)(*q + base);
     }
     if (timing) {
         tc[5] = clock64();
@@ -703,14 +604,8 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
             atomicAdd(&stats[1], (unsigned long long)rounds);
             atomicMax(&stats[2], (unsigned long long)rounds);
         }
-        if (kRec && rec_total > out.cap_rec) {   // more non-zero coefficients than the record space holds
-            out.rec_count[frame] = kNever;
-            out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
-        } else {
-            status[frame] = (int32_t)st;
-            nmcu_ok[frame] = good_blocks / 6u;
-            if (kRec) out.rec_count[frame] = rec_total;
-        }
+        status[frame] = (int32_t)st;
+        nmcu_ok[frame] = good_blocks / 6u;
     }
     }   // next task
 }
@@ -1284,33 +1179,33 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
 
 namespace {
 
-template <int L, bool kRec>
+template <int L>
 void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
                  const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
                  uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
-    constexpr uint32_t kMaxWaves = (uint32_t)waves_per_group(kRec, L);
-    constexpr uint32_t kPerWave = kRingWords * kWave * 4u + (kRec ? 2u * flush_records(L) * kWave * 4u : 0u);
+    constexpr uint32_t kMaxWaves = 10u;
+    constexpr uint32_t kPerWave = kRingWords * kWave * 4u;
     // the attribute belongs to the device's copy of the function: once per device and instantiation
     static std::atomic<uint64_t> raised{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L, kRec>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_huffman_sync_kernel<L>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTableBytes + kMaxWaves * kPerWave));
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
     // Workgroups: as many as the chip holds (the rest of the tasks come from the queue); a batch that does not fill
     // them gets smaller workgroups, so that its waves spread over all the compute units instead of filling a few.
-    const uint32_t groups = cus * (uint32_t)groups_per_cu(kRec);
+    const uint32_t groups = cus * 2u;
     const uint32_t tasks = (n + (uint32_t)(kWave / L) - 1u) / (uint32_t)(kWave / L);
     uint32_t waves = (tasks + groups - 1u) / groups;
     if (waves < 4u) waves = 4u;
     if (waves > kMaxWaves) waves = kMaxWaves;
     uint32_t grid = (tasks + waves - 1u) / waves;
     if (grid > groups) grid = groups;
-    hipLaunchKernelGGL((amv_huffman_sync_kernel<L, kRec>), dim3(grid), dim3(kWave * waves), kTableBytes + waves * kPerWave, s, ws,
+    hipLaunchKernelGGL((amv_huffman_sync_kernel<L>), dim3(grid), dim3(kWave * waves), kTableBytes + waves * kPerWave, s, ws,
                        ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
 }
 
@@ -1370,17 +1265,17 @@ void launch_sync2(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, cons
 // Lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units.
 // More lanes per frame mean shorter walks (a shorter launch when the chip is not full) but more
 // speculative work per frame: every lane needs ~4 400 bits to fall in step whatever its share of the
-// frame.  Measured on MI355X: a batch that fills the chip with ONE lane per frame (>= ~300 frames per CU) does best
-// with exactly that -- no speculative work at all, 2.7 ms per 160 000 frames of
-// 160x120 against 3.1 with two lanes and 4.9 with eight; from ~200 frames per CU two lanes (lane 0 is exact, so
-// lane 1 starts right after one walk); below that the best share is about the synchronisation length (160x120
-// at ~1.5 bits per pixel: 8 lanes; 320x240: 16), and a small batch does best with the most lanes that keep
-// it at ~10 waves per CU (10 000 frames of 160x120: 16; 2 000 of 320x240: 64).  `wanted` (a power of two
-// up to 64) overrides.
+// frame.  Measured on MI355X (entropy kernel, ms; 160x120 unless said): a batch that fills the chip with ONE lane per
+// frame does best with exactly that -- no speculative work at all: 160 000 frames 2.11 with one lane, 2.70 with two,
+// 3.15 with four; 120 000: 1.65 / 2.20; 80 000: 1.50 / 1.53; 60 000: 1.21 / 1.19 -- so one lane from ~230 frames per CU,
+// two from ~150 (40 000: 0.97 with two, 1.01 with eight).  Below that the best share is about the synchronisation
+// length and as many lanes as keep every task resident: 20 000: 0.67 with eight; 10 000: 0.49 with sixteen (0.52 / 0.63
+// with eight / thirty-two); 320x240: 32 000 frames 1.90 with eight (1.84 with sixteen), 8 000: 0.68 with sixteen,
+// 2 000: 0.32 with sixty-four.  `wanted` (a power of two up to 64) overrides.
 int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     if (wanted == 1 || wanted == 2 || wanted == 4 || wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
-    if (n >= cus * 300u) return 1;                 // measured: 80 000 frames 1 lane 1.98 ms / 2 lanes 2.02; 120 000: 2.04 / 2.58
-    if (n >= cus * 200u) return 2;
+    if (n >= cus * 230u) return 1;
+    if (n >= cus * 150u) return 2;
     int full = 8;                                  // chip full: 8 lanes up to 320x240 (32 000 frames: 2.54 ms against 2.67 with 16)
     while (full < 64 && (uint64_t)full * 25000u <= pixels) full *= 2;
     const uint64_t waves = (uint64_t)cus * 10u;
@@ -1408,17 +1303,7 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
     SyncOut out{sinks.coef, sinks.rec, sinks.cap_rec, sinks.seg_start, sinks.lane_tab, SegGeom{g.mcu_cols, per_row, per_row * g.mcu_rows},
                 sinks.rec_count, sinks.retry_list, sinks.retry_count};
 #define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, d_img, out, status, nmcu_ok, queue, stats, cus, s
-    if (sinks.rec && getenv("AMVHIP_SYNC_OLD")) {
-        switch (lanes_per_frame) {
-            case 64: launch_sync<64, true>(AMV_SYNC_ARGS); break;
-            case 32: launch_sync<32, true>(AMV_SYNC_ARGS); break;
-            case 8: launch_sync<8, true>(AMV_SYNC_ARGS); break;
-            case 4: launch_sync<4, true>(AMV_SYNC_ARGS); break;
-            case 2: launch_sync<2, true>(AMV_SYNC_ARGS); break;
-            case 1: launch_fast<8>(AMV_SYNC_ARGS); break;
-            default: launch_sync<16, true>(AMV_SYNC_ARGS); break;
-        }
-    } else if (sinks.rec) {
+    if (sinks.rec) {
         switch (lanes_per_frame) {
             case 64: launch_sync2<64>(AMV_SYNC_ARGS); break;
             case 32: launch_sync2<32>(AMV_SYNC_ARGS); break;
@@ -1430,13 +1315,13 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
         }
     } else {
         switch (lanes_per_frame) {
-            case 64: launch_sync<64, false>(AMV_SYNC_ARGS); break;
-            case 32: launch_sync<32, false>(AMV_SYNC_ARGS); break;
-            case 8: launch_sync<8, false>(AMV_SYNC_ARGS); break;
-            case 4: launch_sync<4, false>(AMV_SYNC_ARGS); break;
-            case 2: launch_sync<2, false>(AMV_SYNC_ARGS); break;
-            case 1: launch_sync<1, false>(AMV_SYNC_ARGS); break;
-            default: launch_sync<16, false>(AMV_SYNC_ARGS); break;
+            case 64: launch_sync<64>(AMV_SYNC_ARGS); break;
+            case 32: launch_sync<32>(AMV_SYNC_ARGS); break;
+            case 8: launch_sync<8>(AMV_SYNC_ARGS); break;
+            case 4: launch_sync<4>(AMV_SYNC_ARGS); break;
+            case 2: launch_sync<2>(AMV_SYNC_ARGS); break;
+            case 1: launch_sync<1>(AMV_SYNC_ARGS); break;
+            default: launch_sync<16>(AMV_SYNC_ARGS); break;
         }
     }
 #undef AMV_SYNC_ARGS
