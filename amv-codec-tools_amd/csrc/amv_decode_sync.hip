@@ -883,19 +883,24 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
             const uint4 v0 = make_uint4(p[0], p[kWave], p[2 * kWave], p[3 * kWave]);
             const uint4 v1 = make_uint4(p[4 * kWave], p[5 * kWave], p[6 * kWave], p[7 * kWave]);
             const uint32_t quarter = (flushed >> 3) & 3u;
-            if (quarter == 3u) {
-                if (flushed + 8u <= out.cap_rec) {   // never past the frame's record space (a multiple of 32); an overfull frame is redone densely
-                    uint4* d = reinterpret_cast<uint4*>(rec + flushed - 24u);
+            if (quarter == 3u && flushed + 8u <= out.cap_rec) {   // never past the frame's record space (a multiple of 32); an overfull frame is redone densely
+                uint4* d = reinterpret_cast<uint4*>(rec + flushed - 24u);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) d[q] = held[q];
-                    d[6] = v0; d[7] = v1;
-                }
-            } else if (quarter == 0u) { held[0] = v0; held[1] = v1; }
-            else if (quarter == 1u) { held[2] = v0; held[3] = v1; }
-            else { held[4] = v0; held[5] = v1; }
+                for (int q = 0; q < 6; ++q) d[q] = held[q];
+                d[6] = v0; d[7] = v1;
+            }
+            // (selects in place: with a branch per quarter the compiler shuffled all 24 registers around the loop)
+#pragma unroll
+            for (uint32_t q = 0; q < 3u; ++q) {
+                const bool mine = quarter == q;
+                held[2u * q].x = mine ? v0.x : held[2u * q].x; held[2u * q].y = mine ? v0.y : held[2u * q].y;
+                held[2u * q].z = mine ? v0.z : held[2u * q].z; held[2u * q].w = mine ? v0.w : held[2u * q].w;
+                held[2u * q + 1u].x = mine ? v1.x : held[2u * q + 1u].x; held[2u * q + 1u].y = mine ? v1.y : held[2u * q + 1u].y;
+                held[2u * q + 1u].z = mine ? v1.z : held[2u * q + 1u].z; held[2u * q + 1u].w = mine ? v1.w : held[2u * q + 1u].w;
+            }
             flushed += 8u;
         };
-        while (__ballot(alive) != 0ull) {
+        if (__ballot(alive) != 0ull) do {   // (bottom-tested: with the test on top the compiler copies the 24 held registers at every loop entry)
             if (alive) fast_service(win, (s.t + 1u) >> 5);
             if ((s.rp8 >> 8) - flushed >= 8u) flush();
             const bool running = alive;
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
                     seg_col = last ? 0u : seg_col + 1u;
                 }
             }
-        }
+        } while (__ballot(alive) != 0ull);
         const uint32_t recpos = s.rp8 >> 8;
         {   // what is still staged leaves padded to a whole line with records no block owns
             const uint32_t end = (recpos + 31u) & ~31u;
@@ -1076,8 +1081,9 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
             seg_next = row * sg.per_row + seg_col;
             seg_blk = (row * sg.mcu_cols + seg_col * kSegMcus) * 6u;
         }
-        if (__ballot(alive) != 0ull) fast_open_at(win, alive ? (s.t + 1u) >> 5 : 0u);
-        while (__ballot(alive) != 0ull) {
+        if (__ballot(alive) != 0ull) {
+        fast_open_at(win, alive ? (s.t + 1u) >> 5 : 0u);
+        do {   // (bottom-tested, as in amv_huffman_fast_kernel)
             if (alive) fast_service(win, (s.t + 1u) >> 5);
             if ((s.rp8 >> 8) - flushed >= kFlush) {
                 stage_flush<kFlush>(stage, rec, flushed, out.cap_rec);
@@ -1111,6 +1117,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
                     seg_col = last ? 0u : seg_col + 1u;
                 }
             }
+        } while (__ballot(alive) != 0ull);
         }
         const uint32_t recpos = s.rp8 >> 8;
         {   // what is still staged leaves padded to a whole piece with records no block owns
