@@ -94,35 +94,74 @@ __device__ __forceinline__ uint32_t seg_excl_sum(uint32_t v, uint32_t sub, uint3
     return x - v;
 }
 
+// inclusive prefix sum over the wave's 64 lanes in six DPP adds (no LDS round trips: the shuffle form above is a
+// chain of six ds_bpermute, and the unstuffer does one scan per 256 bytes, each waiting for the one before)
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// lane i gets lane i - 1's value (lane 0: 0)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);   // wave_shr:1
+}
+
 }  // namespace
 
 // =============================================================================================
 // unstuffing
 // =============================================================================================
 
+// A byte is dropped when an odd run of FF bytes precedes it (ReadByte swallows the byte behind every FF it delivers).
+// Per 256-byte tile a lane takes one word: FF flags of its four bytes (SWAR: three instructions + a multiply that
+// gathers them), the neighbour's last flag through a lane shift; unless the wave sees two FF bytes in a row (never in a
+// valid stream) "dropped" is simply "the byte before is FF", else the general rule with an eight-byte look-back runs.
+// The kept bytes are packed with one byte permute (selector by keep mask from a 16-entry LDS table), shifted to their
+// place in the output and OR-ed into a ring of words in LDS; whole words then leave as one coalesced dword store per
+// tile (byte stores, one per kept byte, cost the kernel half its time).
 __global__ __launch_bounds__(256) void amv_unstuff_kernel(
     const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offs,
     const uint32_t* __restrict__ lens, uint32_t n, uint32_t cap_words, uint32_t* __restrict__ ws,
     uint32_t* __restrict__ ws_bytes, uint32_t* __restrict__ retry_list, uint32_t* __restrict__ retry_count) {
+    constexpr uint32_t kRing = 128;                 // output words being put together, per wave (a tile adds <= 64)
+    __shared__ uint32_t s_words[4][kRing];
+    __shared__ uint32_t s_pack[16];                 // keep mask -> selector that packs the kept bytes low, zeros above
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t frame = blockIdx.x * 4u + wave;
+    if (threadIdx.x < 16u) {
+        uint32_t sel = 0, k = 0;
+        for (uint32_t j = 0; j < 4u; ++j)
+            if (threadIdx.x & (1u << j)) sel |= j << (8u * k++);
+        for (; k < 4u; ++k) sel |= 0x0cu << (8u * k);
+        s_pack[threadIdx.x] = sel;
+    }
+    uint32_t* const ring = s_words[wave];
+    ring[lane] = 0u;
+    ring[lane + kWave] = 0u;
+    __syncthreads();
     if (frame >= n) return;
     uint64_t off = offs[frame];
     uint32_t len = lens[frame];
     if (off > blob_bytes) { off = blob_bytes; len = 0; }
     if ((uint64_t)len > blob_bytes - off) len = (uint32_t)(blob_bytes - off);
-    uint8_t* out = reinterpret_cast<uint8_t*>(ws + (uint64_t)frame * cap_words);
+    uint32_t* const out = ws + (uint64_t)frame * cap_words;
 
     const uint32_t mis = (uint32_t)(off & 3u);
     const uint8_t* base = blob + (off - mis);
     const uint64_t guard = blob_bytes - (off - mis);
     const uint32_t first = mis + 2u, end = mis + len;      // data bytes [first, end), relative to base
     bool retry = len > 2u && (len - 2u) > cap_words * 4u;   // does not fit its window
-    uint32_t total = 0;
+    uint32_t total = 0, flushed = 0;                        // bytes kept so far; whole words that have left
     if (!retry) {
         uint32_t carry = 0;   // FF flags of the eight bytes in front of the tile, nearest first
         // tiles of 64 words, eight at a time: the eight loads go out together, so a frame costs two or three trips
-        // to memory instead of one per tile (the kernel does little else than wait for them)
+        // to memory instead of one per tile
         constexpr uint32_t kBurst = 8;
         for (uint32_t b0 = 0; b0 * 4u < end && !retry; b0 += kBurst * kWave) {
             uint32_t wv[kBurst];
@@ -143,42 +182,75 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
             if (t0 * 4u >= end) break;
             const uint32_t wi = t0 + lane;
             const uint32_t w = wv[q];
-            // which of this lane's four bytes are FF (bytes in front of the data never count)
-            uint32_t ff = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j)
-                ff |= (wi * 4u + j >= first && ((w >> (8u * j)) & 0xffu) == 0xffu ? 1u : 0u) << j;
+            // which of this lane's four bytes are FF: bit 7 of a byte of t is set iff the byte is FF; the multiply
+            // gathers bits 7, 15, 23, 31 into four neighbouring bits
+            const uint32_t t = ((w & 0x7f7f7f7fu) + 0x01010101u) & w & 0x80808080u;
+            uint32_t ff = (((t >> 7) * 0x00204081u) >> 21) & 15u;
+            uint32_t valid = 15u;                                         // bytes inside [first, end)
+            if (t0 == 0u || (t0 + kWave) * 4u > end) {                    // (wave-uniform) the chunk's first and last tile
+                const uint32_t p0 = wi * 4u;
+                const uint32_t lo = first > p0 ? min(first - p0, 4u) : 0u, hi = end > p0 ? min(end - p0, 4u) : 0u;
+                valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                ff &= ~((1u << lo) - 1u);                                 // bytes in front of the data never count
+            }
             // the flags of the eight bytes in front of this word, NEAREST FIRST (bit i: the byte i + 1 places back)
             const uint32_t rev = __brev(ff) >> 28;                       // this word's flags, last byte in bit 0
-            uint32_t prev = __shfl_up(rev, 1) | (__shfl_up(rev, 2) << 4);
-            if (lane == 0) prev = carry;                                  // the eight bytes in front of the tile
-            if (lane == 1) prev = (prev & 0xfu) | ((carry & 0xfu) << 4);
-            carry = __shfl(rev, kWave - 1) | (__shfl(rev, kWave - 2) << 4);
-            uint32_t keep = 0, cnt = 0;
-            bool deep = false;
+            uint32_t prev1 = wave_shr1(rev);
+            if (lane == 0) prev1 = carry & 0xfu;
+            // two FF bytes in a row anywhere in the tile (or across its front edge)?
+            const uint32_t before = (ff << 1) | (prev1 & 1u);            // bit j: the byte in front of byte j is FF
+            uint32_t keep, cnt;
+            if (!__any((ff & before) != 0u || (lane == 0 && (carry & 3u) == 3u))) {
+                keep = valid & ~before;
+                cnt = (uint32_t)__builtin_popcount(keep);
+                carry = __builtin_amdgcn_readlane(rev, kWave - 1) | (__builtin_amdgcn_readlane(rev, kWave - 2) << 4);
+            } else {   // the general rule: a byte is dropped iff an odd run of FF bytes precedes it
+                uint32_t prev = prev1 | (__shfl_up(rev, 2) << 4);
+                if (lane == 0) prev = carry;                                  // the eight bytes in front of the tile
+                if (lane == 1) prev = (prev & 0xfu) | ((carry & 0xfu) << 4);
+                carry = __builtin_amdgcn_readlane(rev, kWave - 1) | (__builtin_amdgcn_readlane(rev, kWave - 2) << 4);
+                keep = 0;
+                cnt = 0;
+                bool deep = false;
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t pos = wi * 4u + j;
-                // flags in front of byte j, nearest first: this word's bytes j-1 .. 0, then `prev`
-                const uint32_t own = j == 0u ? 0u : __brev(ff & ((1u << j) - 1u)) >> (32u - j);
-                const uint32_t seq = own | (prev << j);                  // 8 + j flags
-                const uint32_t run = (uint32_t)__builtin_ctz(~seq);      // FF bytes immediately in front of pos
-                deep = deep || run >= 8u + j;                             // the run may reach past the look-back
-                const bool kept = pos >= first && pos < end && !(run & 1u);   // dropped iff an odd run of FF precedes it
-                keep |= (kept ? 1u : 0u) << j;
-                cnt += kept ? 1u : 0u;
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    // flags in front of byte j, nearest first: this word's bytes j-1 .. 0, then `prev`
+                    const uint32_t own = j == 0u ? 0u : __brev(ff & ((1u << j) - 1u)) >> (32u - j);
+                    const uint32_t seq = own | (prev << j);                  // 8 + j flags
+                    const uint32_t run = (uint32_t)__builtin_ctz(~seq);      // FF bytes immediately in front of the byte
+                    deep = deep || run >= 8u + j;                             // the run may reach past the look-back
+                    const bool kept = (valid >> j & 1u) && !(run & 1u);
+                    keep |= (kept ? 1u : 0u) << j;
+                    cnt += kept ? 1u : 0u;
+                }
+                if (__any(deep)) { retry = true; break; }
             }
-            if (__any(deep)) { retry = true; break; }
-            uint32_t tile_total;
-            uint32_t d = total + seg_excl_sum<kWave>(cnt, lane, tile_total);
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j)
-                if (keep & (1u << j)) { out[d ^ 3u] = (uint8_t)(w >> (8u * j)); ++d; }   // big-endian inside the word
+            const uint32_t upto = wave_incl_sum(cnt);
+            const uint32_t tile_total = __builtin_amdgcn_readlane(upto, kWave - 1);
+            const uint32_t d = total + upto - cnt;                                    // where this lane's kept bytes go
+            // kept bytes, packed low, in stream order -> their place in output words d / 4 and d / 4 + 1
+            const uint32_t packed = __builtin_amdgcn_perm(0u, w, s_pack[keep]);
+            const uint32_t sh = (d & 3u) * 8u;
+            const uint32_t wd = d >> 2;
+            atomicOr(&ring[wd & (kRing - 1u)], packed << sh);
+            atomicOr(&ring[(wd + 1u) & (kRing - 1u)], (packed >> 1) >> (31u - sh));
             total += tile_total;
+            // whole words leave, big-endian inside the word
+            const uint32_t whole = (total >> 2) - flushed;
+            if (lane < whole) {
+                const uint32_t x = flushed + lane;
+                const uint32_t v = ring[x & (kRing - 1u)];
+                ring[x & (kRing - 1u)] = 0u;
+                out[x] = __builtin_amdgcn_perm(0u, v, 0x00010203u);
+            }
+            flushed += whole;
             }
         }
-        // zero the tail up to the next 16-byte boundary: the decoder copies whole 16-byte pieces
-        if (!retry && lane < ((16u - (total & 15u)) & 15u)) out[(total + lane) ^ 3u] = 0;
+        // the last, partial word and zeros up to the next 16-byte boundary: the decoder copies whole 16-byte pieces
+        if (!retry) {
+            const uint32_t x = flushed + lane;
+            if (x < ((total + 15u) & ~15u) >> 2) out[x] = __builtin_amdgcn_perm(0u, ring[x & (kRing - 1u)], 0x00010203u);
+        }
     }
     if (lane == 0) {
         ws_bytes[frame] = retry ? kNever : total;
