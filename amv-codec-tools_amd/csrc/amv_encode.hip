@@ -125,7 +125,32 @@ __global__ __launch_bounds__(kWave) void amv_forward_kernel(
     const Weights k = is_bgr ? Weights{117, 306, 512, -173, -83, 512} : Weights{306, 117, -173, 512, 512, -83};
 
     const uint32_t d4 = cnt * 4u, inv = (65536u + d4 - 1u) / d4;   // t / d4 == (t * inv) >> 16 for t < 8 * d4 <= 320
-    for (uint32_t t = lane; t < 8u * d4; t += kWave) {
+    // A lane takes up to kTrips 4x2-pixel patches.  Their pixels are requested all at once (a loop that loaded and
+    // converted a patch per trip waited for memory five times in a row); the conversion follows.
+    constexpr int kTrips = 5;                                      // 8 * d4 <= 320 = 5 * 64
+    Px12 ra[kTrips], rb[kTrips];
+    if (!kYuv) {
+#pragma unroll
+        for (int it = 0; it < kTrips; ++it) {
+            const uint32_t t = lane + (uint32_t)it * kWave;
+            ra[it] = rb[it] = Px12{{0u, 0u, 0u}};
+            if (t < 8u * d4) {
+                const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
+                const uint32_t k0 = my * 16u + 2u * i2;
+                const bool inside = k0 < h;
+                const uint32_t row_a = inside ? h - 1u - k0 : 1u, row_b = inside ? h - 2u - k0 : 0u;
+                const uint32_t c = m0 * 16u + 4u * p;
+                if (c + 3u < w) {
+                    ra[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_a * pix_stride + c * 3u);
+                    rb[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_b * pix_stride + c * 3u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kTrips; ++it) {
+        const uint32_t t = lane + (uint32_t)it * kWave;
+        if (t >= 8u * d4) break;
         const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
         const uint32_t k0 = my * 16u + 2u * i2;                    // bitstream rows k0, k0 + 1
         const bool inside = k0 < h;                                // h is even
@@ -152,8 +177,8 @@ __global__ __launch_bounds__(kWave) void amv_forward_kernel(
             }
         } else if (c + 3u < w) {
             int a[12], b[12];
-            unpack12(*reinterpret_cast<const Px12*>(pa + c * 3u), a);
-            unpack12(*reinterpret_cast<const Px12*>(pb + c * 3u), b);
+            unpack12(ra[it], a);
+            unpack12(rb[it], b);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 ya[q] = luma(k, a[3 * q], a[3 * q + 1], a[3 * q + 2]);
