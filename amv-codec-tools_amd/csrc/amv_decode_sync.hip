@@ -119,17 +119,20 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
 // =============================================================================================
 
 // A byte is dropped when an odd run of FF bytes precedes it (ReadByte swallows the byte behind every FF it delivers).
-// Per 256-byte tile a lane takes one word: FF flags of its four bytes (SWAR: three instructions + a multiply that
+// A lane takes 16 bytes of a 1 KB tile: FF flags of its bytes (SWAR: three instructions per word + a multiply that
 // gathers them), the neighbour's last flag through a lane shift; unless the wave sees two FF bytes in a row (never in a
-// valid stream) "dropped" is simply "the byte before is FF", else the general rule with an eight-byte look-back runs.
-// The kept bytes are packed with one byte permute (selector by keep mask from a 16-entry LDS table), shifted to their
-// place in the output and OR-ed into a ring of words in LDS; whole words then leave as one coalesced dword store per
-// tile (byte stores, one per kept byte, cost the kernel half its time).
+// valid stream) "dropped" is simply "the byte before is FF", else the general rule runs with the lane's and its
+// neighbour's flags as look-back.  One six-step DPP prefix sum per tile says where a lane's kept bytes go; each word's
+// kept bytes are packed with one byte permute (selector by keep mask from a 16-entry LDS table), shifted to their
+// place and OR-ed into a ring of words in LDS; whole words then leave as coalesced dword stores.
+// (One word per lane and tile, a shuffle-based prefix sum and a byte store per kept byte took 0.47 ms per 160 000
+// frames; the same with DPP and LDS words 0.34.)
 __global__ __launch_bounds__(256) void amv_unstuff_kernel(
     const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offs,
     const uint32_t* __restrict__ lens, uint32_t n, uint32_t cap_words, uint32_t* __restrict__ ws,
     uint32_t* __restrict__ ws_bytes, uint32_t* __restrict__ retry_list, uint32_t* __restrict__ retry_count) {
-    constexpr uint32_t kRing = 128;                 // output words being put together, per wave (a tile adds <= 64)
+    constexpr uint32_t kRing = 512;                 // output words being put together, per wave (a tile adds <= 256)
+    constexpr uint32_t kTile = kWave * 16u;         // bytes
     __shared__ uint32_t s_words[4][kRing];
     __shared__ uint32_t s_pack[16];                 // keep mask -> selector that packs the kept bytes low, zeros above
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -142,8 +145,7 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
         s_pack[threadIdx.x] = sel;
     }
     uint32_t* const ring = s_words[wave];
-    ring[lane] = 0u;
-    ring[lane + kWave] = 0u;
+    for (uint32_t i = lane; i < kRing; i += kWave) ring[i] = 0u;
     __syncthreads();
     if (frame >= n) return;
     uint64_t off = offs[frame];
@@ -159,91 +161,90 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
     bool retry = len > 2u && (len - 2u) > cap_words * 4u;   // does not fit its window
     uint32_t total = 0, flushed = 0;                        // bytes kept so far; whole words that have left
     if (!retry) {
-        uint32_t carry = 0;   // FF flags of the eight bytes in front of the tile, nearest first
-        // tiles of 64 words, eight at a time: the eight loads go out together, so a frame costs two or three trips
-        // to memory instead of one per tile
-        constexpr uint32_t kBurst = 8;
-        for (uint32_t b0 = 0; b0 * 4u < end && !retry; b0 += kBurst * kWave) {
-            uint32_t wv[kBurst];
+        uint32_t carry = 0;   // FF flags of the 16 bytes in front of the tile (bit 15: the byte right in front)
+        // four tiles' loads go out together, so a frame costs one or two trips to memory
+        constexpr uint32_t kBurst = 4;
+        for (uint32_t b0 = 0; b0 < end && !retry; b0 += kBurst * kTile) {
+            uint4 wv[kBurst];
 #pragma unroll
             for (uint32_t q = 0; q < kBurst; ++q) {
-                const uint32_t wi = b0 + q * kWave + lane;
-                uint32_t w = 0;
-                if (wi * 4u < end) {
-                    const uint64_t bo = (uint64_t)wi * 4u;
-                    if (bo + 4u <= guard) w = *reinterpret_cast<const uint32_t*>(base + bo);
-                    else for (uint32_t j = 0; j < 4u; ++j) if (bo + j < guard) w |= (uint32_t)base[bo + j] << (8u * j);
+                const uint64_t bo = (uint64_t)b0 + q * kTile + lane * 16u;
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                if (bo < end) {
+                    if (bo + 16u <= guard) {
+                        struct __attribute__((packed, aligned(4))) W4 { uint32_t x[4]; };
+                        const W4 v = *reinterpret_cast<const W4*>(base + bo);
+                        w[0] = v.x[0]; w[1] = v.x[1]; w[2] = v.x[2]; w[3] = v.x[3];
+                    } else {
+                        for (uint32_t j = 0; j < 16u; ++j) if (bo + j < guard) w[j >> 2] |= (uint32_t)base[bo + j] << (8u * (j & 3u));
+                    }
                 }
-                wv[q] = w;
+                wv[q] = make_uint4(w[0], w[1], w[2], w[3]);
             }
 #pragma unroll
             for (uint32_t q = 0; q < kBurst; ++q) {
-            const uint32_t t0 = b0 + q * kWave;
-            if (t0 * 4u >= end) break;
-            const uint32_t wi = t0 + lane;
-            const uint32_t w = wv[q];
-            // which of this lane's four bytes are FF: bit 7 of a byte of t is set iff the byte is FF; the multiply
+            const uint32_t t0 = b0 + q * kTile;            // the tile's first byte
+            if (t0 >= end) break;
+            const uint32_t p0 = t0 + lane * 16u;           // this lane's first byte
+            const uint32_t w[4] = {wv[q].x, wv[q].y, wv[q].z, wv[q].w};
+            // which of this lane's sixteen bytes are FF: bit 7 of a byte of t is set iff the byte is FF; the multiply
             // gathers bits 7, 15, 23, 31 into four neighbouring bits
-            const uint32_t t = ((w & 0x7f7f7f7fu) + 0x01010101u) & w & 0x80808080u;
-            uint32_t ff = (((t >> 7) * 0x00204081u) >> 21) & 15u;
-            uint32_t valid = 15u;                                         // bytes inside [first, end)
-            if (t0 == 0u || (t0 + kWave) * 4u > end) {                    // (wave-uniform) the chunk's first and last tile
-                const uint32_t p0 = wi * 4u;
-                const uint32_t lo = first > p0 ? min(first - p0, 4u) : 0u, hi = end > p0 ? min(end - p0, 4u) : 0u;
+            uint32_t ff = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t t = ((w[j] & 0x7f7f7f7fu) + 0x01010101u) & w[j] & 0x80808080u;
+                ff |= ((((t >> 7) * 0x00204081u) >> 21) & 15u) << (4u * j);
+            }
+            uint32_t valid = 0xffffu;                                     // bytes inside [first, end)
+            if (t0 == 0u || t0 + kTile > end) {                           // (wave-uniform) the chunk's first and last tile
+                const uint32_t lo = first > p0 ? min(first - p0, 16u) : 0u, hi = end > p0 ? min(end - p0, 16u) : 0u;
                 valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
                 ff &= ~((1u << lo) - 1u);                                 // bytes in front of the data never count
             }
-            // the flags of the eight bytes in front of this word, NEAREST FIRST (bit i: the byte i + 1 places back)
-            const uint32_t rev = __brev(ff) >> 28;                       // this word's flags, last byte in bit 0
-            uint32_t prev1 = wave_shr1(rev);
-            if (lane == 0) prev1 = carry & 0xfu;
+            uint32_t back = wave_shr1(ff);                                // the 16 flags in front of this lane's bytes
+            if (lane == 0) back = carry;
+            const uint32_t before = ((ff << 1) | (back >> 15)) & 0xffffu; // bit j: the byte in front of byte j is FF
+            uint32_t keep;
             // two FF bytes in a row anywhere in the tile (or across its front edge)?
-            const uint32_t before = (ff << 1) | (prev1 & 1u);            // bit j: the byte in front of byte j is FF
-            uint32_t keep, cnt;
-            if (!__any((ff & before) != 0u || (lane == 0 && (carry & 3u) == 3u))) {
+            if (!__any((ff & before) != 0u || (lane == 0 && (carry >> 14) == 3u))) {
                 keep = valid & ~before;
-                cnt = (uint32_t)__builtin_popcount(keep);
-                carry = __builtin_amdgcn_readlane(rev, kWave - 1) | (__builtin_amdgcn_readlane(rev, kWave - 2) << 4);
             } else {   // the general rule: a byte is dropped iff an odd run of FF bytes precedes it
-                uint32_t prev = prev1 | (__shfl_up(rev, 2) << 4);
-                if (lane == 0) prev = carry;                                  // the eight bytes in front of the tile
-                if (lane == 1) prev = (prev & 0xfu) | ((carry & 0xfu) << 4);
-                carry = __builtin_amdgcn_readlane(rev, kWave - 1) | (__builtin_amdgcn_readlane(rev, kWave - 2) << 4);
+                const uint32_t hist = back | (ff << 16);                  // byte j of this lane at bit 16 + j
                 keep = 0;
-                cnt = 0;
                 bool deep = false;
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) {
-                    // flags in front of byte j, nearest first: this word's bytes j-1 .. 0, then `prev`
-                    const uint32_t own = j == 0u ? 0u : __brev(ff & ((1u << j) - 1u)) >> (32u - j);
-                    const uint32_t seq = own | (prev << j);                  // 8 + j flags
-                    const uint32_t run = (uint32_t)__builtin_ctz(~seq);      // FF bytes immediately in front of the byte
-                    deep = deep || run >= 8u + j;                             // the run may reach past the look-back
-                    const bool kept = (valid >> j & 1u) && !(run & 1u);
-                    keep |= (kept ? 1u : 0u) << j;
-                    cnt += kept ? 1u : 0u;
+                for (uint32_t j = 0; j < 16u; ++j) {
+                    const uint32_t run = (uint32_t)__builtin_clz(~(hist << (16u - j)) | 1u);   // FF bytes immediately in front of byte j (<= 16 + j)
+                    deep = deep || run >= 16u + j;                        // the run may reach past the look-back
+                    keep |= (!(run & 1u) ? 1u : 0u) << j;
                 }
+                keep &= valid;
                 if (__any(deep)) { retry = true; break; }
             }
+            carry = __builtin_amdgcn_readlane(ff, kWave - 1);
+            const uint32_t cnt = (uint32_t)__builtin_popcount(keep);
             const uint32_t upto = wave_incl_sum(cnt);
             const uint32_t tile_total = __builtin_amdgcn_readlane(upto, kWave - 1);
-            const uint32_t d = total + upto - cnt;                                    // where this lane's kept bytes go
-            // kept bytes, packed low, in stream order -> their place in output words d / 4 and d / 4 + 1
-            const uint32_t packed = __builtin_amdgcn_perm(0u, w, s_pack[keep]);
-            const uint32_t sh = (d & 3u) * 8u;
-            const uint32_t wd = d >> 2;
-            atomicOr(&ring[wd & (kRing - 1u)], packed << sh);
-            atomicOr(&ring[(wd + 1u) & (kRing - 1u)], (packed >> 1) >> (31u - sh));
+            uint32_t d = total + upto - cnt;                              // where this lane's kept bytes go
+            // every word's kept bytes, packed low, in stream order -> their place in output words d / 4 and d / 4 + 1
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t k4 = (keep >> (4u * j)) & 15u;
+                const uint32_t packed = __builtin_amdgcn_perm(0u, w[j], s_pack[k4]);
+                const uint32_t sh = (d & 3u) * 8u, wd = d >> 2;
+                atomicOr(&ring[wd & (kRing - 1u)], packed << sh);
+                atomicOr(&ring[(wd + 1u) & (kRing - 1u)], (packed >> 1) >> (31u - sh));
+                d += (uint32_t)__builtin_popcount(k4);
+            }
             total += tile_total;
             // whole words leave, big-endian inside the word
-            const uint32_t whole = (total >> 2) - flushed;
-            if (lane < whole) {
-                const uint32_t x = flushed + lane;
+            const uint32_t whole = total >> 2;
+            for (uint32_t x = flushed + lane; x < whole; x += kWave) {
                 const uint32_t v = ring[x & (kRing - 1u)];
                 ring[x & (kRing - 1u)] = 0u;
                 out[x] = __builtin_amdgcn_perm(0u, v, 0x00010203u);
             }
-            flushed += whole;
+            flushed = whole;
             }
         }
         // the last, partial word and zeros up to the next 16-byte boundary: the decoder copies whole 16-byte pieces

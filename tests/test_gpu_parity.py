@@ -1175,7 +1175,8 @@ def test_one_lane_per_frame_walk(pkg, orc, amv1):
                     b[int(rng.integers(2, len(b) - 2))] ^= 1 << int(rng.integers(0, 8))
                 chunks.append(bytes(b))
             c = chunks[1]
-            chunks.append(c[:12] + b"\xff" * 12 + c[12:])   # a run of FF bytes past the unstuffer's look-back: serial kernel
+            chunks.append(c[:12] + b"\xff" * 40 + c[12:])   # a run of FF bytes past the unstuffer's look-back: serial kernel
+            chunks.append(c[:12] + b"\xff" * 5 + c[12:])    # a short run: the unstuffer's general rule
             for flags in (0, 1):
                 got, st = _gpu_decode(one, chunks, w, h, flags, pad_front=flags)
                 want, wst = _oracle_decode(orc, chunks, w, h, flags)
