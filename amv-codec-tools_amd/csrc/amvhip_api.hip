@@ -1199,7 +1199,7 @@ extern "C" uint32_t amvhip_jpeg_header(uint16_t height, uint16_t width, uint8_t*
 
 extern "C" const char* amvhip_kernel_name(int kernel) {
     switch (kernel) {
-        case AMVHIP_K_HUFFMAN: return "amv_huffman_sync_kernel";
+        case AMVHIP_K_HUFFMAN: return "amv_huffman_fast_kernel|sync2|sync";   // whichever the batch got (huffman_sync_lanes; dense form: sync)
         case AMVHIP_K_UNSTUFF: return "amv_unstuff_kernel";
         case AMVHIP_K_HUFFMAN_SERIAL: return "amv_huffman_kernel";
         case AMVHIP_K_RECON: return "amv_reconstruct_kernel";
