@@ -47,7 +47,6 @@ struct amvhip_ctx {
     hipStream_t front = nullptr, back = nullptr;
     hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done[2] = {nullptr, nullptr};
     uint64_t submitted = 0, collected = 0;
-    bool dense_intermediate = false;   // AMVHIP_DENSE=1: dense coefficient lines between the decode stages (experiments)
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
     uint32_t cus = 256;   // compute units of the device
     bool want_stats = false;
@@ -270,7 +269,6 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
     if (hipSetDevice(device) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = (uint32_t)cus;
-    if (const char* e = getenv("AMVHIP_DENSE")) c->dense_intermediate = atoi(e) != 0;
     if (const char* e = getenv("AMVHIP_SYNC_LANES")) {   // tuning knob: lanes per frame of the entropy kernel
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->sync_lanes = v;
