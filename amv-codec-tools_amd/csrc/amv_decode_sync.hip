@@ -1356,13 +1356,19 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     if (wanted == 1 || wanted == 2 || wanted == 4 || wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
     if (n >= cus * 230u) return 1;
     if (n >= cus * 150u) return 2;
-    int full = 8;                                  // chip full: 8 lanes up to 320x240 (32 000 frames: 2.54 ms against 2.67 with 16)
+    int full = 8;                                  // chip full: 8 lanes up to 320x240 (32 000 frames: 1.90 ms against 1.84 with 16)
     while (full < 64 && (uint64_t)full * 25000u <= pixels) full *= 2;
     const uint64_t waves = (uint64_t)cus * 10u;
-    int fill = 8;                                  // small batch: as many lanes as keep every task resident
+    int fill = 8;                                  // small batch: as many lanes as keep every task resident ...
     if (n <= waves) fill = 64;
-    else if (n <= 2u * waves) fill = 32;
+    else if (2u * n <= 3u * waves) fill = 32;
     else if (n <= 4u * waves) fill = 16;
+    // ... but no share much shorter than the synchronisation length, or the re-walk rounds take over (160x120, lanes
+    // 16 / 32 / 64: 1 250 frames 0.32 / 0.27 / 0.33 ms with 2.5 / 5.1 / 10.3 rounds, 2 500: 0.37 / 0.34 / 0.46,
+    // 5 000: 0.38 / 0.41 / 0.56; 320x240, 2 000 frames: 0.51 / 0.35 / 0.32)
+    int cap = 8;
+    while (cap < 64 && (uint64_t)cap * 2u * 500u <= pixels) cap *= 2;
+    if (fill > cap) fill = cap;
     return fill > full ? fill : full;
 }
 
