@@ -532,8 +532,11 @@ extern "C" int amvhip_decode_submit_dev(amvhip_ctx* c, const uint8_t* d_blob, ui
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->submitted - c->collected >= 2) return fail(c, AMVHIP_ERR_ARG, "decode_submit: two batches are in flight, collect one first");
     if (!c->front) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->front, hipStreamNonBlocking));
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->back, hipStreamNonBlocking));
+        // the entropy stage's few large workgroups (127 KB of LDS) ahead of the reconstruction's many small ones
+        int least = 0, greatest = 0;
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->front, hipStreamNonBlocking, greatest));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->back, hipStreamNonBlocking, least));
         for (hipEvent_t* e : {&c->ev_in, &c->ev_front, &c->ev_done[0], &c->ev_done[1]})
             HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
