@@ -1246,3 +1246,26 @@ def test_decode_submit_collect_pipeline(pkg, orc, amv1):
             assert (j["st"].cpu().numpy() == wst).all() and (j["out"].cpu().numpy() == want).all()
     finally:
         ctx.close()
+
+
+def test_unstuffer_boundaries(ctx, orc):
+    """FF bytes where the unstuffer's tiles (1 KB), lanes (16 bytes) and words meet: a valid chunk with FF 00, FF FF 00,
+    FF FF FF 00 and a lone FF spliced in around those places, for every alignment of the chunk in the blob; chunks that
+    end in FF, at a tile boundary, one byte short of it -- status and pixels equal the oracle's"""
+    w, h = 160, 120
+    rng = np.random.default_rng(404)
+    base = orc.encode_frame(rng.integers(0, 256, (h, w, 3)).astype(np.uint8), w, h)   # noise: a long chunk (> 4 tiles)
+    assert len(base) > 4200
+    chunks = []
+    for splice in (b"\xff\x00", b"\xff\xff\x00", b"\xff\xff\xff\x00", b"\xff"):
+        for at in (2, 3, 13, 14, 15, 16, 17, 18, 1021, 1022, 1023, 1024, 1025, 1026, 1027, 2047, 2048, 2049, 4094, 4095, 4096):
+            chunks.append(base[:at] + splice + base[at:])
+    for cut in (1024, 1025, 1026, 1027, 1028, 2050, 4097, 4098):
+        chunks.append(base[:cut])
+        chunks.append(base[:cut - 1] + b"\xff")
+        chunks.append(base[:cut - 2] + b"\xff\xff")
+    for pad in range(4):
+        got, st = _gpu_decode(ctx, chunks, w, h, 0, pad_front=pad)
+        want, wst = _oracle_decode(orc, chunks, w, h)
+        assert (st == wst).all(), (pad, np.nonzero(st != wst)[0][:8])
+        assert (got == want).all(), pad
