@@ -47,30 +47,37 @@ __device__ __forceinline__ int coef_at(const uint32_t (&c)[32], int i) {
     return (i & 1) ? ((int)c[i >> 1] >> 16) : (int)(int16_t)(c[i >> 1] & 0xffffu);
 }
 
-// Bits of one block appended at an arbitrary bit position of the LDS string.
+// Bits appended to a bit string in LDS.  kCount: lengths only.  kShared: at an arbitrary bit position of the frame's
+// string (neighbouring blocks share words, hence the atomic OR).  kOwn: into the lane's own scratch column (word i of
+// lane l at words[i * stride]; words past `cap` are dropped: the lane then codes its blocks a second time, into the string).
+enum { kCount = 0, kShared = 1, kOwn = 2 };
 struct Emitter {
     uint32_t* words;
     uint32_t wi;        // word being filled
     uint64_t acc;       // pending bits, right aligned
     int nacc;
-    uint32_t nbits;     // total length so far (both modes)
+    uint32_t nbits;     // total length so far (every mode)
+    uint32_t stride, cap;   // kOwn
 };
 
-template <bool kEmit>
+template <int kMode>
 __device__ __forceinline__ void put(Emitter& e, uint32_t entry, int extra_bits, uint32_t extra) {
     const int len = (int)(entry >> 16) + extra_bits;
     e.nbits += (uint32_t)len;
-    if (!kEmit) return;
+    if (kMode == kCount) return;
     e.acc = (e.acc << len) | ((uint64_t)(entry & 0xffffu) << extra_bits) | extra;
     e.nacc += len;
     if (e.nacc >= 32) {
         e.nacc -= 32;
-        atomicOr(&e.words[e.wi++], (uint32_t)(e.acc >> e.nacc));
+        const uint32_t word = (uint32_t)(e.acc >> e.nacc);
+        if (kMode == kShared) atomicOr(&e.words[e.wi], word);
+        else if (e.wi < e.cap) e.words[e.wi * e.stride] = word;
+        ++e.wi;
     }
 }
 
 // encode_block (mjpegenc.c:379-435) over a block held in registers; prev_dc = the component's predictor
-template <bool kEmit>
+template <int kEmit>
 __device__ __forceinline__ void code_block(Emitter& e, const uint32_t (&c)[32], int prev_dc, const uint32_t* dcbook,
                                            const uint32_t* acbook) {
     int diff = coef_at(c, 0) - prev_dc;
@@ -132,7 +139,7 @@ __device__ __forceinline__ uint32_t team_excl_sum(uint32_t v, uint32_t tl, uint3
     return x + before;
 }
 
-// dynamic LDS: [ code book 4 KB | per team: bits[cap_words] | block lengths[blocks_cap] | 8 words of partial sums ]
+// dynamic LDS: [ code book 4 KB | per team: bits[cap_words] | block lengths[blocks_cap] | 8 words of partial sums | 16 words of scratch per lane ]
 template <int kTeam>
 __global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
     const int16_t* __restrict__ coef, uint32_t n, uint32_t blocks_per_frame, uint32_t blocks_cap,
@@ -148,13 +155,18 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
     const uint32_t frame = kTeam == 1 ? blockIdx.x * (blockDim.x >> 6) + team : blockIdx.x;
     if (frame >= n) return;                            // kTeam > 1: the whole workgroup leaves
 
-    uint32_t* bits = reinterpret_cast<uint32_t*>(s_mem + 4096u + team * (cap_words + blocks_cap + 8u) * 4u);
+    constexpr uint32_t kOwnWords = 16;                 // a lane's scratch: 512 bits for its ~4 blocks (41 bits a block on the bench stream)
+    uint32_t* bits = reinterpret_cast<uint32_t*>(s_mem + 4096u + team * (cap_words + blocks_cap + 8u + kLanes * kOwnWords) * 4u);
     uint32_t* blen = bits + cap_words;
     uint32_t* s_part = blen + blocks_cap;
+    uint32_t* own = s_part + 8u + tl;                  // word i of this lane's scratch at own[i * kLanes]: the bank follows the lane
     const int16_t* fcoef = coef + (uint64_t)frame * blocks_per_frame * 64u;
     for (uint32_t i = tl; i < cap_words; i += kLanes) bits[i] = 0u;
 
-    // ---- 1. code length of every block
+    // ---- 1. every block is coded once, into its lane's scratch (blocks lane, lane + team size, ... one behind the
+    // other), and its length noted.  (The second walk over the coefficients that put the bits in place once the
+    // positions were known cost as much as this one: 0.42 of the kernel's 0.92 ms.)
+    Emitter mine{own, 0u, 0ull, 0, 0u, kLanes, kOwnWords};
     for (uint32_t b = tl; b < blocks_per_frame; b += kLanes) {
         uint32_t c[32];
         const uint4* src = reinterpret_cast<const uint4*>(fcoef + (uint64_t)b * 64u);
@@ -163,10 +175,12 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
         const int pb = pred_block(b);
         const int prev = pb >= 0 ? (int)fcoef[(uint64_t)pb * 64u] : 0;
         const uint32_t cls = (b % 6u) >= 4u ? 1u : 0u;
-        Emitter e{nullptr, 0u, 0ull, 0, 0u};
-        code_block<false>(e, c, prev, book + cls * 256u, book + (2u + cls) * 256u);
-        blen[b] = e.nbits;
+        const uint32_t before = mine.nbits;
+        code_block<kOwn>(mine, c, prev, book + cls * 256u, book + (2u + cls) * 256u);
+        blen[b] = mine.nbits - before;
     }
+    if (mine.nacc && mine.wi < kOwnWords) own[mine.wi * kLanes] = (uint32_t)(mine.acc << (32 - mine.nacc));
+    const bool spilled = mine.nbits > kOwnWords * 32u;   // more bits than the scratch holds: this lane walks its blocks again
     team_sync<kTeam>();
 
     // ---- 2. first bit of every block: each lane owns a run of consecutive blocks for the scan
@@ -184,19 +198,37 @@ __global__ __launch_bounds__(kWave* kMaxWaves) void amv_pack_wave_kernel(
         return;
     }
 
-    // ---- 3. the bits
-    for (uint32_t b = tl; b < blocks_per_frame; b += kLanes) {
-        uint32_t c[32];
-        const uint4* src = reinterpret_cast<const uint4*>(fcoef + (uint64_t)b * 64u);
+    // ---- 3. the bits go to their place: a copy out of the scratch, 32 bits at a time ...
+    if (!spilled) {
+        uint32_t from = 0;                             // bit cursor in the scratch
+        for (uint32_t b = tl; b < blocks_per_frame; b += kLanes) {
+            uint32_t pos = blen[b];
+            uint32_t left = (b + 1u < blocks_per_frame ? blen[b + 1u] : total_bits) - pos;
+            while (left) {
+                const uint32_t take = min(left, 32u);
+                // `take` bits of the scratch from bit `from` on, left-aligned
+                const uint32_t w0 = own[(from >> 5) * kLanes], w1 = (from >> 5) + 1u < kOwnWords ? own[((from >> 5) + 1u) * kLanes] : 0u;
+                const uint32_t piece = (uint32_t)((((uint64_t)w0 << 32) | w1) >> (32u - (from & 31u))) & (uint32_t)(0xffffffff00000000ull >> take);
+                // into the string at bit `pos`
+                atomicOr(&bits[pos >> 5], piece >> (pos & 31u));
+                if ((pos & 31u) + take > 32u) atomicOr(&bits[(pos >> 5) + 1u], piece << (32u - (pos & 31u)));
+                from += take; pos += take; left -= take;
+            }
+        }
+    } else {   // ... or, for a lane whose blocks did not fit its scratch, a second walk
+        for (uint32_t b = tl; b < blocks_per_frame; b += kLanes) {
+            uint32_t c[32];
+            const uint4* src = reinterpret_cast<const uint4*>(fcoef + (uint64_t)b * 64u);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const uint4 q = src[i]; c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w; }
-        const int pb = pred_block(b);
-        const int prev = pb >= 0 ? (int)fcoef[(uint64_t)pb * 64u] : 0;
-        const uint32_t cls = (b % 6u) >= 4u ? 1u : 0u;
-        const uint32_t pos = blen[b];
-        Emitter e{bits, pos >> 5, 0ull, (int)(pos & 31u), 0u};   // the word's earlier bits belong to the previous block: zeros here, OR-ed in
-        code_block<true>(e, c, prev, book + cls * 256u, book + (2u + cls) * 256u);
-        if (e.nacc) atomicOr(&e.words[e.wi], (uint32_t)(e.acc << (32 - e.nacc)));
+            for (int i = 0; i < 8; ++i) { const uint4 q = src[i]; c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w; }
+            const int pb = pred_block(b);
+            const int prev = pb >= 0 ? (int)fcoef[(uint64_t)pb * 64u] : 0;
+            const uint32_t cls = (b % 6u) >= 4u ? 1u : 0u;
+            const uint32_t pos = blen[b];
+            Emitter e{bits, pos >> 5, 0ull, (int)(pos & 31u), 0u, 1u, 0u};   // the word's earlier bits belong to the previous block: zeros here, OR-ed in
+            code_block<kShared>(e, c, prev, book + cls * 256u, book + (2u + cls) * 256u);
+            if (e.nacc) atomicOr(&e.words[e.wi], (uint32_t)(e.acc << (32 - e.nacc)));
+        }
     }
     team_sync<kTeam>();
     if (tl == 0 && (total_bits & 7u))   // ff_mjpeg_encode_stuffing: ones up to the byte boundary
@@ -238,7 +270,8 @@ bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const
     uint32_t cap_bytes = ((g.width * g.height * 2u / 5u) + 1023u) & ~1023u;
     if (cap_bytes < 2048u) cap_bytes = 2048u;
     const uint32_t blocks_cap = (g.blocks + 3u) & ~3u;
-    const uint32_t per_team = cap_bytes + blocks_cap * 4u + 32u;
+    // per team: the bit string, block lengths, partial sums, and per lane a scratch of 16 words (kOwnWords)
+    const auto per_team_of = [&](uint32_t lanes) { return cap_bytes + blocks_cap * 4u + 32u + lanes * 64u; };
     static bool raised = false;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(amv_pack_wave_kernel<1>),
@@ -249,17 +282,19 @@ bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
-    const uint32_t lds_team = 4096u + per_team;
-    if (g.blocks >= 1024u && lds_team <= 150u * 1024u) {   // large frames: eight waves per frame, one frame per workgroup (measured: 4 -> 1.17 ms, 8 -> 0.89, 16 -> 1.40 per 8 000 frames of 320x240)
+    if (g.blocks >= 1024u && 4096u + per_team_of(512u) <= 150u * 1024u) {
+        const uint32_t lds_team = 4096u + per_team_of(512u);   // large frames: eight waves per frame, one frame per workgroup (measured: 4 -> 1.17 ms, 8 -> 0.89, 16 -> 1.40 per 8 000 frames of 320x240)
         hipLaunchKernelGGL(amv_pack_wave_kernel<8>, dim3(n), dim3(kWave * 8), lds_team, s, coef, n, g.blocks, blocks_cap,
                            cap_bytes / 4u, d_img, tmp, bound, lens, retry_list, retry_count);
         return true;
     }
-    if (g.blocks >= 256u && lds_team <= 150u * 1024u) {    // medium frames: four waves per frame (160x120: 2 -> 1.36 ms, 4 -> 1.15 per 40 000 frames)
+    if (g.blocks >= 256u && 4096u + per_team_of(256u) <= 150u * 1024u) {
+        const uint32_t lds_team = 4096u + per_team_of(256u);    // medium frames: four waves per frame (160x120: 2 -> 1.36 ms, 4 -> 1.15 per 40 000 frames)
         hipLaunchKernelGGL(amv_pack_wave_kernel<4>, dim3(n), dim3(kWave * 4), lds_team, s, coef, n, g.blocks, blocks_cap,
                            cap_bytes / 4u, d_img, tmp, bound, lens, retry_list, retry_count);
         return true;
     }
+    const uint32_t per_team = per_team_of(64u);
     uint32_t waves = 4;
     while (waves > 1u && 4096u + waves * per_team > 79u * 1024u) waves >>= 1;   // aim at two workgroups per CU
     const uint32_t lds = 4096u + waves * per_team;
