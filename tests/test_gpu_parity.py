@@ -1269,3 +1269,48 @@ def test_unstuffer_boundaries(ctx, orc):
         want, wst = _oracle_decode(orc, chunks, w, h)
         assert (st == wst).all(), (pad, np.nonzero(st != wst)[0][:8])
         assert (got == want).all(), pad
+
+
+def test_every_lane_count_gives_the_same_bytes(pkg, orc):
+    """4 000 chunks, a quarter of them damaged (bit flips, truncation, runs of FF spliced in), decoded with 1, 2, 8, 16 and
+    64 lanes per frame (three different entropy kernels): identical statuses and pixels, and a sample equals the oracle's"""
+    import os
+    import torch
+    w, h, n = 160, 120, 4000
+    rng = np.random.default_rng(7)
+    base = _synth_chunks(orc, 100, w, h)
+    chunks = []
+    for i in range(n):
+        c = bytearray(base[i % 100])
+        r = rng.random()
+        if r < 0.15:
+            for _ in range(int(rng.integers(1, 4))):
+                c[int(rng.integers(2, len(c) - 2))] ^= 1 << int(rng.integers(0, 8))
+        elif r < 0.20:
+            c = c[: int(rng.integers(2, len(c)))]
+        elif r < 0.25:
+            p = int(rng.integers(2, len(c) - 2))
+            c[p:p] = b"\xff" * int(rng.integers(1, 30))
+        chunks.append(bytes(c))
+    old = os.environ.get("AMVHIP_SYNC_LANES")
+    res = {}
+    try:
+        for lanes in ("1", "2", "8", "16", "64"):
+            os.environ["AMVHIP_SYNC_LANES"] = lanes
+            one = pkg.Context(0)
+            try:
+                res[lanes] = _gpu_decode(one, chunks, w, h, 0, pad_front=int(lanes) % 4)
+            finally:
+                one.close()
+    finally:
+        if old is None:
+            os.environ.pop("AMVHIP_SYNC_LANES", None)
+        else:
+            os.environ["AMVHIP_SYNC_LANES"] = old
+    ref_out, ref_st = res["1"]
+    assert (ref_st != 0).sum() > n // 10
+    for lanes, (out, st) in res.items():
+        assert (st == ref_st).all() and (out == ref_out).all(), lanes
+    for i in rng.integers(0, n, 120):
+        want, wst, _ = orc.decode_frame(chunks[int(i)], w, h)
+        assert wst == ref_st[int(i)] and (ref_out[int(i)] == want).all(), int(i)
