@@ -401,3 +401,48 @@ def test_rgb_to_yuvj420p_matches_reference_build(orc):
             R.amvref_rgb24_to_yuvj420p(src.ctypes.data, stride, w, h, *[a.ctypes.data for a in want])
             for a, b in zip(got, want):
                 assert (a == b).all(), (w, h, kind)
+
+
+def _reference_outputs():
+    return json.load(open(os.path.join(GOLDEN, "reference_outputs.json")))
+
+
+def test_oracle_matches_reference_produced_outputs(orc, amv1):
+    """tests/golden/reference_outputs.json: hashes of what the REAL reference code produced (amvlib's AmvJpegDecode, the
+    patched FFmpeg's amv decoder, its adpcm_ima_amv encoder plain and -trellis 3) on inputs this repository can rebuild
+    from its seed -- the pin for the four slices DESIGN.md section 2 could not build here (amvlib dequant / IDCT / colour /
+    StoreBuffer at the headline geometries, the FFmpeg-compat decode as a whole frame, the ADPCM-AMV encoder, its trellis)"""
+    ref = _reference_outputs()
+    seed, basis = ref["seed"], int(ref["fnv_basis"], 16)
+    assert seed == SEED and basis == orc.FNV_BASIS
+    step = ref["amvlib_decode"]["frame_step"]
+    for c in ref["amvlib_decode"]["cases"]:
+        w, h, hh = c["w"], c["h"], basis
+        for t in range(c["n"]):
+            out, st, _ = orc.decode_frame(orc.encode_frame(orc.synth_frame(seed, step * t, w, h), w, h), w, h)
+            assert st == 0
+            hh = orc.fnv1a64(hh, out)
+        assert "%016x" % hh == c["fnv"], (w, h)
+    ff = ref["ffmpeg_decode"]
+    hh = basis
+    for chunk in amv1["video"]:
+        out, st, _ = orc.decode_frame_ffmpeg(chunk, 128, 96)
+        assert st == 0
+        hh = orc.fnv1a64(hh, out)
+    assert "%016x" % hh == ff["amv1_all_252_frames"]
+    s = ff["synth_160x120"]
+    hh = basis
+    for t in range(s["n"]):
+        chunk = orc.encode_frame(orc.synth_frame(seed, s["frame_step"] * t, s["w"], s["h"]), s["w"], s["h"])
+        hh = orc.fnv1a64(hh, orc.decode_frame_ffmpeg(chunk, s["w"], s["h"])[0])
+    assert "%016x" % hh == s["fnv"]
+    a = ref["adpcm_ima_amv_encode"]
+    fs, k = a["frame_size"], a["chunks"]
+    pcm = orc.synth_audio(seed, 0, k * fs)
+    for key in ("plain", "trellis3"):
+        idx, hh = 0, basis
+        for i in range(k):
+            x = pcm[i * fs: (i + 1) * fs]
+            chunk, idx = orc.adpcm_encode_chunk(x, idx) if key == "plain" else orc.adpcm_encode_chunk_trellis(x, idx, a[key]["trellis"])
+            hh = orc.fnv1a64(hh, np.frombuffer(chunk, np.uint8))
+        assert ("%016x" % hh, idx) == (a[key]["fnv"], a[key]["end_index"]), key
