@@ -123,6 +123,8 @@ SYMBOLS = {
     "amvhip_synth_audio_dev": (_int, [_vp, _u32, _u64, _u64, _vp, _vp]),
     "amvhip_set_entropy_mode": (_int, [_vp, _int]),
     "amvhip_entropy_stats": (_int, [_vp, _int, _vp]),
+    "amvhip_adpcm_chain_stats": (_int, [_vp, _vp]),
+    "amvhip_adpcm_quotient_table": (None, [_vp]),
     "amvhip_prof_enable": (None, [_vp, _int]),
     "amvhip_prof_reset": (None, [_vp]),
     "amvhip_prof_read": (_int, [_vp, _int, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double)]),
@@ -309,6 +311,15 @@ class Context:
         return {"frames": out[0], "rounds": out[1], "max_rounds": out[2], "waves": out[9],
                 "clocks_per_wave": {"zero": out[4] / waves, "first_walk": out[5] / waves, "sync_rounds": out[6] / waves,
                                     "write": out[7] / waves, "dc": out[8] / waves}}
+
+    def adpcm_chain_stats(self):
+        """last chained ADPCM encode: {"exhaustive": bool, "recoded": [chunks coded again in sweep 1, 2, ...]}"""
+        out = (ctypes.c_uint32 * 64)()
+        self._check(self.lib.amvhip_adpcm_chain_stats(self.h, out), "adpcm_chain_stats")
+        rec = list(out[1:63])
+        while rec and rec[-1] == 0:
+            rec.pop()
+        return {"exhaustive": bool(out[0]), "recoded": rec}
 
     # timing
     def prof_enable(self, on=True):

@@ -11,12 +11,20 @@
 // step-table lookups (LDS) and those ahead of the predictor chain, and stores the 32 samples as
 // one 64-byte run.  On encode the reference carries step_index from chunk to chunk, and the end
 // index of a chunk does depend on where it started (measured on the synthetic audio: 69 % of the
-// chunks, 8.6 distinct encoder states still alive at the end of a chunk), so guessing does not
-// work.  The chain is cut with the fact that step_index has only 89 values:
-// amv_adpcm_map_kernel runs every chunk from all 89 starts (state only, no output, one lane per
-// (chunk, start) pair), the amv_adpcm_chain_* kernels compose the 89-entry maps (256 chunks per
-// workgroup through LDS, then the workgroup maps, then back down), and the real encode runs one
-// lane per chunk from its now-known start.
+// chunks), so the chunks form one chain.  It is cut the way the entropy stage cuts a frame's bit
+// stream: every chunk is coded from a GUESSED start (the index a short state-only run over the
+// tail of the chunk before arrives at: right for 59 % of the synthetic chunks) and notes the index
+// it ends with; a chunk whose predecessor ended elsewhere than it assumed is coded again, and so
+// on while ends keep changing (amv_adpcm_guess_kernel, amv_adpcm_sweep_kernel: the lists shrink
+// by 3.7x per sweep on the synthetic audio, 1.7 encodes of work in all instead of 89).  Chunk 0
+// starts from the true index, so after k sweeps the first k chunks are final whatever the data:
+// a stream whose chain does not settle within the sweeps given (amv_adpcm_settle_kernel raises a
+// flag on the device) takes the exhaustive route instead, which needs no guess because
+// step_index has only 89 values: amv_adpcm_map_kernel runs every chunk from all 89 starts (state
+// only, one lane per (chunk, start) pair), the amv_adpcm_chain_* kernels compose the 89-entry
+// maps (256 chunks per workgroup through LDS, then the workgroup maps, then back down), and the
+// encode runs one lane per chunk from its now-known start.  Those kernels are always queued
+// (the stream is never waited for) and leave at once when the flag is down.
 #include <atomic>
 
 #include "amv_kernels.h"
@@ -56,45 +64,164 @@ __device__ __forceinline__ int expand(int& predictor, int& index, uint32_t nibbl
     return predictor;
 }
 
-// adpcm_ima_compress_sample, adpcm.c:219-227.  min(7, |delta|*4/step) is taken bit by bit (the
-// classic IMA quantiser ladder: identical quotient, no integer division on the chain).
-__device__ __forceinline__ uint32_t compress(int& prev, int& index, int sample, const uint32_t* s_step) {
-    const int delta = sample - prev;
-    const uint32_t step = s_step[index];
-    uint32_t d4 = (uint32_t)abs(delta) << 2;
-    uint32_t q = 0;
-    if (d4 >= step * 4u) { q = 4u; d4 -= step * 4u; }
-    if (d4 >= step * 2u) { q |= 2u; d4 -= step * 2u; }
-    if (d4 >= step) q |= 1u;
-    const int mag = (int)((step * (2u * q + 1u)) >> 3);   // step * yamaha_difflookup[nibble] / 8
-    prev = clip16(delta < 0 ? prev - mag : prev + mag);
-    index = clip_index(index + index_adjust(q));
-    return q + (delta < 0 ? 8u : 0u);
+// adpcm_ima_compress_sample, adpcm.c:219-227, shaped for a lane that is alone on its SIMD (the sweeps of the index chain
+// are as long as one chunk's serial chain, so what counts is the length of the dependency chain per sample, not the
+// instruction count):
+//   * samples and predictor are kept biased by 32768, so |delta| is one v_sad_u32 and the clip is a med3 to 0..65535;
+//   * min(7, |delta| * 4 / step) is one float multiply: trunc(float(|delta|) * r) with r = 4 / step nudged up by 2^-20.
+//     Exact for every |delta| < 65536 and every step of the table: the nudge outweighs the two roundings (2^-23 each) so
+//     exact multiples do not fall short, and 7 * (2^-20 + 2^-22) < 1 / 32767, the closest a quotient below 8 comes to the
+//     next integer from underneath (tests/test_abi_and_host.py checks all 89 x 65536 cases against the integer division
+//     with the table amvhip_adpcm_quotient_table hands out);
+//   * the table look-up for the NEXT step leaves the chain: the index moves by -1, +2, +4, +6 or +8, so the five steps it
+//     can arrive at and their reciprocals (a 32-byte row per index: AdpcmRow) are requested as soon as the index is
+//     known, a sample ahead of their use, and the quotient picks among them (one byte permute + selects).
+struct AdpcmRow {
+    uint32_t s12, s34, s0;   // the step after a move of +2 | +4 << 16, of +6 | +8 << 16, of -1
+    float r0, r1, r2, r3, r4;  // reciprocals (4 / step, nudged) in the order -1, +2, +4, +6, +8
+};
+static_assert(sizeof(AdpcmRow) == 32, "two 16-byte LDS reads per row");
+
+struct AdpcmTables {
+    AdpcmRow row[89];
+    float rcp[89];
+};
+
+constexpr float quotient_factor(int step) { return (float)((4.0 / step) * (1.0 + 1.0 / 1048576.0)); }
+constexpr int clip_index_c(int v) { return v < 0 ? 0 : (v > 88 ? 88 : v); }
+constexpr AdpcmTables make_adpcm_tables() {
+    AdpcmTables t{};
+    for (int i = 0; i < 89; ++i) {
+        const int to[5] = {clip_index_c(i - 1), clip_index_c(i + 2), clip_index_c(i + 4), clip_index_c(i + 6), clip_index_c(i + 8)};
+        t.row[i].s0 = (uint32_t)kImaStep[to[0]];
+        t.row[i].s12 = (uint32_t)kImaStep[to[1]] | ((uint32_t)kImaStep[to[2]] << 16);
+        t.row[i].s34 = (uint32_t)kImaStep[to[3]] | ((uint32_t)kImaStep[to[4]] << 16);
+        t.row[i].r0 = quotient_factor(kImaStep[to[0]]);
+        t.row[i].r1 = quotient_factor(kImaStep[to[1]]);
+        t.row[i].r2 = quotient_factor(kImaStep[to[2]]);
+        t.row[i].r3 = quotient_factor(kImaStep[to[3]]);
+        t.row[i].r4 = quotient_factor(kImaStep[to[4]]);
+        t.rcp[i] = quotient_factor(kImaStep[i]);
+    }
+    return t;
+}
+static constexpr AdpcmTables kAdpcmHost = make_adpcm_tables();
+__device__ const AdpcmTables kAdpcmTables = make_adpcm_tables();
+
+// LDS image of a workgroup that encodes: the rows, the reciprocals and the steps themselves.  Lanes look up rows of
+// their own, so a plain [89][32 bytes] table would put lanes whose indices differ by 8 on the same banks (a row is
+// an eighth of the 256-byte bank row).  Every half row exists sixteen times instead, once per 16-byte slot of the
+// bank row, and lane l reads slot l & 15: the sixteen lanes ds_read_b128 serves together ({0-3, 12-15, 20-27}, ...)
+// have sixteen different l & 15, so no look-up ever meets a conflict, whatever the indices.
+constexpr uint32_t kEncodeBlock = 256;   // 45 KB of tables per workgroup: three workgroups = twelve waves per CU
+struct EncodeLds {
+    uint4 row[2][89][16];
+    float rcp[96];
+    uint32_t step[96];
+};
+
+__device__ __forceinline__ void load_encode_tables(EncodeLds& l) {
+    const uint4* src = reinterpret_cast<const uint4*>(kAdpcmTables.row);
+    for (uint32_t i = threadIdx.x; i < 2u * 89u * 16u; i += blockDim.x) {
+        const uint32_t half = i / (89u * 16u), row = (i / 16u) % 89u;
+        (&l.row[0][0][0])[i] = src[2u * row + half];
+    }
+    for (uint32_t i = threadIdx.x; i < 89u; i += blockDim.x) {
+        l.rcp[i] = kAdpcmTables.rcp[i];
+        l.step[i] = (uint32_t)kImaStep[i];
+    }
+    __syncthreads();
 }
 
-// a chunk's samples from (prev, index): 16 samples per 32-byte load pair, 8 bytes out.  m is even.
+struct EncodeState {
+    uint32_t prev;   // predictor + 32768
+    uint32_t index;
+    uint32_t step;   // kImaStep[index]
+    float rcp;       // its quotient factor
+};
+
+__device__ __forceinline__ EncodeState encode_state(int prev, int index, const EncodeLds& l) {
+    return EncodeState{(uint32_t)(prev + 32768), (uint32_t)index, l.step[index], l.rcp[index]};
+}
+
+// one sample (biased by 32768) -> its nibble
+__device__ __forceinline__ uint32_t compress(EncodeState& s, uint32_t sample, const EncodeLds& l) {
+    const uint32_t slot = threadIdx.x & 15u;
+    const uint4 ra = l.row[0][s.index][slot], rb = l.row[1][s.index][slot];
+    uint32_t ad;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(ad) : "v"(sample), "v"(s.prev));
+    const uint32_t sign = sample < s.prev ? 1u : 0u;
+    const uint32_t q = min((uint32_t)((float)ad * s.rcp), 7u);
+    const uint32_t mag = __umul24(s.step, 2u * q + 1u) >> 3;                      // step * yamaha_difflookup[nibble] / 8
+    const int moved = (int)(s.prev + (mag ^ (0u - sign)) + sign);                 // prev -+ mag
+    s.prev = (uint32_t)min(max(moved, 0), 65535);
+    const uint32_t up = __builtin_amdgcn_ubfe(0x97530000u, q * 4u, 4u);           // kImaIndexAdjust[q] + 1
+    s.index = (uint32_t)min(max((int)(s.index + up) - 1, 0), 88);
+    const bool low = q < 4u, odd = (q & 1u) != 0u;
+    const uint32_t hop = __builtin_amdgcn_perm(ra.y, ra.x, __umul24(q, 0x0202u) + 0x0c0bf8f8u);   // halves 0..3 of {s12, s34} for q = 4..7
+    s.step = low ? ra.z : hop;
+    const float r12 = odd ? __uint_as_float(rb.y) : __uint_as_float(rb.x);
+    const float r34 = odd ? __uint_as_float(rb.w) : __uint_as_float(rb.z);
+    s.rcp = low ? __uint_as_float(ra.w) : (q < 6u ? r12 : r34);
+    return q | (sign << 3);
+}
+
+// sixteen samples (eight words, biased here) -> eight bytes
+__device__ __forceinline__ Bytes8 compress16(EncodeState& s, const uint32_t* w, const EncodeLds& l) {
+    Bytes8 o;
+    o.w[0] = 0u;
+    o.w[1] = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t word = w[j >> 1] ^ 0x80008000u;
+        const uint32_t nib = compress(s, (j & 1) ? word >> 16 : word & 0xffffu, l);
+        o.w[j >> 3] |= nib << (8 * ((j >> 1) & 3) + ((j & 1) ? 0 : 4));   // :489-493 high nibble = earlier sample
+    }
+    return o;
+}
+
+// A chunk's samples from state s (m is even).  One lane owns the chunk, so what it waits for is its own memory
+// latency: the samples come a 128-byte line (64 samples) at a time, and the line after is requested before the
+// current one is worked on -- one exposed round trip per chunk instead of one per sixteen samples (the sweeps of the
+// index chain run a wave per SIMD or less: 130 us per sweep before, the chain itself takes half of that).
 template <bool kWrite>
-__device__ __forceinline__ void encode_run(const int16_t* __restrict__ x, uint32_t m, int& prev, int& index,
-                                           uint8_t* __restrict__ d, const uint32_t* s_step) {
+__device__ __forceinline__ void encode_run(const int16_t* __restrict__ x, uint32_t m, EncodeState& s,
+                                           uint8_t* __restrict__ d, const EncodeLds& l) {
     uint32_t k = 0;
+    if (m >= 64u) {
+        Pcm8 cur[8], nxt[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = *reinterpret_cast<const Pcm8*>(x + 8 * i);
+        for (; k + 64u <= m; k += 64u) {
+            const bool more = k + 128u <= m;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) nxt[i] = *reinterpret_cast<const Pcm8*>(x + k + 64u + 8 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = cur[2 * i + (j >> 2)].w[j & 3];
+                const Bytes8 o = compress16(s, w, l);
+                if (kWrite) *reinterpret_cast<Bytes8*>(d + (k >> 1) + 8 * i) = o;
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+            }
+        }
+    }
     for (; k + 16u <= m; k += 16u) {
         const Pcm8 a = *reinterpret_cast<const Pcm8*>(x + k);
         const Pcm8 b = *reinterpret_cast<const Pcm8*>(x + k + 8u);
-        Bytes8 o;
-        o.w[0] = 0u;
-        o.w[1] = 0u;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t word = j < 8 ? a.w[j >> 1] : b.w[(j - 8) >> 1];
-            const int sample = (j & 1) ? ((int)word >> 16) : (int)(int16_t)(word & 0xffffu);
-            const uint32_t nib = compress(prev, index, sample, s_step);
-            o.w[j >> 3] |= nib << (8 * ((j >> 1) & 3) + ((j & 1) ? 0 : 4));   // :489-493 high nibble = earlier sample
-        }
+        const uint32_t w[8] = {a.w[0], a.w[1], a.w[2], a.w[3], b.w[0], b.w[1], b.w[2], b.w[3]};
+        const Bytes8 o = compress16(s, w, l);
         if (kWrite) *reinterpret_cast<Bytes8*>(d + (k >> 1)) = o;
     }
     for (; k < m; k += 2u) {
-        const uint32_t hi = compress(prev, index, x[k], s_step);
-        const uint32_t lo = compress(prev, index, x[k + 1u], s_step);
+        const uint32_t hi = compress(s, (uint32_t)(x[k] + 32768), l);
+        const uint32_t lo = compress(s, (uint32_t)(x[k + 1u] + 32768), l);
         if (kWrite) d[k >> 1] = (uint8_t)((hi << 4) | lo);
     }
 }
@@ -120,9 +247,8 @@ __global__ __launch_bounds__(64) void amv_adpcm_decode_kernel(
     int16_t* o = pcm + pcm_offs[i];
     const uint8_t* p = c + 8;
     const uint32_t nb = len - 8u;
-    uint32_t k = 0;
-    for (; k + 16u <= nb; k += 16u) {                // AdpcmIma.c:225-237, 32 samples per trip
-        const Bytes16 in = *reinterpret_cast<const Bytes16*>(p + k);
+    // AdpcmIma.c:225-237, 32 samples per 16 bytes
+    auto decode16 = [&](const Bytes16& in, int16_t* dst) {
         Pcm32 out;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -144,8 +270,28 @@ __global__ __launch_bounds__(64) void amv_adpcm_decode_kernel(
                 else out.w[4 * w + (j >> 1)] = (uint32_t)predictor & 0xffffu;
             }
         }
-        *reinterpret_cast<Pcm32*>(o + 2u * k) = out;
+        *reinterpret_cast<Pcm32*>(dst) = out;
+    };
+    uint32_t k = 0;
+    if (nb >= 64u) {                                 // 64 bytes at a time, the next 64 requested before these are decoded
+        Bytes16 cur[4], nxt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const Bytes16*>(p + 16 * q);
+        for (; k + 64u <= nb; k += 64u) {
+            const bool more = k + 128u <= nb;
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const Bytes16*>(p + k + 64u + 16 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) decode16(cur[q], o + 2u * k + 32 * q);
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+            }
+        }
     }
+    for (; k + 16u <= nb; k += 16u) decode16(*reinterpret_cast<const Bytes16*>(p + k), o + 2u * k);
     for (; k < nb; ++k) {
         const uint32_t byte = p[k];
         o[2u * k] = (int16_t)expand(predictor, index, byte >> 4, s_step);
@@ -190,27 +336,153 @@ __global__ void amv_adpcm_wav_encode_kernel(const int16_t* __restrict__ x, int g
     state[1] = index;
 }
 
+// ---- the guessed-start route ----------------------------------------------------------------------------------
+// device words with agent scope: what one lane stores another lane of the same launch may read (never torn, possibly
+// the value before -- the sweeps are written for that)
+__device__ __forceinline__ uint32_t peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void poke(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int encode_chunk(const int16_t* __restrict__ x, uint32_t nsamp, int start, uint8_t* __restrict__ d,
+                                            const EncodeLds& l) {
+    const uint32_t pairs = nsamp >> 1;
+    const int prev = pairs ? x[0] : 0;              // adpcm.c:464
+    d[0] = (uint8_t)(prev & 0xff);                  // :465 le16 first sample
+    d[1] = (uint8_t)((prev >> 8) & 0xff);
+    d[2] = (uint8_t)start;                          // :466 le16 step index
+    d[3] = 0;
+    const uint32_t cnt = pairs << 1;                // :479 le32 sample count
+    d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
+    EncodeState s = encode_state(prev, start, l);
+    encode_run<true>(x, cnt, s, d + 8, l);
+    return (int)s.index;
+}
+
+constexpr uint32_t kGuessTail = 128;    // samples of the chunk before that the guess is run over
+constexpr uint32_t kSettleMost = 1024;  // entries the one-workgroup kernel takes on
+constexpr uint32_t kSettleRounds = 48;
+
+// every chunk from a guessed start; state[i] = {start used, end reached}
+__global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_guess_kernel(
+    const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
+    uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state) {
+    __shared__ EncodeLds s_tab;
+    load_encode_tables(s_tab);
+    const uint32_t i = blockIdx.x * kEncodeBlock + threadIdx.x;
+    if (i >= n) return;
+    int start = 0;                                  // chunk 0: the encoder context starts zeroed
+    if (i) {
+        const uint32_t mp = nsamp[i - 1u] & ~1u, tail = min(mp, kGuessTail);
+        const int16_t* t = pcm + pcm_offs[i - 1u] + (mp - tail);
+        EncodeState s = encode_state(tail ? t[0] : 0, 0, s_tab);
+        encode_run<false>(t, tail, s, nullptr, s_tab);
+        start = (int)s.index;
+    }
+    const int end = encode_chunk(pcm + pcm_offs[i], nsamp[i], start, blob + offs[i], s_tab);
+    state[i] = make_uint2((uint32_t)start, (uint32_t)end);
+}
+
+// the chunks whose predecessor ended elsewhere than they assumed
+__global__ __launch_bounds__(256) void amv_adpcm_mismatch_kernel(const uint2* __restrict__ state, uint32_t n, uint32_t* __restrict__ list,
+                                                                 uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_count, s_base;
+    if (threadIdx.x == 0) s_count = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x + 1u;
+    const bool wrong = i < n && state[i].x != state[i - 1u].y;
+    uint32_t slot = 0;
+    if (wrong) slot = atomicAdd(&s_count, 1u);                  // one update of the global counter per workgroup
+    __syncthreads();
+    if (threadIdx.x == 0 && s_count) s_base = atomicAdd(count, s_count);
+    __syncthreads();
+    if (wrong) list[s_base + slot] = i;
+}
+
+// One sweep over a list: a listed chunk whose predecessor's end is not the start it used is coded again from there; if
+// its own end moves, its successor is listed for the next sweep.  A chunk is listed by its predecessor only, so no list
+// holds it twice.  Predecessor and successor may be in the same list: whichever of the predecessor's ends the successor
+// reads, it is listed again when that end moved, and skips the work then if it had read the new one already.
+__device__ __forceinline__ void sweep_one(const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs,
+                                          const uint32_t* __restrict__ nsamp, uint32_t n, uint8_t* __restrict__ blob,
+                                          const uint64_t* __restrict__ offs, uint2* __restrict__ state, uint32_t i,
+                                          uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out, const EncodeLds& s_tab) {
+    uint32_t* st = reinterpret_cast<uint32_t*>(state);
+    const uint32_t start = peek(st + 2u * (i - 1u) + 1u);
+    if (start == peek(st + 2u * i)) return;
+    const uint32_t end = (uint32_t)encode_chunk(pcm + pcm_offs[i], nsamp[i], (int)start, blob + offs[i], s_tab);
+    poke(st + 2u * i, start);
+    if (end == peek(st + 2u * i + 1u)) return;
+    poke(st + 2u * i + 1u, end);
+    if (i + 1u < n) list_out[atomicAdd(count_out, 1u)] = i + 1u;
+}
+
+__global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_sweep_kernel(
+    const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
+    uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state, const uint32_t* __restrict__ list_in,
+    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out) {
+    __shared__ EncodeLds s_tab;
+    const uint32_t count = *count_in;
+    if (blockIdx.x * kEncodeBlock >= count) return;
+    // a sweep is as long as one chunk's serial chain and occupies a wave per SIMD or less: beside another stream's
+    // kernels (the co-resident video decode) its waves should issue whenever they can
+    __builtin_amdgcn_s_setprio(3);
+    load_encode_tables(s_tab);
+    for (uint32_t k = blockIdx.x * kEncodeBlock + threadIdx.x; k < count; k += gridDim.x * kEncodeBlock)
+        sweep_one(pcm, pcm_offs, nsamp, n, blob, offs, state, list_in[k], list_out, count_out, s_tab);
+}
+
+// What the sweeps left, in one workgroup: rounds over the list until it is empty.  If it holds too much or does not
+// empty within the rounds given, *need_map = 1 sends the stream down the exhaustive route.
+__global__ __launch_bounds__(256) void amv_adpcm_settle_kernel(
+    const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
+    uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state, uint32_t* __restrict__ list_a,
+    uint32_t* __restrict__ count_a, uint32_t* __restrict__ list_b, uint32_t* __restrict__ count_b, uint32_t* __restrict__ need_map) {
+    __shared__ EncodeLds s_tab;
+    __builtin_amdgcn_s_setprio(3);
+    load_encode_tables(s_tab);
+    for (uint32_t round = 0;; ++round) {
+        const uint32_t count = peek(count_a);
+        if (count == 0u) return;
+        if (count > kSettleMost || round == kSettleRounds) {
+            if (threadIdx.x == 0) *need_map = 1u;
+            return;
+        }
+        for (uint32_t k = threadIdx.x; k < count; k += 256u)
+            sweep_one(pcm, pcm_offs, nsamp, n, blob, offs, state, peek(list_a + k), list_b, count_b, s_tab);
+        __threadfence();
+        __syncthreads();                            // everyone has read count_a and finished its appends
+        if (threadIdx.x == 0) poke(count_a, 0u);
+        __threadfence();
+        __syncthreads();
+        uint32_t* t = list_a; list_a = list_b; list_b = t;
+        t = count_a; count_a = count_b; count_b = t;
+    }
+}
+
+// ---- the exhaustive route (queued behind the other; every kernel of it leaves at once unless *need says otherwise) ---
 // state-only run of chunk i from start index s: where does step_index end up?  One lane per
 // (chunk, start) pair, pairs packed densely into waves.
-__global__ __launch_bounds__(64) void amv_adpcm_map_kernel(
+__global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_map_kernel(
     const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs,
-    const uint32_t* __restrict__ nsamp, uint32_t n, uint8_t* __restrict__ map /* [n][96] */) {
-    __shared__ uint32_t s_step[96];
-    load_steps(s_step);
-    const uint64_t pair = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    const uint32_t i = (uint32_t)(pair / 89u), s = (uint32_t)(pair % 89u);
-    if (i >= n) return;
-    const int16_t* x = pcm + pcm_offs[i];
-    const uint32_t m = nsamp[i] & ~1u;
-    int prev = m ? x[0] : 0, index = (int)s;
-    encode_run<false>(x, m, prev, index, nullptr, s_step);
-    map[(uint64_t)i * 96u + s] = (uint8_t)index;
+    const uint32_t* __restrict__ nsamp, uint32_t n, uint8_t* __restrict__ map /* [n][96] */, const uint32_t* __restrict__ need) {
+    __shared__ EncodeLds s_tab;
+    if (need && *need == 0u) return;
+    load_encode_tables(s_tab);
+    const uint64_t pairs = (uint64_t)n * 89u;
+    for (uint64_t pair = (uint64_t)blockIdx.x * kEncodeBlock + threadIdx.x; pair < pairs; pair += (uint64_t)gridDim.x * kEncodeBlock) {
+        const uint32_t i = (uint32_t)(pair / 89u);
+        const int16_t* x = pcm + pcm_offs[i];
+        const uint32_t m = nsamp[i] & ~1u;
+        EncodeState s = encode_state(m ? x[0] : 0, (int)(pair % 89u), s_tab);
+        encode_run<false>(x, m, s, nullptr, s_tab);
+        map[(uint64_t)i * 96u + (uint32_t)(pair % 89u)] = (uint8_t)s.index;
+    }
 }
 
 // composition of the maps of kChainBlock consecutive chunks: bmap[b][s] = where start s ends up
 __global__ __launch_bounds__(128) void amv_adpcm_chain_block_kernel(const uint8_t* __restrict__ map, uint32_t n,
-                                                                    uint8_t* __restrict__ bmap) {
+                                                                    uint8_t* __restrict__ bmap, const uint32_t* __restrict__ need) {
     __shared__ uint32_t s_map[kChainBlock * 24u];
+    if (need && *need == 0u) return;
     const uint32_t c0 = blockIdx.x * kChainBlock, cnt = min(kChainBlock, n - c0);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(map + (uint64_t)c0 * 96u);
     for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
@@ -224,8 +496,9 @@ __global__ __launch_bounds__(128) void amv_adpcm_chain_block_kernel(const uint8_
 
 // the serial walk over the workgroup maps (n / 256 steps through LDS): start index of every block
 __global__ __launch_bounds__(128) void amv_adpcm_chain_top_kernel(const uint8_t* __restrict__ bmap, uint32_t nb,
-                                                                  int32_t* __restrict__ bstart) {
+                                                                  int32_t* __restrict__ bstart, const uint32_t* __restrict__ need) {
     __shared__ uint32_t s_map[kChainBlock * 24u];
+    if (need && *need == 0u) return;
     uint32_t v = 0;   // the encoder context starts zeroed
     for (uint32_t t0 = 0; t0 < nb; t0 += kChainBlock) {
         const uint32_t cnt = min(kChainBlock, nb - t0);
@@ -246,9 +519,10 @@ __global__ __launch_bounds__(128) void amv_adpcm_chain_top_kernel(const uint8_t*
 // back down: start index of every chunk of a block from the block's start
 __global__ __launch_bounds__(128) void amv_adpcm_chain_fill_kernel(const uint8_t* __restrict__ map, uint32_t n,
                                                                    const int32_t* __restrict__ bstart,
-                                                                   int32_t* __restrict__ start) {
+                                                                   int32_t* __restrict__ start, const uint32_t* __restrict__ need) {
     __shared__ uint32_t s_map[kChainBlock * 24u];
     __shared__ int32_t s_start[kChainBlock];
+    if (need && *need == 0u) return;
     const uint32_t c0 = blockIdx.x * kChainBlock, cnt = min(kChainBlock, n - c0);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(map + (uint64_t)c0 * 96u);
     for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
@@ -265,26 +539,16 @@ __global__ __launch_bounds__(128) void amv_adpcm_chain_fill_kernel(const uint8_t
     for (uint32_t c = threadIdx.x; c < cnt; c += 128u) start[c0 + c] = s_start[c];
 }
 
-__global__ __launch_bounds__(64) void amv_adpcm_encode_kernel(
+__global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_encode_kernel(
     const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs,
     const uint32_t* __restrict__ nsamp, uint32_t n, const int32_t* __restrict__ step_in,
-    uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs) {
-    __shared__ uint32_t s_step[96];
-    load_steps(s_step);
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, const uint32_t* __restrict__ need) {
+    __shared__ EncodeLds s_tab;
+    if (need && *need == 0u) return;
+    load_encode_tables(s_tab);
+    const uint32_t i = blockIdx.x * kEncodeBlock + threadIdx.x;
     if (i >= n) return;
-    const int16_t* x = pcm + pcm_offs[i];
-    const uint32_t pairs = nsamp[i] >> 1;
-    uint8_t* d = blob + offs[i];
-    int prev = pairs ? x[0] : 0;                    // adpcm.c:464
-    int index = clip_index(step_in[i]);
-    d[0] = (uint8_t)(prev & 0xff);                  // :465 le16 first sample
-    d[1] = (uint8_t)((prev >> 8) & 0xff);
-    d[2] = (uint8_t)index;                          // :466 le16 step index
-    d[3] = 0;
-    const uint32_t cnt = pairs << 1;                // :479 le32 sample count
-    d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
-    encode_run<true>(x, cnt, prev, index, d + 8, s_step);
+    encode_chunk(pcm + pcm_offs[i], nsamp[i], clip_index(step_in[i]), blob + offs[i], s_tab);
 }
 
 // The reference's trellis search (adpcm_compress_trellis, adpcm.c:287-443, IMA branch; `-trellis N`): a beam of the
@@ -451,28 +715,60 @@ void launch_adpcm_wav_encode(const int16_t* samples, int groups, int32_t* state,
 }
 
 void launch_adpcm_map(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,
-                      uint8_t* map, int32_t* start, hipStream_t s) {
+                      uint8_t* map, int32_t* start, const uint32_t* need, hipStream_t s) {
     // map: (n + nb) * 96 bytes, start: n + nb words, nb = adpcm_chain_blocks(n)
     if (n == 0) return;
     const uint32_t nb = adpcm_chain_blocks(n);
     uint8_t* bmap = map + (uint64_t)n * 96u;
     int32_t* bstart = start + n;
-    const uint64_t pairs = (uint64_t)n * 89u;
-    hipLaunchKernelGGL(amv_adpcm_map_kernel, dim3((uint32_t)((pairs + 63u) / 64u)), dim3(64), 0, s, pcm, pcm_offs, nsamp,
-                       n, map);
-    hipLaunchKernelGGL(amv_adpcm_chain_block_kernel, dim3(nb), dim3(128), 0, s, map, n, bmap);
-    hipLaunchKernelGGL(amv_adpcm_chain_top_kernel, dim3(1), dim3(128), 0, s, bmap, nb, bstart);
-    hipLaunchKernelGGL(amv_adpcm_chain_fill_kernel, dim3(nb), dim3(128), 0, s, map, n, bstart, start);
+    const uint64_t groups = ((uint64_t)n * 89u + kEncodeBlock - 1u) / kEncodeBlock;
+    hipLaunchKernelGGL(amv_adpcm_map_kernel, dim3((uint32_t)(groups < 4096u ? groups : 4096u)), dim3(kEncodeBlock), 0, s, pcm, pcm_offs,
+                       nsamp, n, map, need);
+    hipLaunchKernelGGL(amv_adpcm_chain_block_kernel, dim3(nb), dim3(128), 0, s, map, n, bmap, need);
+    hipLaunchKernelGGL(amv_adpcm_chain_top_kernel, dim3(1), dim3(128), 0, s, bmap, nb, bstart, need);
+    hipLaunchKernelGGL(amv_adpcm_chain_fill_kernel, dim3(nb), dim3(128), 0, s, map, n, bstart, start, need);
 }
 
 uint32_t adpcm_chain_blocks(uint32_t n) { return (n + kChainBlock - 1u) / kChainBlock; }
 
+void adpcm_quotient_table(float out[89]) {
+    for (int i = 0; i < 89; ++i) out[i] = kAdpcmHost.rcp[i];
+}
+
 void launch_adpcm_encode(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp,
-                         uint32_t n, const int32_t* step_in, uint8_t* blob, const uint64_t* offs,
+                         uint32_t n, const int32_t* step_in, uint8_t* blob, const uint64_t* offs, const uint32_t* need,
                          hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(amv_adpcm_encode_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pcm, pcm_offs,
-                       nsamp, n, step_in, blob, offs);
+    hipLaunchKernelGGL(amv_adpcm_encode_kernel, dim3((n + kEncodeBlock - 1u) / kEncodeBlock), dim3(kEncodeBlock), 0, s, pcm, pcm_offs,
+                       nsamp, n, step_in, blob, offs, need);
+}
+
+// The guessed-start route.  work: adpcm_chain_workspace(n) bytes = state[n] (uint2), two lists of n words, 64 words of
+// counters (zeroed here; word 63 is the flag launch_adpcm_map / launch_adpcm_encode are given as `need`).
+uint64_t adpcm_chain_workspace(uint32_t n) { return (uint64_t)n * 16u + 256u; }
+
+const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, uint8_t* blob,
+                                   const uint64_t* offs, void* work, uint32_t sweeps, hipStream_t s) {
+    uint2* state = static_cast<uint2*>(work);
+    uint32_t* list[2] = {reinterpret_cast<uint32_t*>(state + n), reinterpret_cast<uint32_t*>(state + n) + n};
+    uint32_t* count = list[1] + n;                   // [0 .. sweeps + 1]: one per list generation; [63]: the flag
+    if (sweeps > 60u) sweeps = 60u;
+    (void)hipMemsetAsync(count, 0, 256, s);
+    hipLaunchKernelGGL(amv_adpcm_guess_kernel, dim3((n + kEncodeBlock - 1u) / kEncodeBlock), dim3(kEncodeBlock), 0, s, pcm, pcm_offs, nsamp, n,
+                       blob, offs, state);
+    if (n > 1u) {
+        hipLaunchKernelGGL(amv_adpcm_mismatch_kernel, dim3((n + 254u) / 256u), dim3(256), 0, s, state, n, list[0], count);
+        // sweep k's list is a fraction of the one before; the grid is sized for the first and strides if it must
+        uint32_t grid = (n + kEncodeBlock - 1u) / kEncodeBlock;
+        for (uint32_t k = 0; k < sweeps; ++k) {
+            hipLaunchKernelGGL(amv_adpcm_sweep_kernel, dim3(grid), dim3(kEncodeBlock), 0, s, pcm, pcm_offs, nsamp, n, blob, offs, state,
+                               list[k & 1u], count + k, list[(k + 1u) & 1u], count + k + 1u);
+            grid = grid > 256u ? (grid + 1u) / 2u : grid;
+        }
+        hipLaunchKernelGGL(amv_adpcm_settle_kernel, dim3(1), dim3(256), 0, s, pcm, pcm_offs, nsamp, n, blob, offs, state,
+                           list[sweeps & 1u], count + sweeps, list[(sweeps + 1u) & 1u], count + sweeps + 1u, count + 63);
+    }
+    return count + 63;
 }
 
 // ============================================================================================

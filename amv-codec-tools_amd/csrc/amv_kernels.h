@@ -123,14 +123,21 @@ void launch_resample(const ResamplePlanes& src, const ResamplePlanes& dst, const
 void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs,
                          const uint32_t* lens, uint32_t n, int16_t* pcm, const uint64_t* pcm_offs,
                          int32_t* final_state, hipStream_t s);
-// 89-way state map of every chunk + serial walk of the maps -> start[i] (reference step_index carry)
+// The reference's step_index carry (adpcm.c:461-498) without a serial pass over the stream.  launch_adpcm_chain: every
+// chunk coded from a guessed start, then `sweeps` launches + one settling workgroup that code again what started wrong;
+// returns the device word that is 1 when the stream did not settle.  launch_adpcm_map (89-way state map of every chunk +
+// composition of the maps -> start[i]) and launch_adpcm_encode leave at once when *need == 0 (need == nullptr: run).
+uint64_t adpcm_chain_workspace(uint32_t n);
+const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, uint8_t* blob,
+                                   const uint64_t* offs, void* work, uint32_t sweeps, hipStream_t s);
+void adpcm_quotient_table(float out[89]);   // the encoder's quotient factors (see amv_adpcm.hip: compress)
 uint32_t adpcm_chain_blocks(uint32_t n);   // launch_adpcm_map needs map[(n + blocks) * 96] and start[n + blocks]
 void launch_adpcm_map(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,
-                      uint8_t* map, int32_t* start, hipStream_t s);
+                      uint8_t* map, int32_t* start, const uint32_t* need, hipStream_t s);
 // amvlib's IMA-WAV-layout frame encoder (AdpcmIma.c:43-160), one lane
 void launch_adpcm_wav_encode(const int16_t* samples, int groups, int32_t* state, uint8_t* frame, hipStream_t s);
 void launch_adpcm_encode(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp,
-                         uint32_t n, const int32_t* step_in, uint8_t* blob, const uint64_t* offs,
+                         uint32_t n, const int32_t* step_in, uint8_t* blob, const uint64_t* offs, const uint32_t* need,
                          hipStream_t s);
 
 // the reference's trellis search (adpcm.c:287-443), one lane per independent chunk; paths: adpcm_trellis_workspace bytes.

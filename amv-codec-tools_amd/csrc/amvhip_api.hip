@@ -40,7 +40,7 @@ struct amvhip_ctx {
     HuffDecodeImage* d_dec = nullptr;
     HuffEncodeImage* d_enc = nullptr;
     // workspace
-    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count, scaled, trellis_ws;
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count, scaled, trellis_ws, chain;
     // amvhip_decode_submit_dev / _collect_dev: what the entropy stage hands to the reconstruction exists twice, so that
     // the entropy stage of one batch can run (stream `front`) beside the reconstruction of the batch before (`back`)
     struct DecodeSet { DevBuf nmcu, retry, rec, seg_start, lane_tab, rec_count; } second;
@@ -52,6 +52,9 @@ struct amvhip_ctx {
     bool want_stats = false;
     double ws_bytes_per_frame = 0.0;
     int entropy_mode = AMVHIP_ENTROPY_AUTO;
+    int adpcm_sweeps = 0;            // AMVHIP_ADPCM_SWEEPS: sweeps of the guessed-start route (-1: exhaustive route only)
+    bool adpcm_sweeps_set = false;   // false: by stream length
+    uint32_t chain_n = 0;            // chunks of the last chained ADPCM encode (where its counters are in `chain`)
     // host-pointer staging (one in-order stream of the context's own carries every host-buffer entry point)
     DevBuf h_in, h_offs, h_lens, h_out, h_status, h_aux, a_in, a_tab, a_out;
     hipStream_t hstream = nullptr;
@@ -273,6 +276,10 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->sync_lanes = v;
     }
+    if (const char* e = getenv("AMVHIP_ADPCM_SWEEPS")) {   // tuning / test knob: "map" = exhaustive route only, or a sweep count
+        c->adpcm_sweeps_set = true;
+        c->adpcm_sweeps = strcmp(e, "map") == 0 ? -1 : (atoi(e) < 0 ? 0 : (atoi(e) > 60 ? 60 : atoi(e)));
+    }
     if (hipMalloc((void**)&c->d_dec, sizeof dec) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
     if (hipMalloc((void**)&c->d_enc, sizeof enc) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
     if (hipMemcpy(c->d_dec, &dec, sizeof dec, hipMemcpyHostToDevice) != hipSuccess) return die(AMVHIP_ERR_DEVICE);
@@ -292,7 +299,7 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     for (hipEvent_t e : {c->ev_in, c->ev_front, c->ev_done[0], c->ev_done[1]})
         if (e) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out,
+                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->chain, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out,
                       &c->second.nmcu, &c->second.retry, &c->second.rec, &c->second.seg_start, &c->second.lane_tab, &c->second.rec_count})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
@@ -892,15 +899,45 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
     if (int r = use_device(c)) return r;
     std::lock_guard<std::mutex> lk(c->mu);
     Timed t(c, AMVHIP_K_ADPCM_ENC, (hipStream_t)stream);
+    const uint32_t* need = nullptr;
     if (!d_step_in) {  // the reference's behaviour: step_index runs through the whole stream
         const size_t slots = (size_t)n + adpcm_chain_blocks(n);
         if (int r = ensure(c, c->map, slots * 96)) return r;
         if (int r = ensure(c, c->start, slots * 4)) return r;
-        launch_adpcm_map(d_pcm, d_pcm_offs, d_nsamp, n, (uint8_t*)c->map.p, (int32_t*)c->start.p, (hipStream_t)stream);
+        if (c->adpcm_sweeps >= 0) {   // guessed starts + sweeps; the exhaustive route behind it runs only if they do not settle
+            if (int r = ensure(c, c->chain, adpcm_chain_workspace(n))) return r;
+            uint32_t sweeps = (uint32_t)c->adpcm_sweeps;
+            if (!c->adpcm_sweeps_set) {   // the lists shrink ~3.7x per sweep on ordinary audio; a few to spare
+                sweeps = 0;
+                for (uint64_t left = n; left > 64u; left = left * 3u / 10u) ++sweeps;
+                sweeps = n > 64u ? sweeps + 2u : 0u;
+            }
+            c->chain_n = n;
+            need = launch_adpcm_chain(d_pcm, d_pcm_offs, d_nsamp, n, d_blob, d_offs, c->chain.p, sweeps, (hipStream_t)stream);
+        }
+        launch_adpcm_map(d_pcm, d_pcm_offs, d_nsamp, n, (uint8_t*)c->map.p, (int32_t*)c->start.p, need, (hipStream_t)stream);
         d_step_in = (const int32_t*)c->start.p;
     }
-    launch_adpcm_encode(d_pcm, d_pcm_offs, d_nsamp, n, d_step_in, d_blob, d_offs, (hipStream_t)stream);
+    launch_adpcm_encode(d_pcm, d_pcm_offs, d_nsamp, n, d_step_in, d_blob, d_offs, need, (hipStream_t)stream);
     return check_launch(c, "adpcm_encode");
+}
+
+extern "C" void amvhip_adpcm_quotient_table(float out[89]) {
+    if (out) adpcm_quotient_table(out);
+}
+
+extern "C" int amvhip_adpcm_chain_stats(amvhip_ctx* c, uint32_t out[64]) {
+    if (!c || !out) return AMVHIP_ERR_ARG;
+    if (int r = use_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->chain_n) return fail(c, AMVHIP_ERR_ARG, "adpcm_chain_stats: no chained encode has run");
+    uint32_t w[64];
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(w, (const uint8_t*)c->chain.p + (size_t)c->chain_n * 16, sizeof w, hipMemcpyDeviceToHost));
+    out[0] = w[63];
+    for (int k = 0; k < 62; ++k) out[k + 1] = w[k];
+    out[63] = 0;
+    return AMVHIP_OK;
 }
 
 extern "C" int amvhip_adpcm_decode_batch_async(amvhip_ctx* c, const uint8_t* blob, uint64_t blob_bytes,
@@ -1209,7 +1246,7 @@ extern "C" const char* amvhip_kernel_name(int kernel) {
         case AMVHIP_K_PACK_SERIAL: return "amv_pack_kernel";
         case AMVHIP_K_COMPACT: return "amv_scan_kernel+amv_gather_kernel";
         case AMVHIP_K_ADPCM_DEC: return "amv_adpcm_decode_kernel";
-        case AMVHIP_K_ADPCM_ENC: return "amv_adpcm_map_kernel+amv_adpcm_chain_*+amv_adpcm_encode_kernel";
+        case AMVHIP_K_ADPCM_ENC: return "amv_adpcm_guess_kernel+amv_adpcm_sweep_kernel*+settle (+map, chain_*, encode when the chain does not settle)";
         case AMVHIP_K_SYNTH: return "amv_synth_frames_kernel";
         default: return "";
     }

@@ -110,18 +110,18 @@ def timed(E, step, steps, warmup, finish=None):
 
 
 def kernel_times(E, ids, ctx=None, steps=1):
-    """per kernel: launches in the timed region and milliseconds per STEP (a step may launch a kernel more than once:
-    the decode path's fall-back rounds)"""
+    """per kernel: launches in the timed region, milliseconds per STEP (a step may launch a kernel more than once: the
+    decode path's fall-back rounds, the ADPCM chain's sweeps) and per launch"""
     ctx = ctx or E.ctx
     kern = {}
     for k in ids:
         launches, ms = ctx.prof_read(k)
         if launches:
-            kern[ctx.kernel_name(k)] = {"launches": launches, "avg_ms": ms / max(steps, 1)}
+            kern[ctx.kernel_name(k)] = {"launches": launches, "ms_per_step": ms / max(steps, 1), "ms_per_launch": ms / launches}
     return kern
 
 
-TRAFFIC_ROUND = "r02"   # profiles/<round>_traffic*.json: this round's PMC passes (tools/profile_round.sh)
+TRAFFIC_ROUND = "r03"   # profiles/<round>_traffic*.json: this round's PMC passes (tools/profile_round.sh)
 
 
 def profiled_traffic(tag, dom):
@@ -159,8 +159,8 @@ def roofline(kern, algo_bytes, elapsed_per_step, traffic, extra=None):
     """achieved / frac: the path's algorithmic bytes per launch over the dominant kernel's time, as the bench contract
     defines them; path_achieved / path_frac: the same bytes over the whole step (every kernel of the path), the
     figure to read the path by"""
-    dom = max(kern, key=lambda name: kern[name]["avg_ms"])
-    achieved = algo_bytes / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+    dom = max(kern, key=lambda name: kern[name]["ms_per_step"])
+    achieved = algo_bytes / (kern[dom]["ms_per_step"] * 1e-3) / 1e9
     tr, src = traffic(dom) if callable(traffic) else (traffic, None)
     path = algo_bytes / elapsed_per_step / 1e9
     r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -198,6 +198,18 @@ def run_decode(E, args):
             raise SystemExit("HIP decode differs from the oracle at frame %d" % (first + i))
         if ch != orc.encode_frame(orc.synth_frame(SEED, first + i, w, h), w, h):
             raise SystemExit("device-made stream differs from the oracle's encoder at frame %d" % (first + i))
+
+    # ... and EVERY frame of the batch against a second decode of it with the other entropy kernel (the serial one-lane
+    # walk, amv_huffman_kernel + dense coefficient lines): two independent routes to the same bytes, compared on the device
+    d_ref = torch.empty_like(d_out)
+    d_st2 = torch.empty_like(d_st)
+    ctx.set_entropy_mode(pkg.ENTROPY_SERIAL)
+    ctx.decode_batch_dev(d_blob, cap, d_offs, d_lens, n, w, h, 0, d_ref, d_st2, stream)
+    ctx.set_entropy_mode(pkg.ENTROPY_AUTO)
+    torch.cuda.synchronize()
+    if not torch.equal(d_ref, d_out) or int((d_st2 != 0).sum().item()) != 0:
+        raise SystemExit("the batch decodes differently through the serial entropy kernel")
+    del d_ref, d_st2
 
     ids = (pkg.K_UNSTUFF, pkg.K_HUFFMAN, pkg.K_HUFFMAN_SERIAL, pkg.K_RECON)
     one_call = None
@@ -249,7 +261,9 @@ def run_decode(E, args):
     result = base_result(E, args, "AMV frames/sec/GPU (%dx%d decode, bit-exact)" % (w, h), "frames/s", n, elapsed)
     result["config"] = {"workload": "%dx%d AMV decode, %d-frame synthetic stream per GPU, chunks resident in HBM" % (w, h, n),
                         "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % E.world,
-                        "per_gpu_frames_per_s": result["value"] / E.world}
+                        "per_gpu_frames_per_s": result["value"] / E.world,
+                        "gate": "every frame == a second decode through the serial entropy kernel (device compare); frames 0, 1, "
+                                "n/2, n-1 == the CPU oracle; their chunks == the oracle's encoder"}
     result["config"]["decode_workspace_bytes_per_frame"] = workspace
     if one_call:
         result["config"]["calls"] = ("amvhip_decode_submit_dev / _collect_dev, batch k+1 submitted before batch k is collected "
@@ -540,6 +554,9 @@ def run_adpcm(E, args, with_video=False):
         result["cpu_baseline"] = {"value": 2 * m * spf / t1, "unit": "samples/s", "cores": 1, "kind": "port",
                                   "sample": "first %d chunks of the same audio, CPU oracle encode + decode, one thread "
                                             "(includes the ctypes call per chunk)" % m}
+    if with_video:
+        E.extra_ctx = []
+        actx.close()
     return result
 
 
@@ -616,6 +633,43 @@ def run_amvlib(E, args):
     return result
 
 
+def run_secondary(E, args):
+    """The other BASELINE.json configs beside the headline, each with its own gate and timed loop (fewer steps), so that
+    the one line the driver records carries all five: 320x240 decode, the 10 000-frame 160x120 stream (configs[3]'s
+    stream on one GPU), 320x240 encode (configs[2]), video decode with co-resident ADPCM (configs[4]), ADPCM alone."""
+    import copy
+    out = {}
+    plan = (("decode_320x240", run_decode, {"width": 320, "height": 240, "frames": 32000}),
+            ("decode_160x120_10k_stream", run_decode, {"frames": 10000}),
+            ("encode_320x240", run_encode, {}),
+            ("coresident_320x240_adpcm", lambda e, a: run_adpcm(e, a, with_video=True), {}),
+            ("adpcm", lambda e, a: run_adpcm(e, a, with_video=False), {}))
+    for name, fn, over in plan:
+        a = copy.copy(args)
+        a.no_cpu_baseline, a.steps, a.warmup = True, min(args.steps, 10), min(args.warmup, 2)
+        for k, v in over.items():
+            setattr(a, k, v)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        r = fn(E, a)
+        E.extra_ctx = []
+        roof = r["roofline"]
+        entry_ = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
+                  "workload": r["config"]["workload"], "kernels": roof["kernels"],
+                  "roofline": {k: roof[k] for k in ("kernel", "achieved", "frac", "path_achieved", "path_frac", "traffic", "traffic_source",
+                                                    "algorithmic_bytes_per_launch")},
+                  "wall_s": None}
+        for k in ("mean_chunk_bytes", "round_trip_psnr_db", "psnr_floor_db", "bit_exact_vs_cpu_encoder", "adpcm_samples_per_s", "gate"):
+            if k in r["config"]:
+                entry_[k] = r["config"][k]
+        if "co_resident_audio_kernels" in roof:
+            entry_["co_resident_audio_kernels"] = roof["co_resident_audio_kernels"]
+        entry_["wall_s"] = time.perf_counter() - t0
+        out[name] = entry_
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -637,6 +691,8 @@ def main():
                     help="decode: also run configs[3] as stated (one 10 000-frame stream scattered from rank 0, decoded, gathered "
                          "back) and report it under config.config4_strong_10k; always on when WORLD_SIZE > 1")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="frames of the stream the CPU baseline decodes")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default line only: skip the other BASELINE configs (config.secondary)")
     args = ap.parse_args()
 
     E = Env()
@@ -665,6 +721,9 @@ def main():
 
     if args.workload == "decode":
         result = run_decode(E, args)
+        plain = not (args.frames or args.width or args.height or args.pipelined or args.strong)
+        if plain and E.world == 1 and not args.no_secondary:
+            result["config"]["secondary"] = run_secondary(E, args)
     elif args.workload == "encode":
         result = run_encode(E, args)
     elif args.workload == "coresident":

@@ -349,7 +349,10 @@ int amvhip_encode_coefs_dev(amvhip_ctx *ctx, const uint8_t *d_pix, uint32_t pix_
  *         8 + nsamp/2 bytes at d_blob + d_offs[i].  step_index handling:
  *         d_step_in != NULL : chunk i starts from d_step_in[i] (independent chunks);
  *         d_step_in == NULL : the reference's behaviour, step_index carried from chunk i-1
- *                             (chunk 0 starts at 0); chunks of one call form one stream.
+ *                             (chunk 0 starts at 0); chunks of one call form one stream.  The chain is
+ *                             resolved on the device (guessed starts, chunks that guessed wrong coded
+ *                             again; a stream that does not settle takes an exhaustive 89-start map
+ *                             instead), never by a serial pass and never by waiting for the stream.
  */
 int amvhip_adpcm_decode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64_t blob_bytes,
                                   const uint64_t *d_offs, const uint32_t *d_lens, uint32_t n,
@@ -359,6 +362,13 @@ int amvhip_adpcm_decode_batch_dev(amvhip_ctx *ctx, const uint8_t *d_blob, uint64
 int amvhip_adpcm_encode_batch_dev(amvhip_ctx *ctx, const int16_t *d_pcm, const uint64_t *d_pcm_offs,
                                   const uint32_t *d_nsamp, uint32_t n, const int32_t *d_step_in,
                                   uint8_t *d_blob, const uint64_t *d_offs, void *stream);
+/* The 89 factors r[i] with which the encode kernels take min(7, |delta| * 4 / step[i]) as trunc((float)|delta| * r[i])
+ * (host arithmetic, no device needed): published so that the exactness of that shortcut can be checked off the device. */
+void amvhip_adpcm_quotient_table(float out[89]);
+/* Diagnostic of the last amvhip_adpcm_encode_batch_dev call with d_step_in == NULL (waits for the device):
+ * out[0] = 1 if the stream took the exhaustive route, out[1..] = chunks coded again in sweep 1, 2, ... (0-terminated,
+ * at most 60).  Returns AMVHIP_OK, or AMVHIP_ERR_ARG when no such call has been made. */
+int amvhip_adpcm_chain_stats(amvhip_ctx *ctx, uint32_t out[64]);
 /* host-buffer forms (H2D, kernel, D2H, synchronous).  pcm_samples / blob_bytes are the sizes of
  * the whole pcm / blob arrays the offsets index into. */
 int amvhip_adpcm_decode_batch(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_bytes,

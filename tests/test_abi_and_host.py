@@ -235,3 +235,20 @@ def test_avcodec_plugin_tables(pkg):
         ids[sym] = t.id
     assert ids["amv_decoder"] == ids["amv_encoder"] and ids["adpcm_ima_amv_decoder"] == ids["adpcm_ima_amv_encoder"]
     assert ids["amv_decoder"] != ids["adpcm_ima_amv_decoder"]
+
+
+def test_adpcm_float_quotient_is_exact(pkg):
+    """The encode kernels take min(7, |delta| * 4 / step) (adpcm.c:221) as trunc(float(|delta|) * r[index]): one float
+    multiply, round to nearest, then truncation -- exactly what numpy's float32 does.  Every |delta| a pair of 16-bit
+    samples can have, every step of the table: equal to the integer division."""
+    lib = pkg.load_library()
+    r = np.zeros(89, np.float32)
+    lib.amvhip_adpcm_quotient_table(r.ctypes.data)
+    steps = [7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 21, 23, 25, 28, 31, 34, 37, 41, 45, 50, 55, 60, 66, 73, 80, 88, 97, 107, 118,
+             130, 143, 157, 173, 190, 209, 230, 253, 279, 307, 337, 371, 408, 449, 494, 544, 598, 658, 724, 796, 876, 963, 1060,
+             1166, 1282, 1411, 1552, 1707, 1878, 2066, 2272, 2499, 2749, 3024, 3327, 3660, 4026, 4428, 4871, 5358, 5894, 6484,
+             7132, 7845, 8630, 9493, 10442, 11487, 12635, 13899, 15289, 16818, 18500, 20350, 22385, 24623, 27086, 29794, 32767]
+    ad = np.arange(65536, dtype=np.uint32)
+    for i, s in enumerate(steps):                      # adpcm.c:66-76 step_table
+        got = np.minimum((ad.astype(np.float32) * r[i]).astype(np.uint32), 7)
+        assert (got == np.minimum(ad.astype(np.int64) * 4 // s, 7)).all(), s

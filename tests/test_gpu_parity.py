@@ -1373,3 +1373,78 @@ def test_kernels_match_reference_produced_outputs(ctx, pkg, orc, amv1):
     for i in range(k):
         hh = orc.fnv1a64(hh, blob[i * (8 + fs // 2): (i + 1) * (8 + fs // 2)])
     assert "%016x" % hh == a["plain"]["fnv"]
+
+
+def _with_env(pkg, name, value):
+    """a context created while the environment variable holds `value` (the knobs are read at creation)"""
+    import os
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return pkg.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+
+
+def test_adpcm_index_chain_routes(pkg, orc):
+    """The step-index chain (adpcm.c:461-498) resolved by guessed starts + sweeps, by the settling workgroup alone, by the
+    exhaustive 89-start map, and -- on a stream built so that every chunk's end depends on its start (hundreds of
+    two-to-eight-sample chunks: each sweep settles one more chunk) -- by the exhaustive route the device falls back to on
+    its own.  Every route writes the bytes of the oracle's sequential encode."""
+    rng = np.random.default_rng(99)
+    ordinary = [1378] * 900 + [2 * int(rng.integers(0, 700)) for _ in range(100)]
+    rng.shuffle(ordinary)
+    cases = []
+    for kind, sizes in (("audio", ordinary), ("walk", [2] * 1500), ("audio", [1378] * 40), ("walk", [2] * 70), ("audio", [1378])):
+        n = len(sizes)
+        pcm_offs = np.cumsum([0] + sizes).astype(np.uint64)
+        pcm = orc.synth_audio(SEED, 777, int(pcm_offs[-1]) + 2)
+        if kind == "walk":
+            # two-sample chunks {a, a} (index - 2) and {a, a + 20000} (index - 1 + 8): a walk kept inside 20..60, where
+            # nothing clamps and every chunk maps start s to s + constant -- the end depends on the start all along
+            idx = 0
+            for i in range(n):
+                up = idx < 20 or (idx < 60 and rng.integers(0, 4) == 0)
+                pcm[2 * i] = -10000
+                pcm[2 * i + 1] = 10000 if up else -10000
+                idx += 7 if up else -2
+        offs = np.cumsum([0] + [8 + s // 2 for s in sizes]).astype(np.uint64)
+        want, idx, starts = [], 0, []
+        for i in range(n):
+            starts.append(idx)
+            seg = pcm[int(pcm_offs[i]):int(pcm_offs[i + 1])]
+            if seg.size:
+                chunk, idx = orc.adpcm_encode_chunk(seg, idx)
+            else:
+                chunk = bytes([0, 0, idx, 0, 0, 0, 0, 0])
+            want.append(chunk)
+        if kind == "walk":
+            assert 15 <= min(starts[8:]) and max(starts) <= 70 and len(set(starts)) > 20, (min(starts[8:]), max(starts))
+        cases.append((sizes, pcm, pcm_offs, offs, b"".join(want), len(set(starts))))
+    seen_exhaustive = seen_settled = 0
+    for knob in (None, "0", "3", "map"):
+        ctx = pkg.Context(0) if knob is None else _with_env(pkg, "AMVHIP_ADPCM_SWEEPS", knob)
+        try:
+            for k, (sizes, pcm, pcm_offs, offs, want, _) in enumerate(cases):
+                n = len(sizes)
+                blob = np.full(int(offs[-1]), 0xEE, np.uint8)
+                ctx.adpcm_encode_batch(pcm, pcm.size, pcm_offs[:-1].copy(), np.array(sizes, np.uint32), n, None, blob, blob.size,
+                                       offs[:-1].copy())
+                assert blob.tobytes() == want, (knob, k)
+                if knob != "map":
+                    st = ctx.adpcm_chain_stats()
+                    if k == 1:
+                        assert st["exhaustive"], (knob, st)                  # 1 500 dependent chunks: no sweep count settles them
+                        seen_exhaustive += 1
+                    if k == 0 and knob is None:
+                        assert not st["exhaustive"] and len(st["recoded"]) >= 2 and st["recoded"][0] < n, st
+                        assert all(a >= b for a, b in zip(st["recoded"], st["recoded"][1:])), st
+                        seen_settled += 1
+                    if k in (2, 4):
+                        assert not st["exhaustive"], (knob, k, st)
+        finally:
+            ctx.close()
+    assert seen_exhaustive == 3 and seen_settled == 1
