@@ -13,7 +13,15 @@ namespace amv {
 constexpr uint32_t kSegImageBytes = 60u * 128u;   // the LDS image of a segment's <= 60 blocks; 128 spare bytes follow it
 constexpr uint32_t kDummyRecordWord = 0x8000u;   // bit 15: a filler no block owns (amv_decode_sync.hip's kDummyRecord)
 
-// s_img: kSegImageBytes + 128 bytes of LDS, 16-byte aligned; the caller may reuse it after a __syncthreads().
+// A segment belongs to one wave and so does its LDS: what one lane wrote another lane of the same wave may read once
+// the wave has passed this point (a wave's LDS operations are served in order; the fence keeps the compiler from
+// moving them across).  No workgroup barrier: the waves of a workgroup work on segments of their own.
+__device__ __forceinline__ void seg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// s_img: kSegImageBytes + 128 bytes of LDS, 16-byte aligned; the caller may reuse it after a seg_sync().
 // segidx: this segment's number in the frame (mcu_row * segments_per_row + segment).
 // Returns true when this lane holds a block (lane < cnt * 6).
 // Which frame this workgroup works on: work item `item` of the launch (FrameSel); false when there is none (past
@@ -71,7 +79,7 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
         }
         uint4* img16 = reinterpret_cast<uint4*>(s_img);
         for (uint32_t i = lane; i < nb * 8u; i += kWave) img16[i] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
+        seg_sync();
         // Scatter, without a branch per record: the word shifted left by one holds 2 * index in bits 1-6, the block field
         // in bits 7-12 and the filler flag in bit 16.  Adding (64 - first block) << 7 turns the field into the block's
         // number in the segment (modulo 64, carry into bit 13); with bit 16 kept, one unsigned compare against
@@ -115,7 +123,7 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
                 if (babs >= first) dc_base = k6 < 4u ? by : (k6 == 4u ? bu : bv);
             }
         }
-        __syncthreads();
+        seg_sync();
     }
     if (lane >= nb) return false;
     if (records) {

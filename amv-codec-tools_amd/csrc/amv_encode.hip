@@ -18,281 +18,69 @@
 //                       one lane per frame; a wave stages block b of its 64 frames in LDS with
 //                       whole-line loads and every lane codes its own block from there.
 //   amv_scan_kernel / amv_gather_kernel   prefix sum of chunk lengths and compaction.
-#include "amv_kernels.h"
+#include "amv_encode_common.h"
 
 namespace amv {
 
-namespace {
+using namespace enc;
 
-constexpr int kWave = 64;
-constexpr int kSegMcus = 10;
-
-__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
-
-// One 8-point LL&M pass of jfdctint.c: kPass 0 = row_fdct (:184-258), 1 = column pass (:273-341)
-template <int kPass>
-__device__ __forceinline__ void fdct8(int (&d)[8]) {
-    constexpr int kConstBits = 13, kPass1Bits = 4;
-    constexpr int kShift = kPass == 0 ? kConstBits - kPass1Bits : kConstBits + kPass1Bits;
-    const int t0 = d[0] + d[7], t7 = d[0] - d[7];
-    const int t1 = d[1] + d[6], t6 = d[1] - d[6];
-    const int t2 = d[2] + d[5], t5 = d[2] - d[5];
-    const int t3 = d[3] + d[4], t4 = d[3] - d[4];
-    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
-    if (kPass == 0) {
-        d[0] = (t10 + t11) << kPass1Bits;
-        d[4] = (t10 - t11) << kPass1Bits;
-    } else {
-        d[0] = descale(t10 + t11, kPass1Bits);
-        d[4] = descale(t10 - t11, kPass1Bits);
-    }
-    int z1 = (t12 + t13) * 4433;
-    d[2] = descale(z1 + t13 * 6270, kShift);
-    d[6] = descale(z1 - t12 * 15137, kShift);
-    z1 = t4 + t7;
-    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
-    const int z5 = (z3 + z4) * 9633;
-    const int u4 = t4 * 2446, u5 = t5 * 16819, u6 = t6 * 25172, u7 = t7 * 12299;
-    z1 *= -7373;
-    z2 *= -20995;
-    z3 = z3 * -16069 + z5;
-    z4 = z4 * -3196 + z5;
-    d[7] = descale(u4 + z1 + z3, kShift);
-    d[5] = descale(u5 + z2 + z4, kShift);
-    d[3] = descale(u6 + z2 + z3, kShift);
-    d[1] = descale(u7 + z1 + z4, kShift);
-}
-
-}  // namespace
-
-namespace {
-
-struct __attribute__((packed, aligned(1))) Px12 { uint32_t w[3]; };   // four RGB pixels, any alignment
-
-// LDS plane pitches in samples: multiples of 8 (16-byte rows for ds_read_b128), padded so that the
-// two luma block rows of an MCU do not start on the same bank
-constexpr uint32_t kPitchY = kSegMcus * 16 + 8, kPitchC = kSegMcus * 8 + 8;
-
-// RGB_TO_Y / RGB_TO_U / RGB_TO_V of colorspace.h:78-88 with the channel order folded into the weights
-struct Weights { int y0, y2, u0, u2, v0, v2; };
-
-__device__ __forceinline__ int luma(const Weights& k, int c0, int c1, int c2) {
-    return ((k.y0 * c0 + 601 * c1 + k.y2 * c2 + 512) >> 10) - 128;
-}
-__device__ __forceinline__ int chroma_u(const Weights& k, int s0, int s1, int s2) {   // 2x2 sums, shift 2
-    return (k.u0 * s0 - 339 * s1 + k.u2 * s2 + 2047) >> 12;                           // +128 -128
-}
-__device__ __forceinline__ int chroma_v(const Weights& k, int s0, int s1, int s2) {
-    return (k.v0 * s0 - 429 * s1 + k.v2 * s2 + 2047) >> 12;
-}
-
-__device__ __forceinline__ void unpack12(const Px12& v, int (&b)[12]) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) b[i] = (int)((v.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-}
-
-}  // namespace
-
-// One wave per MCU-row segment of up to kSegMcus MCUs.
-//  1. colour conversion: every lane takes 4x2-pixel patches (two unaligned 12-byte loads), writes
-//     8 luma and 2+2 chroma samples into the LDS planes.  Bitstream row k is picture row h-1-k
-//     (mjpegenc.c:462-467); rows and columns outside the picture repeat the nearest edge sample.
-//  2. one lane per 8x8 block, the block in registers: 8 row passes, DCTELEM truncation, 8 column
-//     passes, dct_quantize_c, scan order (a compile-time permutation), one 128-byte line out.
-// kYuv: the source is planar YUVJ420P, what amv_encoder itself takes (mjpegenc.c:493) -- stage 1 only copies
-// samples (level shift 128) instead of converting; everything else, edge repetition included, is the same, so
-// that rgb24_to_yuvj420p followed by this form equals the RGB form bit for bit.
+// One wave per MCU-row segment of up to kSegMcus MCUs: stage 1 (colour conversion into LDS planes) and stage 2 (one
+// 8x8 block per lane: fdct, quantise, scan order) of amv_encode_common.h, then one 128-byte line per block out.
+// What amvhip_encode_coefs_dev hands out, the serial route (AMVHIP_ENTROPY_SERIAL) and the frames
+// amv_encode_frame_kernel hands back go through here; sel: which frames (FrameSel, as in the decoder's rounds).
 template <bool kYuv>
-__global__ __launch_bounds__(kWave) void amv_forward_kernel(
-    const uint8_t* __restrict__ pix, uint32_t pix_stride, int is_bgr, YuvSource yuv, uint32_t n, FrameGeom g,
-    uint32_t nseg, uint32_t per_seg, uint32_t qbias, int16_t* __restrict__ coef) {
-    __shared__ __attribute__((aligned(16))) int16_t s_y[16 * kPitchY];
-    __shared__ __attribute__((aligned(16))) int16_t s_cb[8 * kPitchC];
-    __shared__ __attribute__((aligned(16))) int16_t s_cr[8 * kPitchC];
+__global__ __launch_bounds__(kWave) void amv_forward_kernel(Source in, uint32_t n, FrameSel sel, FrameGeom g, uint32_t nseg, uint32_t per_seg,
+                                                            uint32_t qbias, int16_t* __restrict__ coef) {
+    __shared__ __attribute__((aligned(16))) int16_t s_planes[kPlaneSamples];
+    int16_t* const s_y = s_planes;
+    int16_t* const s_cb = s_planes + 16 * kPitchY;
+    int16_t* const s_cr = s_cb + 8 * kPitchC;
 
     const uint32_t lane = threadIdx.x;
     uint32_t bid = blockIdx.x;
     const uint32_t seg = bid % nseg;
     bid /= nseg;
     const uint32_t my = bid % g.mcu_rows;
-    const uint32_t f = bid / g.mcu_rows;
+    uint32_t f = bid / g.mcu_rows, slot = f;
+    if (sel.round) {                       // item f of a round: frame list[base + f], lines in slot f
+        const uint32_t p = sel.base + f;
+        if (f >= sel.round || p >= (sel.count ? *sel.count : n)) return;
+        f = sel.list ? sel.list[p] : p;
+    }
     const uint32_t m0 = seg * per_seg;
     if (m0 >= g.mcu_cols) return;          // very wide pictures: the balanced split can leave the last segment empty
     const uint32_t cnt = min(per_seg, g.mcu_cols - m0);
     const uint32_t nb = cnt * 6;
-    const uint32_t w = g.width, h = g.height, cw = w >> 1;
-    const uint8_t* src = pix + (uint64_t)f * pix_stride * h;
-    const Weights k = is_bgr ? Weights{117, 306, 512, -173, -83, 512} : Weights{306, 117, -173, 512, 512, -83};
-
-    const uint32_t d4 = cnt * 4u, inv = (65536u + d4 - 1u) / d4;   // t / d4 == (t * inv) >> 16 for t < 8 * d4 <= 320
-    // A lane takes up to kTrips 4x2-pixel patches.  Their pixels are requested all at once (a loop that loaded and
-    // converted a patch per trip waited for memory five times in a row); the conversion follows.
-    constexpr int kTrips = 5;                                      // 8 * d4 <= 320 = 5 * 64
-    Px12 ra[kTrips], rb[kTrips];
-    if (!kYuv) {
-#pragma unroll
-        for (int it = 0; it < kTrips; ++it) {
-            const uint32_t t = lane + (uint32_t)it * kWave;
-            ra[it] = rb[it] = Px12{{0u, 0u, 0u}};
-            if (t < 8u * d4) {
-                const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
-                const uint32_t k0 = my * 16u + 2u * i2;
-                const bool inside = k0 < h;
-                const uint32_t row_a = inside ? h - 1u - k0 : 1u, row_b = inside ? h - 2u - k0 : 0u;
-                const uint32_t c = m0 * 16u + 4u * p;
-                if (c + 3u < w) {
-                    ra[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_a * pix_stride + c * 3u);
-                    rb[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_b * pix_stride + c * 3u);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < kTrips; ++it) {
-        const uint32_t t = lane + (uint32_t)it * kWave;
-        if (t >= 8u * d4) break;
-        const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
-        const uint32_t k0 = my * 16u + 2u * i2;                    // bitstream rows k0, k0 + 1
-        const bool inside = k0 < h;                                // h is even
-        const uint32_t row_a = inside ? h - 1u - k0 : 1u, row_b = inside ? h - 2u - k0 : 0u;
-        const uint32_t c = m0 * 16u + 4u * p;
-        const uint8_t* pa = src + (uint64_t)row_a * pix_stride;
-        const uint8_t* pb = src + (uint64_t)row_b * pix_stride;
-        int ya[4], yb[4], u[2], v[2];
-        if (kYuv) {
-            const uint8_t* ya_p = yuv.y + (uint64_t)f * yuv.y_frame + (uint64_t)row_a * yuv.y_stride;
-            const uint8_t* yb_p = yuv.y + (uint64_t)f * yuv.y_frame + (uint64_t)row_b * yuv.y_stride;
-            const uint64_t co = (uint64_t)f * yuv.c_frame + (uint64_t)(row_b >> 1) * yuv.c_stride;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t x = min(c + (uint32_t)q, w - 1u);
-                ya[q] = (int)ya_p[x] - 128;
-                yb[q] = (int)yb_p[x] - 128;
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const uint32_t x = min((c >> 1) + (uint32_t)e, cw - 1u);
-                u[e] = (int)yuv.cb[co + x] - 128;
-                v[e] = (int)yuv.cr[co + x] - 128;
-            }
-        } else if (c + 3u < w) {
-            int a[12], b[12];
-            unpack12(ra[it], a);
-            unpack12(rb[it], b);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ya[q] = luma(k, a[3 * q], a[3 * q + 1], a[3 * q + 2]);
-                yb[q] = luma(k, b[3 * q], b[3 * q + 1], b[3 * q + 2]);
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int s0 = a[6 * e] + a[6 * e + 3] + b[6 * e] + b[6 * e + 3];
-                const int s1 = a[6 * e + 1] + a[6 * e + 4] + b[6 * e + 1] + b[6 * e + 4];
-                const int s2 = a[6 * e + 2] + a[6 * e + 5] + b[6 * e + 2] + b[6 * e + 5];
-                u[e] = chroma_u(k, s0, s1, s2);
-                v[e] = chroma_v(k, s0, s1, s2);
-            }
-        } else {                                                   // right edge of a picture whose width is not 0 mod 16
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t x = min(c + (uint32_t)q, w - 1u) * 3u;
-                ya[q] = luma(k, pa[x], pa[x + 1], pa[x + 2]);
-                yb[q] = luma(k, pb[x], pb[x + 1], pb[x + 2]);
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const uint32_t x = min((c >> 1) + (uint32_t)e, cw - 1u) * 6u;
-                const int s0 = pa[x] + pa[x + 3] + pb[x] + pb[x + 3];
-                const int s1 = pa[x + 1] + pa[x + 4] + pb[x + 1] + pb[x + 4];
-                const int s2 = pa[x + 2] + pa[x + 5] + pb[x + 2] + pb[x + 5];
-                u[e] = chroma_u(k, s0, s1, s2);
-                v[e] = chroma_v(k, s0, s1, s2);
-            }
-        }
-        if (!inside) {                                             // below the picture: luma repeats picture row 0
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ya[q] = yb[q];
-        }
-        uint2 la, lb;
-        la.x = ((uint32_t)ya[0] & 0xffffu) | ((uint32_t)ya[1] << 16);
-        la.y = ((uint32_t)ya[2] & 0xffffu) | ((uint32_t)ya[3] << 16);
-        lb.x = ((uint32_t)yb[0] & 0xffffu) | ((uint32_t)yb[1] << 16);
-        lb.y = ((uint32_t)yb[2] & 0xffffu) | ((uint32_t)yb[3] << 16);
-        *reinterpret_cast<uint2*>(s_y + (2u * i2) * kPitchY + 4u * p) = la;
-        *reinterpret_cast<uint2*>(s_y + (2u * i2 + 1u) * kPitchY + 4u * p) = lb;
-        *reinterpret_cast<uint32_t*>(s_cb + i2 * kPitchC + 2u * p) = ((uint32_t)u[0] & 0xffffu) | ((uint32_t)u[1] << 16);
-        *reinterpret_cast<uint32_t*>(s_cr + i2 * kPitchC + 2u * p) = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
-    }
+    convert_segment<kYuv>(in, f, g, my, m0, cnt, lane, s_y, s_cb, s_cr);
     __syncthreads();
     if (lane >= nb) return;
-
-    const uint32_t m = lane / 6u, k6 = lane - 6u * m;
-    const bool is_c = k6 >= 4u;
-    const int16_t* in = is_c ? (k6 == 4u ? s_cb : s_cr) + m * 8u
-                             : s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u;
-    const uint32_t pitch = is_c ? kPitchC : kPitchY;
-    int d[8][8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {                                  // get_pixels + row_fdct
-        const uint4 q = *reinterpret_cast<const uint4*>(in + r * pitch);
-        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) d[r][c] = (c & 1) ? ((int)ws[c >> 1] >> 16) : (int)(int16_t)(ws[c >> 1] & 0xffffu);
-        fdct8<0>(d[r]);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) d[r][c] = (int16_t)d[r][c];    // DCTELEM is 16 bit (dsputil.h:38)
-    }
-    const int bias = (int)(qbias << 14);   // intra_quant_bias << (QMAT_SHIFT - QUANT_BIAS_SHIFT), :3679
-    uint32_t out[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) out[i] = 0u;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {                                  // column pass + dct_quantize_c
-        int col[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) col[r] = d[r][c];
-        fdct8<1>(col);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int scan = kScanOfNatural[r * 8 + c];
-            const int x = (int16_t)col[r];
-            int a;
-            if (r == 0 && c == 0) {        // DC: (block[0] + q/2) / q with q = 8 * step, :3670-3676
-                constexpr int ql = 8 * kQuantLuma[0], qc = 8 * kQuantChroma[0];
-                const int ax = abs(x);
-                a = is_c ? (ax + (qc >> 1)) / qc : (ax + (ql >> 1)) / ql;
-            } else {                       // AC: (bias + |level|) >> QMAT_SHIFT with ff_convert_matrix's
-                                           // (1<<22)/(8*Q) (mpegvideo_enc.c:80-91, qscale 8), :3702-3712
-                const int ml = (int)((1u << 22) / (8u * kQuantLuma[scan])), mc = (int)((1u << 22) / (8u * kQuantChroma[scan]));
-                const int level = x * (is_c ? mc : ml);
-                a = (abs(level) + bias) >> 22;
-            }
-            const uint32_t val = (uint32_t)(x < 0 ? -a : a) & 0xffffu;
-            out[scan >> 1] |= val << (16 * (scan & 1));
-        }
-    }
-    uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)f * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u + lane * 64u);
+    uint32_t out[32], nz_lo, nz_hi;
+    transform_block(s_y, s_cb, s_cr, lane, qbias, out, nz_lo, nz_hi);
+    uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)slot * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u + lane * 64u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
 }
 
-void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n,
-                    const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s) {
-    if (n == 0) return;
+static void launch_forward_any(const Source& in, bool yuv, uint32_t n, const FrameSel& sel, uint32_t items, const FrameGeom& g,
+                               uint32_t qbias, int16_t* coef, hipStream_t s) {
+    if (items == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
     const uint32_t per_seg = (g.mcu_cols + nseg - 1) / nseg;      // balanced: 11 columns -> 6 + 5
-    const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
-    hipLaunchKernelGGL(amv_forward_kernel<false>, dim3((uint32_t)grid), dim3(kWave), 0, s, pix, pix_stride,
-                       is_bgr, YuvSource{}, n, g, nseg, per_seg, qbias, coef);
+    const uint64_t grid = (uint64_t)items * g.mcu_rows * nseg;
+    if (yuv)
+        hipLaunchKernelGGL(amv_forward_kernel<true>, dim3((uint32_t)grid), dim3(kWave), 0, s, in, n, sel, g, nseg, per_seg, qbias, coef);
+    else
+        hipLaunchKernelGGL(amv_forward_kernel<false>, dim3((uint32_t)grid), dim3(kWave), 0, s, in, n, sel, g, nseg, per_seg, qbias, coef);
 }
 
-void launch_forward_yuv(const YuvSource& src, uint32_t n, const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s) {
-    if (n == 0) return;
-    const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
-    const uint32_t per_seg = (g.mcu_cols + nseg - 1) / nseg;
-    const uint64_t grid = (uint64_t)n * g.mcu_rows * nseg;
-    hipLaunchKernelGGL(amv_forward_kernel<true>, dim3((uint32_t)grid), dim3(kWave), 0, s, (const uint8_t*)nullptr, 0u,
-                       0, src, n, g, nseg, per_seg, qbias, coef);
+void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n, const FrameSel& sel, uint32_t items,
+                    const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s) {
+    launch_forward_any(Source{pix, pix_stride, is_bgr, YuvSource{}}, false, n, sel, items, g, qbias, coef, s);
+}
+
+void launch_forward_yuv(const YuvSource& src, uint32_t n, const FrameSel& sel, uint32_t items, const FrameGeom& g, uint32_t qbias,
+                        int16_t* coef, hipStream_t s) {
+    launch_forward_any(Source{nullptr, 0u, 0, src}, true, n, sel, items, g, qbias, coef, s);
 }
 
 // ============================================================================================
@@ -332,27 +120,27 @@ __device__ __forceinline__ void put_coef(BitWriter& w, const uint32_t* book, int
     put_bits(w, (int)(e >> 16) + nb, ((e & 0xffffu) << nb) | ((uint32_t)mant & ((1u << nb) - 1u)));
 }
 
-__device__ __forceinline__ uint32_t slot_offset(uint32_t lane, uint32_t k) {
-    return lane * 128u + ((((k >> 3) ^ lane) & 7u) << 4) + ((k & 7u) << 1);
-}
+__device__ __forceinline__ uint32_t slot_offset(uint32_t lane, uint32_t k) { return line_offset(lane, k); }
 
 }  // namespace
 
 __global__ __launch_bounds__(kWave) void amv_pack_kernel(
-    const int16_t* __restrict__ coef, uint32_t n, uint32_t blocks_per_frame,
+    const int16_t* __restrict__ coef, uint32_t n, FrameSel sel, uint32_t blocks_per_frame,
     const HuffEncodeImage* __restrict__ img, uint8_t* __restrict__ tmp, uint32_t bound,
-    uint32_t* __restrict__ lens, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+    uint32_t* __restrict__ lens) {
     __shared__ uint32_t s_book[4][256];
     __shared__ __attribute__((aligned(16))) uint4 s_slots[kWave * 8];
     __shared__ uint32_t s_frame[kWave];
 
-    // with a list (frames amv_pack_wave_kernel handed back): frames list[0 .. *list_count)
+    // default: frames 0 .. n, a frame's lines at its own place.  A round (frames amv_encode_frame_kernel handed back):
+    // items base .. base + round, item p = frame list[p] (p < *count), lines in slot p - base.
     const uint32_t lane = threadIdx.x;
     const uint32_t f0 = blockIdx.x * kWave;
-    if (list) n = *list_count;
-    if (f0 >= n) return;
-    const uint32_t frame = f0 + lane < n ? (list ? list[f0 + lane] : f0 + lane) : 0xffffffffu;
-    s_frame[lane] = frame;
+    const uint32_t items = sel.round ? min(sel.round, (sel.count ? *sel.count : n) > sel.base ? (sel.count ? *sel.count : n) - sel.base : 0u) : n;
+    if (f0 >= items) return;
+    const uint32_t slot = f0 + lane;
+    const uint32_t frame = slot < items ? (sel.round ? (sel.list ? sel.list[sel.base + slot] : sel.base + slot) : slot) : 0xffffffffu;
+    s_frame[lane] = slot < items ? slot : 0xffffffffu;
     const bool live = frame != 0xffffffffu;
     for (int i = lane; i < 4 * 256; i += kWave) (&s_book[0][0])[i] = (&img->code[0][0])[i];
 
@@ -409,13 +197,11 @@ __global__ __launch_bounds__(kWave) void amv_pack_kernel(
     }
 }
 
-void launch_pack(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img,
-                 uint8_t* tmp, uint32_t bound, uint32_t* lens, const uint32_t* list, const uint32_t* list_count,
-                 hipStream_t s) {
-    if (n == 0) return;
-    const uint32_t grid = (n + kWave - 1) / kWave;   // with a list: upper bound, surplus groups exit at once
-    hipLaunchKernelGGL(amv_pack_kernel, dim3(grid), dim3(kWave), 0, s, coef, n, g.blocks, d_img, tmp,
-                       bound, lens, list, list_count);
+void launch_pack(const int16_t* coef, uint32_t n, const FrameSel& sel, uint32_t items, const FrameGeom& g,
+                 const HuffEncodeImage* d_img, uint8_t* tmp, uint32_t bound, uint32_t* lens, hipStream_t s) {
+    if (items == 0) return;
+    const uint32_t grid = (items + kWave - 1) / kWave;   // a round: upper bound, surplus groups exit at once
+    hipLaunchKernelGGL(amv_pack_kernel, dim3(grid), dim3(kWave), 0, s, coef, n, sel, g.blocks, d_img, tmp, bound, lens);
 }
 
 // ============================================================================================

@@ -1,0 +1,281 @@
+// amv_encode_common.h -- the front half of the AMV video encoder as device functions: what amv_forward_kernel
+// (dense coefficient lines out) and amv_encode_frame_kernel (coefficients never leave the chip) both run.
+//
+// Reference path: AMVmuxer/ffmpeg (lavc = libavcodec):
+//   RGB24 -> YUVJ420P          lavc/imgconvert_template.h:654-, colorspace.h:30-97
+//   vertical flip              lavc/mjpegenc.c:454-472 (amv_encode_picture)
+//   forward DCT                lavc/jfdctint.c:184-343 (ff_jpeg_fdct_islow)
+//   quantise                   lavc/mpegvideo_enc.c:3647-3724 (dct_quantize_c), :70-91, :492-496
+// The reference encoder quantises with a matrix no AMV decoder uses; this one uses amvlib's
+// fixed tables (AmvJpeg.c:30-61) and a true -128 level shift so that amvlib and the patched FFmpeg both decode it.
+#pragma once
+#include "amv_kernels.h"
+
+namespace amv {
+namespace enc {
+
+constexpr int kWave = 64;
+constexpr int kSegMcus = 10;
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// One 8-point LL&M pass of jfdctint.c: kPass 0 = row_fdct (:184-258), 1 = column pass (:273-341)
+template <int kPass>
+__device__ __forceinline__ void fdct8(int (&d)[8]) {
+    constexpr int kConstBits = 13, kPass1Bits = 4;
+    constexpr int kShift = kPass == 0 ? kConstBits - kPass1Bits : kConstBits + kPass1Bits;
+    const int t0 = d[0] + d[7], t7 = d[0] - d[7];
+    const int t1 = d[1] + d[6], t6 = d[1] - d[6];
+    const int t2 = d[2] + d[5], t5 = d[2] - d[5];
+    const int t3 = d[3] + d[4], t4 = d[3] - d[4];
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    if (kPass == 0) {
+        d[0] = (t10 + t11) << kPass1Bits;
+        d[4] = (t10 - t11) << kPass1Bits;
+    } else {
+        d[0] = descale(t10 + t11, kPass1Bits);
+        d[4] = descale(t10 - t11, kPass1Bits);
+    }
+    int z1 = (t12 + t13) * 4433;
+    d[2] = descale(z1 + t13 * 6270, kShift);
+    d[6] = descale(z1 - t12 * 15137, kShift);
+    z1 = t4 + t7;
+    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    const int z5 = (z3 + z4) * 9633;
+    const int u4 = t4 * 2446, u5 = t5 * 16819, u6 = t6 * 25172, u7 = t7 * 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 = z3 * -16069 + z5;
+    z4 = z4 * -3196 + z5;
+    d[7] = descale(u4 + z1 + z3, kShift);
+    d[5] = descale(u5 + z2 + z4, kShift);
+    d[3] = descale(u6 + z2 + z3, kShift);
+    d[1] = descale(u7 + z1 + z4, kShift);
+}
+
+struct __attribute__((packed, aligned(1))) Px12 { uint32_t w[3]; };   // four RGB pixels, any alignment
+
+// LDS plane pitches in samples: multiples of 8 (16-byte rows for ds_read_b128), padded so that the
+// two luma block rows of an MCU do not start on the same bank
+constexpr uint32_t kPitchY = kSegMcus * 16 + 8, kPitchC = kSegMcus * 8 + 8;
+// a segment's planes: Y (16 rows), Cb, Cr (8 rows each), int16 -- 8 192 bytes, which is also 64 coefficient lines
+constexpr uint32_t kPlaneSamples = 16 * kPitchY + 2 * 8 * kPitchC;
+static_assert(kPlaneSamples * 2 == 64 * 128, "a segment's planes and its 64 coefficient lines share one LDS region");
+
+// RGB_TO_Y / RGB_TO_U / RGB_TO_V of colorspace.h:78-88 with the channel order folded into the weights
+struct Weights { int y0, y2, u0, u2, v0, v2; };
+
+__device__ __forceinline__ int luma(const Weights& k, int c0, int c1, int c2) {
+    return ((k.y0 * c0 + 601 * c1 + k.y2 * c2 + 512) >> 10) - 128;
+}
+__device__ __forceinline__ int chroma_u(const Weights& k, int s0, int s1, int s2) {   // 2x2 sums, shift 2
+    return (k.u0 * s0 - 339 * s1 + k.u2 * s2 + 2047) >> 12;                           // +128 -128
+}
+__device__ __forceinline__ int chroma_v(const Weights& k, int s0, int s1, int s2) {
+    return (k.v0 * s0 - 429 * s1 + k.v2 * s2 + 2047) >> 12;
+}
+
+__device__ __forceinline__ void unpack12(const Px12& v, int (&b)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) b[i] = (int)((v.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+}
+
+struct Source {           // where a frame's pixels are
+    const uint8_t* pix;   // RGB24 / BGR24 frames, rows pix_stride apart (kYuv == false)
+    uint32_t pix_stride;
+    int is_bgr;
+    YuvSource yuv;        // planar YUVJ420P (kYuv == true)
+};
+
+// Stage 1 of a segment (MCU row `my`, MCUs m0 .. m0 + cnt) of frame f: colour conversion of 4x2-pixel patches (two
+// unaligned 12-byte loads each) into the LDS planes -- 8 luma and 2 + 2 chroma samples per patch.  Bitstream row k is
+// picture row h-1-k (mjpegenc.c:462-467); rows and columns outside the picture repeat the nearest edge sample.
+// kYuv: the source is planar YUVJ420P, what amv_encoder itself takes (mjpegenc.c:493) -- samples are copied (level shift
+// 128) instead of converted; everything else, edge repetition included, is the same, so that rgb24_to_yuvj420p followed
+// by this form equals the RGB form bit for bit.  The caller synchronises the wave before the planes are read.
+template <bool kYuv>
+__device__ __forceinline__ void convert_segment(const Source& in, uint32_t f, const FrameGeom& g, uint32_t my, uint32_t m0, uint32_t cnt,
+                                                uint32_t lane, int16_t* s_y, int16_t* s_cb, int16_t* s_cr) {
+    const uint32_t w = g.width, h = g.height, cw = w >> 1;
+    const uint8_t* src = in.pix + (uint64_t)f * in.pix_stride * h;
+    const uint32_t pix_stride = in.pix_stride;
+    const YuvSource& yuv = in.yuv;
+    const Weights k = in.is_bgr ? Weights{117, 306, 512, -173, -83, 512} : Weights{306, 117, -173, 512, 512, -83};
+
+    const uint32_t d4 = cnt * 4u, inv = (65536u + d4 - 1u) / d4;   // t / d4 == (t * inv) >> 16 for t < 8 * d4 <= 320
+    // A lane takes up to kTrips 4x2-pixel patches.  Their pixels are requested all at once (a loop that loaded and
+    // converted a patch per trip waited for memory five times in a row); the conversion follows.
+    constexpr int kTrips = 5;                                      // 8 * d4 <= 320 = 5 * 64
+    Px12 ra[kTrips], rb[kTrips];
+    if (!kYuv) {
+#pragma unroll
+        for (int it = 0; it < kTrips; ++it) {
+            const uint32_t t = lane + (uint32_t)it * kWave;
+            ra[it] = rb[it] = Px12{{0u, 0u, 0u}};
+            if (t < 8u * d4) {
+                const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
+                const uint32_t k0 = my * 16u + 2u * i2;
+                const bool inside = k0 < h;
+                const uint32_t row_a = inside ? h - 1u - k0 : 1u, row_b = inside ? h - 2u - k0 : 0u;
+                const uint32_t c = m0 * 16u + 4u * p;
+                if (c + 3u < w) {
+                    ra[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_a * pix_stride + c * 3u);
+                    rb[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_b * pix_stride + c * 3u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kTrips; ++it) {
+        const uint32_t t = lane + (uint32_t)it * kWave;
+        if (t >= 8u * d4) break;
+        const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
+        const uint32_t k0 = my * 16u + 2u * i2;                    // bitstream rows k0, k0 + 1
+        const bool inside = k0 < h;                                // h is even
+        const uint32_t row_a = inside ? h - 1u - k0 : 1u, row_b = inside ? h - 2u - k0 : 0u;
+        const uint32_t c = m0 * 16u + 4u * p;
+        const uint8_t* pa = src + (uint64_t)row_a * pix_stride;
+        const uint8_t* pb = src + (uint64_t)row_b * pix_stride;
+        int ya[4], yb[4], u[2], v[2];
+        if (kYuv) {
+            const uint8_t* ya_p = yuv.y + (uint64_t)f * yuv.y_frame + (uint64_t)row_a * yuv.y_stride;
+            const uint8_t* yb_p = yuv.y + (uint64_t)f * yuv.y_frame + (uint64_t)row_b * yuv.y_stride;
+            const uint64_t co = (uint64_t)f * yuv.c_frame + (uint64_t)(row_b >> 1) * yuv.c_stride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = min(c + (uint32_t)q, w - 1u);
+                ya[q] = (int)ya_p[x] - 128;
+                yb[q] = (int)yb_p[x] - 128;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t x = min((c >> 1) + (uint32_t)e, cw - 1u);
+                u[e] = (int)yuv.cb[co + x] - 128;
+                v[e] = (int)yuv.cr[co + x] - 128;
+            }
+        } else if (c + 3u < w) {
+            int a[12], b[12];
+            unpack12(ra[it], a);
+            unpack12(rb[it], b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ya[q] = luma(k, a[3 * q], a[3 * q + 1], a[3 * q + 2]);
+                yb[q] = luma(k, b[3 * q], b[3 * q + 1], b[3 * q + 2]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int s0 = a[6 * e] + a[6 * e + 3] + b[6 * e] + b[6 * e + 3];
+                const int s1 = a[6 * e + 1] + a[6 * e + 4] + b[6 * e + 1] + b[6 * e + 4];
+                const int s2 = a[6 * e + 2] + a[6 * e + 5] + b[6 * e + 2] + b[6 * e + 5];
+                u[e] = chroma_u(k, s0, s1, s2);
+                v[e] = chroma_v(k, s0, s1, s2);
+            }
+        } else {                                                   // right edge of a picture whose width is not 0 mod 16
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = min(c + (uint32_t)q, w - 1u) * 3u;
+                ya[q] = luma(k, pa[x], pa[x + 1], pa[x + 2]);
+                yb[q] = luma(k, pb[x], pb[x + 1], pb[x + 2]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t x = min((c >> 1) + (uint32_t)e, cw - 1u) * 6u;
+                const int s0 = pa[x] + pa[x + 3] + pb[x] + pb[x + 3];
+                const int s1 = pa[x + 1] + pa[x + 4] + pb[x + 1] + pb[x + 4];
+                const int s2 = pa[x + 2] + pa[x + 5] + pb[x + 2] + pb[x + 5];
+                u[e] = chroma_u(k, s0, s1, s2);
+                v[e] = chroma_v(k, s0, s1, s2);
+            }
+        }
+        if (!inside) {                                             // below the picture: luma repeats picture row 0
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ya[q] = yb[q];
+        }
+        uint2 la, lb;
+        la.x = ((uint32_t)ya[0] & 0xffffu) | ((uint32_t)ya[1] << 16);
+        la.y = ((uint32_t)ya[2] & 0xffffu) | ((uint32_t)ya[3] << 16);
+        lb.x = ((uint32_t)yb[0] & 0xffffu) | ((uint32_t)yb[1] << 16);
+        lb.y = ((uint32_t)yb[2] & 0xffffu) | ((uint32_t)yb[3] << 16);
+        *reinterpret_cast<uint2*>(s_y + (2u * i2) * kPitchY + 4u * p) = la;
+        *reinterpret_cast<uint2*>(s_y + (2u * i2 + 1u) * kPitchY + 4u * p) = lb;
+        *reinterpret_cast<uint32_t*>(s_cb + i2 * kPitchC + 2u * p) = ((uint32_t)u[0] & 0xffffu) | ((uint32_t)u[1] << 16);
+        *reinterpret_cast<uint32_t*>(s_cr + i2 * kPitchC + 2u * p) = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+    }
+}
+
+constexpr int natural_of_scan(int scan) {
+    for (int nat = 0; nat < 64; ++nat)
+        if (kScanOfNatural[nat] == scan) return nat;
+    return 0;
+}
+
+// Stage 2: lane's block (lane = 6 * MCU in segment + block in MCU) out of the planes, in registers: 8 row passes,
+// DCTELEM truncation, 8 column passes, dct_quantize_c.  out: the 64 quantised coefficients, scan order, int16 pairs;
+// nz_lo / nz_hi: bit k set where coefficient k (scan order, k >= 1) is not zero.
+// The AC quantiser (mpegvideo_enc.c:3702-3712) is sign(x) * ((|x| * m + bias) >> 22) with m = (1 << 22) / (8 * Q)
+// (ff_convert_matrix :80-91, qscale 8); for x < 0 that is ceil((x * m - bias) / 2^22) = (x * m + (2^22 - 1 - bias)) >> 22,
+// so both signs are one multiply-add and one arithmetic shift: (x * m + (bias ^ (sign & (2^22 - 1)))) >> 22.
+// |x * m| stays under 2^31: x is an fdct output of 8-bit samples (|x| <= 2^14), m <= 2^22 / 40.
+__device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_t* s_cb, const int16_t* s_cr, uint32_t lane,
+                                                uint32_t qbias, uint32_t (&out)[32], uint32_t& nz_lo, uint32_t& nz_hi) {
+    const uint32_t m = lane / 6u, k6 = lane - 6u * m;
+    const bool is_c = k6 >= 4u;
+    const int16_t* in = is_c ? (k6 == 4u ? s_cb : s_cr) + m * 8u
+                             : s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u;
+    const uint32_t pitch = is_c ? kPitchC : kPitchY;
+    int d[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                                  // get_pixels + row_fdct
+        const uint4 q = *reinterpret_cast<const uint4*>(in + r * pitch);
+        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) d[r][c] = (c & 1) ? ((int)ws[c >> 1] >> 16) : (int)(int16_t)(ws[c >> 1] & 0xffffu);
+        fdct8<0>(d[r]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) d[r][c] = (int16_t)d[r][c];    // DCTELEM is 16 bit (dsputil.h:38)
+    }
+    const int bias = (int)(qbias << 14);   // intra_quant_bias << (QMAT_SHIFT - QUANT_BIAS_SHIFT), :3679
+    int qv[64];                            // quantised values, natural order
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                                  // column pass + dct_quantize_c
+        int col[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) col[r] = d[r][c];
+        fdct8<1>(col);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int scan = kScanOfNatural[r * 8 + c];
+            const int x = (int16_t)col[r];
+            if (r == 0 && c == 0) {        // DC: (block[0] + q/2) / q with q = 8 * step, :3670-3676
+                constexpr int ql = 8 * kQuantLuma[0], qc = 8 * kQuantChroma[0];
+                const int ax = abs(x);
+                const int a = is_c ? (ax + (qc >> 1)) / qc : (ax + (ql >> 1)) / ql;
+                qv[0] = x < 0 ? -a : a;
+            } else {
+                const int ml = (int)((1u << 22) / (8u * kQuantLuma[scan])), mc = (int)((1u << 22) / (8u * kQuantChroma[scan]));
+                const int sign = x >> 31;
+                qv[r * 8 + c] = (x * (is_c ? mc : ml) + (bias ^ (sign & 0x3fffff))) >> 22;
+            }
+        }
+    }
+    nz_lo = nz_hi = 0u;
+#pragma unroll
+    for (int scan = 63; scan >= 0; --scan) {   // the mask is shifted up as the scan goes down
+        const uint32_t bit = qv[natural_of_scan(scan)] != 0 ? 1u : 0u;
+        if (scan >= 32) nz_hi = nz_hi + nz_hi + bit;
+        else nz_lo = nz_lo + nz_lo + bit;
+    }
+    nz_lo &= ~1u;                              // the DC coefficient is not a run/size symbol
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        out[i] = ((uint32_t)qv[natural_of_scan(2 * i)] & 0xffffu) | ((uint32_t)qv[natural_of_scan(2 * i + 1)] << 16);
+}
+
+// coefficient k of lane `lane`'s 128-byte line in an LDS region of 64 lines: 16-byte granules XOR-swizzled by lane, so
+// that lanes reading the same granule of their own lines do not meet on banks
+__device__ __forceinline__ uint32_t line_offset(uint32_t lane, uint32_t k) {
+    return lane * 128u + ((((k >> 3) ^ lane) & 7u) << 4) + ((k & 7u) << 1);
+}
+
+}  // namespace enc
+}  // namespace amv

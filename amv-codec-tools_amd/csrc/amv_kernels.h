@@ -78,10 +78,7 @@ void launch_reconstruct_yuv(const SyncSinks& sinks, const uint32_t* nmcu_ok, uin
 bool yuv_store_covers_planes(const FrameGeom& g);
 
 // ---- encode -------------------------------------------------------------------------------
-// colour conversion + level shift + forward DCT + quantise: coef [n][blocks][64] int16 scan order
-void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n,
-                    const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s);
-// the same from planar YUVJ420P (what the reference's amv_encoder takes, mjpegenc.c:493): frame i's planes at
+// planar YUVJ420P source (what the reference's amv_encoder takes, mjpegenc.c:493): frame i's planes at
 // y + i*y_frame, cb/cr + i*c_frame (bytes); rows y_stride / c_stride apart
 struct YuvSource {
     const uint8_t* y;
@@ -90,15 +87,22 @@ struct YuvSource {
     uint32_t y_stride, c_stride;
     uint64_t y_frame, c_frame;
 };
-void launch_forward_yuv(const YuvSource& src, uint32_t n, const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s);
-// entropy coder: one lane per frame, writes FFD8 + escaped scan + FFD9 into tmp[i*bound..]
-void launch_pack(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img,
-                 uint8_t* tmp, uint32_t bound, uint32_t* lens, const uint32_t* list, const uint32_t* list_count,
-                 hipStream_t s);
-// entropy coder, one wave per frame (amv_encode_par.hip); frames whose bit string does not fit its LDS
-// window are appended to retry_list for launch_pack(list).  false: geometry too large, use launch_pack.
-bool launch_pack_wave(const int16_t* coef, uint32_t n, const FrameGeom& g, const HuffEncodeImage* d_img, uint8_t* tmp,
-                      uint32_t bound, uint32_t* lens, uint32_t* retry_list, uint32_t* retry_count, hipStream_t s);
+// The whole encoder, one workgroup per frame (amv_encode_par.hip): pixels (RGB24/BGR24, or *yuv when not null) ->
+// FF D8 + escaped scan + FF D9 in tmp[i*bound..], lens[i].  Frames whose bits do not fit the kernel's LDS window are
+// appended to retry_list / *retry_count for launch_forward + launch_pack (rounds).
+void launch_encode_frames(const uint8_t* pix, uint32_t pix_stride, int is_bgr, const YuvSource* yuv, uint32_t n, const FrameGeom& g,
+                          uint32_t qbias, const HuffEncodeImage* d_img, uint8_t* tmp, uint32_t bound, uint32_t* lens,
+                          uint32_t* retry_list, uint32_t* retry_count, hipStream_t s);
+// The two-stage route (amv_encode.hip).  colour conversion + level shift + forward DCT + quantise -> dense lines
+// coef [..][blocks][64] int16 scan order; entropy coder, one lane per frame -> tmp[frame*bound..], lens[frame].
+// sel: default (round == 0) = frames 0 .. n with lines at the frame's own place; round = items base .. base + round,
+// item p = frame list[p] (p < *count), lines in slot p - base.  items: upper bound of the work (grid size).
+void launch_forward(const uint8_t* pix, uint32_t pix_stride, int is_bgr, uint32_t n, const FrameSel& sel, uint32_t items,
+                    const FrameGeom& g, uint32_t qbias, int16_t* coef, hipStream_t s);
+void launch_forward_yuv(const YuvSource& src, uint32_t n, const FrameSel& sel, uint32_t items, const FrameGeom& g, uint32_t qbias,
+                        int16_t* coef, hipStream_t s);
+void launch_pack(const int16_t* coef, uint32_t n, const FrameSel& sel, uint32_t items, const FrameGeom& g,
+                 const HuffEncodeImage* d_img, uint8_t* tmp, uint32_t bound, uint32_t* lens, hipStream_t s);
 // exclusive scan of lens -> offs (single workgroup), then gather tmp -> blob.  A chunk that would end past
 // blob_cap is not copied and its lens entry becomes 0; *overflow = 1 when the total exceeds blob_cap.
 void launch_compact(const uint8_t* tmp, uint32_t bound, uint32_t* lens, uint32_t n,

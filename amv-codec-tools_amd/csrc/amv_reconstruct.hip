@@ -29,6 +29,10 @@ struct __attribute__((aligned(4))) Px12 { uint32_t w[3]; };   // four BGR pixels
 
 constexpr int kWave = 64;
 constexpr int kSegMcus = 10;   // MCUs per wave: 60 of 64 lanes busy in the transform
+// Waves per workgroup: four consecutive MCU rows of a frame.  The waves share nothing (a segment's LDS is its wave's);
+// the workgroup only exists so that the chip launches a quarter as many of them -- 1.28 M single-wave workgroups per
+// 160 000 frames of 160x120 cost 8 % of the kernel's time in launches (profiles/r02_launch_rate.txt).
+constexpr int kRowsPerGroup = 4;
 
 // 8-point inverse DCT of AmvJpeg.c: idctrow (:1082-1128) when kColumn == false, idctcol
 // (:1130-1175, without its final clamp) when true.  The reference's all-AC-zero shortcuts
@@ -123,20 +127,22 @@ __device__ __forceinline__ uint32_t sat_pair(uint32_t yy, uint32_t cc) {
 
 // kRound: a round launch (FrameSel::round != 0), whose workgroups walk the items of the round
 template <bool kRound>
-__global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
+__global__ __launch_bounds__(kWave * kRowsPerGroup) void amv_reconstruct_kernel(
     SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameSel sel,
     FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
     constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;   // int16 units
     // 7 680 bytes (+ the scatter's spare slots): first the records' image of the 60 blocks (128 bytes each), then the three planes
-    __shared__ __attribute__((aligned(16))) int16_t s_mem[16 * kPitchY + 2 * 8 * kPitchC + 64];
+    __shared__ __attribute__((aligned(16))) int16_t s_all[kRowsPerGroup][16 * kPitchY + 2 * 8 * kPitchC + 64];
     static_assert((16 * kPitchY + 2 * 8 * kPitchC) * 2 == kSegImageBytes, "the planes reuse the image");
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t my = blockIdx.y * kRowsPerGroup + wave, seg = blockIdx.z;   // no integer division to find them
+    if (my >= g.mcu_rows) return;                   // (the whole wave)
+    int16_t* const s_mem = s_all[wave];
     int16_t* const s_y = s_mem;
     int16_t* const s_u = s_mem + 16 * kPitchY;
     int16_t* const s_v = s_u + 8 * kPitchC;
     uint8_t* const s_img = reinterpret_cast<uint8_t*>(s_mem);
 
-    const uint32_t lane = threadIdx.x;
-    const uint32_t my = blockIdx.y, seg = blockIdx.z;   // no integer division to find them
     uint32_t qw[16];   // this lane's quantiser steps (blocks 4 and 5 of an MCU are chroma), on their way while stage A runs
     {
         const uint4* q4 = reinterpret_cast<const uint4*>(kQuantWords.w[lane % 6u >= 4u ? 1 : 0]);
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
         }
     }
     if (skip) return;   // (wave-uniform) not this launch's frame
-    __syncthreads();
+    seg_sync();
 
     // ---- D: StoreBuffer (AmvJpeg.c:789-840), straight to the frame.  A lane takes a 4x2-pixel patch: the two rows
     // share their chroma samples, whose three products (:808-810) are formed once, with luma's +128 folded in:
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_kernel(
         }
     }
     if (!kRound) return;
-    __syncthreads();   // the planes are free again
+    seg_sync();   // the planes are free again
     }   // next item of the round
 }
 
@@ -273,12 +279,13 @@ void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
     if (items == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
+    const uint32_t row_groups = (g.mcu_rows + kRowsPerGroup - 1) / kRowsPerGroup;
     if (sel.round) {
-        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, dim3(items > 512u ? 512u : items, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok,
-                           n, sel, g, nseg, flags, out);
+        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, dim3(items > 512u ? 512u : items, row_groups, nseg), dim3(kWave * kRowsPerGroup), 0, s,
+                           sinks, nmcu_ok, n, sel, g, nseg, flags, out);
     } else {
-        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, dim3(items, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok, n, sel, g, nseg,
-                           flags, out);
+        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, dim3(items, row_groups, nseg), dim3(kWave * kRowsPerGroup), 0, s, sinks, nmcu_ok, n,
+                           sel, g, nseg, flags, out);
     }
 }
 

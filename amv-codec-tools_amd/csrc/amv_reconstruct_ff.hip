@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
     }
     }
     if (!kRound) return;
-    __syncthreads();   // the image is free again
+    seg_sync();   // the image is free again
     }   // next item of the round
 }
 

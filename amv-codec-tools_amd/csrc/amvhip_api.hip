@@ -652,30 +652,51 @@ extern "C" int amvhip_encode_coefs_dev(amvhip_ctx* c, const uint8_t* d_pix, uint
     const FrameGeom g = make_geom(w, h);
     {
         Timed t(c, AMVHIP_K_FDCT, (hipStream_t)stream);
-        launch_forward(d_pix, pix_stride, is_bgr, n, g, qbias, d_coef, (hipStream_t)stream);
+        launch_forward(d_pix, pix_stride, is_bgr, n, FrameSel{nullptr, nullptr, 0u, 0u}, n, g, qbias, d_coef, (hipStream_t)stream);
     }
     return check_launch(c, "forward");
 }
 
-// entropy coding + compaction of the n frames whose coefficient lines are in c->coef (the context is locked)
-static int encode_tail(amvhip_ctx* c, uint32_t n, const FrameGeom& g, uint32_t bound, uint8_t* d_blob, uint64_t blob_cap,
-                       uint64_t* d_offs, uint32_t* d_lens, hipStream_t stream) {
+// dense coefficient lines the context keeps for frames that go through the two-stage route: a round's worth
+static uint32_t encode_round(uint32_t n) { return n <= 1024u ? n : (n / 4u > 1024u ? (n + 3u) / 4u : 1024u); }
+
+// Pixels -> chunks for n frames, RGB (yuv == nullptr) or planar YUVJ420P (the context is locked).  The one-kernel
+// encoder takes the batch; what it hands back -- and the whole batch in AMVHIP_ENTROPY_SERIAL mode -- goes through
+// amv_forward_kernel + amv_pack_kernel a round of dense lines at a time (with a list the count is on the device: the
+// rounds past it find nothing to do and leave at once -- usually all of them).
+static int encode_core(amvhip_ctx* c, const uint8_t* d_pix, uint32_t pix_stride, int is_bgr, const YuvSource* yuv, uint32_t n,
+                       const FrameGeom& g, uint32_t qbias, uint8_t* d_blob, uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens,
+                       hipStream_t stream) {
+    const uint32_t bound = amvhip_encode_bound(g.width, g.height);
+    const uint32_t round = encode_round(n);
+    if (int r = ensure(c, c->coef, (size_t)round * g.blocks * 128)) return r;
+    if (int r = ensure(c, c->tmp, (size_t)n * bound)) return r;
+    if (int r = ensure(c, c->flag, 16)) return r;
     if (int r = ensure(c, c->retry, ((size_t)n + 4) * 8)) return r;
     uint32_t* retry_count = (uint32_t*)c->retry.p;
     uint32_t* retry_list = retry_count + 8;
     HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, stream));
-    bool par = false;
-    if (c->entropy_mode != AMVHIP_ENTROPY_SERIAL) {
+    const bool fused = c->entropy_mode != AMVHIP_ENTROPY_SERIAL;
+    if (fused) {
         Timed t(c, AMVHIP_K_PACK, stream);
-        par = launch_pack_wave((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens, retry_list,
-                               retry_count, stream);
+        launch_encode_frames(d_pix, pix_stride, is_bgr, yuv, n, g, qbias, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens, retry_list,
+                             retry_count, stream);
     }
-    {   // the one-lane-per-frame coder: everything, or the frames handed back (usually none)
-        Timed t(c, AMVHIP_K_PACK_SERIAL, stream);
-        launch_pack((const int16_t*)c->coef.p, n, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens,
-                    par ? retry_list : nullptr, par ? retry_count : nullptr, stream);
+    if (int r = check_launch(c, "encode_frames")) return r;
+    for (uint32_t base = 0; base < n; base += round) {
+        const uint32_t items = n - base < round ? n - base : round;
+        const FrameSel sel{fused ? retry_list : nullptr, fused ? retry_count : nullptr, base, items};
+        {
+            Timed t(c, AMVHIP_K_FDCT, stream);
+            if (yuv) launch_forward_yuv(*yuv, n, sel, items, g, qbias, (int16_t*)c->coef.p, stream);
+            else launch_forward(d_pix, pix_stride, is_bgr, n, sel, items, g, qbias, (int16_t*)c->coef.p, stream);
+        }
+        {
+            Timed t(c, AMVHIP_K_PACK_SERIAL, stream);
+            launch_pack((const int16_t*)c->coef.p, n, sel, items, g, c->d_enc, (uint8_t*)c->tmp.p, bound, d_lens, stream);
+        }
+        if (int r = check_launch(c, "forward + pack")) return r;
     }
-    if (int r = check_launch(c, "pack")) return r;
     {
         Timed t(c, AMVHIP_K_COMPACT, stream);
         launch_compact((const uint8_t*)c->tmp.p, bound, d_lens, n, d_offs, d_blob, blob_cap, (int32_t*)c->flag.p, stream);
@@ -687,17 +708,14 @@ extern "C" int amvhip_encode_batch_dev(amvhip_ctx* c, const uint8_t* d_pix, uint
                                        uint32_t n, uint32_t w, uint32_t h, uint32_t qbias, uint8_t* d_blob,
                                        uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens, void* stream) {
     if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (w & 1) || (h & 1) || pix_stride < w * 3 || qbias > 255 || (n && !d_pix))
+        return fail(c, AMVHIP_ERR_ARG, "encode: bad argument (width/height must be even)");
     if (n && (!d_blob || !d_offs || !d_lens)) return fail(c, AMVHIP_ERR_ARG, "encode: null output");
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
-    const FrameGeom g = make_geom(w, h);
-    const uint32_t bound = amvhip_encode_bound(w, h);
     std::lock_guard<std::mutex> lk(c->mu);
-    if (int r = ensure(c, c->coef, (size_t)n * g.blocks * 128)) return r;
-    if (int r = ensure(c, c->tmp, (size_t)n * bound)) return r;
-    if (int r = ensure(c, c->flag, 16)) return r;
-    if (int r = amvhip_encode_coefs_dev(c, d_pix, pix_stride, is_bgr, n, w, h, qbias, (int16_t*)c->coef.p, stream)) return r;
-    return encode_tail(c, n, g, bound, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
+    return encode_core(c, d_pix, pix_stride, is_bgr, nullptr, n, make_geom(w, h), qbias, d_blob, blob_cap, d_offs, d_lens,
+                       (hipStream_t)stream);
 }
 
 extern "C" int amvhip_encode_yuv420_batch_dev(amvhip_ctx* c, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
@@ -711,19 +729,9 @@ extern "C" int amvhip_encode_yuv420_batch_dev(amvhip_ctx* c, const uint8_t* d_y,
         return fail(c, AMVHIP_ERR_ARG, "encode_yuv420: bad argument (width/height must be even)");
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
-    const FrameGeom g = make_geom(w, h);
-    const uint32_t bound = amvhip_encode_bound(w, h);
     std::lock_guard<std::mutex> lk(c->mu);
-    if (int r = ensure(c, c->coef, (size_t)n * g.blocks * 128)) return r;
-    if (int r = ensure(c, c->tmp, (size_t)n * bound)) return r;
-    if (int r = ensure(c, c->flag, 16)) return r;
-    {
-        Timed t(c, AMVHIP_K_FDCT, (hipStream_t)stream);
-        launch_forward_yuv(YuvSource{d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride}, n, g, qbias,
-                           (int16_t*)c->coef.p, (hipStream_t)stream);
-    }
-    if (int r = check_launch(c, "forward_yuv")) return r;
-    return encode_tail(c, n, g, bound, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
+    const YuvSource yuv{d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride};
+    return encode_core(c, nullptr, 0u, 0, &yuv, n, make_geom(w, h), qbias, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
 }
 
 // the device-to-host half of the host-buffer encoders: offs/lens, then the chunks
@@ -1242,7 +1250,7 @@ extern "C" const char* amvhip_kernel_name(int kernel) {
         case AMVHIP_K_HUFFMAN_SERIAL: return "amv_huffman_kernel";
         case AMVHIP_K_RECON: return "amv_reconstruct_kernel";
         case AMVHIP_K_FDCT: return "amv_forward_kernel";
-        case AMVHIP_K_PACK: return "amv_pack_wave_kernel";
+        case AMVHIP_K_PACK: return "amv_encode_frame_kernel";
         case AMVHIP_K_PACK_SERIAL: return "amv_pack_kernel";
         case AMVHIP_K_COMPACT: return "amv_scan_kernel+amv_gather_kernel";
         case AMVHIP_K_ADPCM_DEC: return "amv_adpcm_decode_kernel";
