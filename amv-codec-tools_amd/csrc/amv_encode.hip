@@ -41,24 +41,31 @@ __global__ __launch_bounds__(kWave) void amv_forward_kernel(Source in, uint32_t 
     const uint32_t seg = bid % nseg;
     bid /= nseg;
     const uint32_t my = bid % g.mcu_rows;
-    uint32_t f = bid / g.mcu_rows, slot = f;
-    if (sel.round) {                       // item f of a round: frame list[base + f], lines in slot f
-        const uint32_t p = sel.base + f;
-        if (f >= sel.round || p >= (sel.count ? *sel.count : n)) return;
-        f = sel.list ? sel.list[p] : p;
-    }
     const uint32_t m0 = seg * per_seg;
     if (m0 >= g.mcu_cols) return;          // very wide pictures: the balanced split can leave the last segment empty
     const uint32_t cnt = min(per_seg, g.mcu_cols - m0);
     const uint32_t nb = cnt * 6;
-    convert_segment<kYuv>(in, f, g, my, m0, cnt, lane, s_y, s_cb, s_cr);
-    __syncthreads();
-    if (lane >= nb) return;
-    uint32_t out[32], nz_lo, nz_hi;
-    transform_block(s_y, s_cb, s_cr, lane, qbias, out, nz_lo, nz_hi);
-    uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)slot * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u + lane * 64u);
+    // default: one frame per workgroup column.  A round: the launch is small (the round usually has nothing to do and
+    // the host cannot know) and its workgroups walk the round's items: item i = frame list[base + i], lines in slot i.
+    const uint32_t first = bid / g.mcu_rows, stride = gridDim.x / (g.mcu_rows * nseg);
+    uint32_t items = n;
+    if (sel.round) {
+        const uint32_t have = sel.count ? *sel.count : n;
+        items = have > sel.base ? min(sel.round, have - sel.base) : 0u;
+    }
+    for (uint32_t slot = first; slot < items; slot += stride) {
+        const uint32_t f = sel.round ? (sel.list ? sel.list[sel.base + slot] : sel.base + slot) : slot;
+        convert_segment<kYuv>(in, f, g, my, m0, cnt, lane, s_y, s_cb, s_cr);
+        __syncthreads();
+        if (lane < nb) {
+            uint32_t out[32], nz_lo, nz_hi;
+            transform_block(s_y, s_cb, s_cr, lane, qbias, out, nz_lo, nz_hi);
+            uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)slot * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u + lane * 64u);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+            for (int i = 0; i < 8; ++i) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+        }
+        __syncthreads();                   // the planes are free again
+    }
 }
 
 static void launch_forward_any(const Source& in, bool yuv, uint32_t n, const FrameSel& sel, uint32_t items, const FrameGeom& g,
@@ -66,7 +73,7 @@ static void launch_forward_any(const Source& in, bool yuv, uint32_t n, const Fra
     if (items == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
     const uint32_t per_seg = (g.mcu_cols + nseg - 1) / nseg;      // balanced: 11 columns -> 6 + 5
-    const uint64_t grid = (uint64_t)items * g.mcu_rows * nseg;
+    const uint64_t grid = (uint64_t)(sel.round && items > 64u ? 64u : items) * g.mcu_rows * nseg;
     if (yuv)
         hipLaunchKernelGGL(amv_forward_kernel<true>, dim3((uint32_t)grid), dim3(kWave), 0, s, in, n, sel, g, nseg, per_seg, qbias, coef);
     else
@@ -234,6 +241,7 @@ __global__ __launch_bounds__(256) void amv_gather_kernel(const uint8_t* __restri
                                                          uint32_t* __restrict__ lens,
                                                          const uint64_t* __restrict__ offs,
                                                          uint8_t* __restrict__ blob, uint64_t cap) {
+    struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t w[4]; };   // a chunk lands at any byte of the blob
     const uint32_t i = blockIdx.x;
     const uint32_t len = lens[i];
     const uint64_t off = offs[i];
@@ -242,7 +250,11 @@ __global__ __launch_bounds__(256) void amv_gather_kernel(const uint8_t* __restri
         return;
     }
     const uint8_t* src = tmp + (uint64_t)i * bound;
-    for (uint32_t k = threadIdx.x; k < len; k += 256) blob[off + k] = src[k];
+    uint8_t* dst = blob + off;
+    const uint32_t whole = len & ~15u;
+    for (uint32_t k = threadIdx.x * 16u; k < whole; k += 256u * 16u)
+        *reinterpret_cast<Bytes16*>(dst + k) = *reinterpret_cast<const Bytes16*>(src + k);
+    if (threadIdx.x < len - whole) dst[whole + threadIdx.x] = src[whole + threadIdx.x];
 }
 
 void launch_compact(const uint8_t* tmp, uint32_t bound, uint32_t* lens, uint32_t n,

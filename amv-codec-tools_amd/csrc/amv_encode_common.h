@@ -19,11 +19,30 @@ constexpr int kSegMcus = 10;
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
-// One 8-point LL&M pass of jfdctint.c: kPass 0 = row_fdct (:184-258), 1 = column pass (:273-341)
+// a.lo * w.lo + a.hi * w.hi + c over the 16-bit signed halves of a and w, 32-bit wrap: two of a pass's products and
+// their sum in one instruction
+constexpr uint32_t pair16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t w, int c) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(w), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) {   // the low halves of two values side by side
+    return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
+
+// One 8-point LL&M pass of jfdctint.c: kPass 0 = row_fdct (:184-258), 1 = column pass (:273-341).
+// The reference forms its outputs from shared partial products (z1 .. z5); in 32-bit wrap arithmetic each output is
+// just as well the plain linear combination of the pass's inputs those add up to -- d[7] = -11363 t4 + 9633 t5 -
+// 6436 t6 + 2260 t7 and so on (every combined weight fits 16 bits) -- which is two dot products of 16-bit pairs.
+// That needs the inputs themselves inside 16 bits: true of the whole row pass (sums of eight samples of -128..127),
+// and of the odd half of the column pass (differences of two row-pass outputs, each inside +-16384); the column
+// pass's t12, t13 are sums of four and can reach +-65536, so its d[2], d[6] keep the 32-bit form.
 template <int kPass>
 __device__ __forceinline__ void fdct8(int (&d)[8]) {
     constexpr int kConstBits = 13, kPass1Bits = 4;
     constexpr int kShift = kPass == 0 ? kConstBits - kPass1Bits : kConstBits + kPass1Bits;
+    constexpr int kHalf = 1 << (kShift - 1);          // descale's rounding term rides in the accumulator
     const int t0 = d[0] + d[7], t7 = d[0] - d[7];
     const int t1 = d[1] + d[6], t6 = d[1] - d[6];
     const int t2 = d[2] + d[5], t5 = d[2] - d[5];
@@ -32,25 +51,24 @@ __device__ __forceinline__ void fdct8(int (&d)[8]) {
     if (kPass == 0) {
         d[0] = (t10 + t11) << kPass1Bits;
         d[4] = (t10 - t11) << kPass1Bits;
+        const uint32_t e = pack16(t12, t13);
+        d[2] = dot2(e, pair16(4433, 4433 + 6270), kHalf) >> kShift;        // (t12 + t13) * 4433 + t13 * 6270
+        d[6] = dot2(e, pair16(4433 - 15137, 4433), kHalf) >> kShift;       // (t12 + t13) * 4433 - t12 * 15137
     } else {
         d[0] = descale(t10 + t11, kPass1Bits);
         d[4] = descale(t10 - t11, kPass1Bits);
+        const int z1 = (t12 + t13) * 4433;
+        d[2] = descale(z1 + t13 * 6270, kShift);
+        d[6] = descale(z1 - t12 * 15137, kShift);
     }
-    int z1 = (t12 + t13) * 4433;
-    d[2] = descale(z1 + t13 * 6270, kShift);
-    d[6] = descale(z1 - t12 * 15137, kShift);
-    z1 = t4 + t7;
-    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
-    const int z5 = (z3 + z4) * 9633;
-    const int u4 = t4 * 2446, u5 = t5 * 16819, u6 = t6 * 25172, u7 = t7 * 12299;
-    z1 *= -7373;
-    z2 *= -20995;
-    z3 = z3 * -16069 + z5;
-    z4 = z4 * -3196 + z5;
-    d[7] = descale(u4 + z1 + z3, kShift);
-    d[5] = descale(u5 + z2 + z4, kShift);
-    d[3] = descale(u6 + z2 + z3, kShift);
-    d[1] = descale(u7 + z1 + z4, kShift);
+    // z5 = (t4 + t5 + t6 + t7) * 9633; z1 = (t4 + t7) * -7373; z2 = (t5 + t6) * -20995; z3 = (t4 + t6) * -16069 + z5;
+    // z4 = (t5 + t7) * -3196 + z5; d[7] = t4 * 2446 + z1 + z3; d[5] = t5 * 16819 + z2 + z4; d[3] = t6 * 25172 + z2 + z3;
+    // d[1] = t7 * 12299 + z1 + z4
+    const uint32_t o45 = pack16(t4, t5), o67 = pack16(t6, t7);
+    d[7] = dot2(o67, pair16(-16069 + 9633, -7373 + 9633), dot2(o45, pair16(2446 - 7373 - 16069 + 9633, 9633), kHalf)) >> kShift;
+    d[5] = dot2(o67, pair16(-20995 + 9633, -3196 + 9633), dot2(o45, pair16(9633, 16819 - 20995 - 3196 + 9633), kHalf)) >> kShift;
+    d[3] = dot2(o67, pair16(25172 - 20995 - 16069 + 9633, 9633), dot2(o45, pair16(-16069 + 9633, -20995 + 9633), kHalf)) >> kShift;
+    d[1] = dot2(o67, pair16(9633, 12299 - 7373 - 3196 + 9633), dot2(o45, pair16(-7373 + 9633, -3196 + 9633), kHalf)) >> kShift;
 }
 
 struct __attribute__((packed, aligned(1))) Px12 { uint32_t w[3]; };   // four RGB pixels, any alignment
@@ -93,38 +111,44 @@ struct Source {           // where a frame's pixels are
 // kYuv: the source is planar YUVJ420P, what amv_encoder itself takes (mjpegenc.c:493) -- samples are copied (level shift
 // 128) instead of converted; everything else, edge repetition included, is the same, so that rgb24_to_yuvj420p followed
 // by this form equals the RGB form bit for bit.  The caller synchronises the wave before the planes are read.
+// In two halves: a lane takes up to kTrips patches, and load_patches requests all their pixels at once (a loop that
+// loaded and converted a patch per trip waited for memory five times in a row) -- a caller with other work in hand
+// puts it between the two.
+constexpr int kTrips = 5;                                      // 8 rows pairs x cnt * 4 patches <= 320 = 5 * 64
+struct Patches { Px12 a[kTrips], b[kTrips]; };
+
+__device__ __forceinline__ void load_patches(const Source& in, uint32_t f, const FrameGeom& g, uint32_t my, uint32_t m0, uint32_t cnt,
+                                             uint32_t lane, Patches& px) {
+    const uint32_t w = g.width, h = g.height;
+    const uint8_t* src = in.pix + (uint64_t)f * in.pix_stride * h;
+    const uint32_t d4 = cnt * 4u, inv = (65536u + d4 - 1u) / d4;   // t / d4 == (t * inv) >> 16 for t < 8 * d4 <= 320
+#pragma unroll
+    for (int it = 0; it < kTrips; ++it) {
+        const uint32_t t = lane + (uint32_t)it * kWave;
+        px.a[it] = px.b[it] = Px12{{0u, 0u, 0u}};
+        if (t < 8u * d4) {
+            const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
+            const uint32_t k0 = my * 16u + 2u * i2;
+            const bool inside = k0 < h;
+            const uint32_t row_a = inside ? h - 1u - k0 : 1u, row_b = inside ? h - 2u - k0 : 0u;
+            const uint32_t c = m0 * 16u + 4u * p;
+            if (c + 3u < w) {
+                px.a[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_a * in.pix_stride + c * 3u);
+                px.b[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_b * in.pix_stride + c * 3u);
+            }
+        }
+    }
+}
+
 template <bool kYuv>
-__device__ __forceinline__ void convert_segment(const Source& in, uint32_t f, const FrameGeom& g, uint32_t my, uint32_t m0, uint32_t cnt,
-                                                uint32_t lane, int16_t* s_y, int16_t* s_cb, int16_t* s_cr) {
+__device__ __forceinline__ void convert_patches(const Source& in, const Patches& px, uint32_t f, const FrameGeom& g, uint32_t my, uint32_t m0,
+                                                uint32_t cnt, uint32_t lane, int16_t* s_y, int16_t* s_cb, int16_t* s_cr) {
     const uint32_t w = g.width, h = g.height, cw = w >> 1;
     const uint8_t* src = in.pix + (uint64_t)f * in.pix_stride * h;
     const uint32_t pix_stride = in.pix_stride;
     const YuvSource& yuv = in.yuv;
     const Weights k = in.is_bgr ? Weights{117, 306, 512, -173, -83, 512} : Weights{306, 117, -173, 512, 512, -83};
-
-    const uint32_t d4 = cnt * 4u, inv = (65536u + d4 - 1u) / d4;   // t / d4 == (t * inv) >> 16 for t < 8 * d4 <= 320
-    // A lane takes up to kTrips 4x2-pixel patches.  Their pixels are requested all at once (a loop that loaded and
-    // converted a patch per trip waited for memory five times in a row); the conversion follows.
-    constexpr int kTrips = 5;                                      // 8 * d4 <= 320 = 5 * 64
-    Px12 ra[kTrips], rb[kTrips];
-    if (!kYuv) {
-#pragma unroll
-        for (int it = 0; it < kTrips; ++it) {
-            const uint32_t t = lane + (uint32_t)it * kWave;
-            ra[it] = rb[it] = Px12{{0u, 0u, 0u}};
-            if (t < 8u * d4) {
-                const uint32_t i2 = (t * inv) >> 16, p = t - i2 * d4;
-                const uint32_t k0 = my * 16u + 2u * i2;
-                const bool inside = k0 < h;
-                const uint32_t row_a = inside ? h - 1u - k0 : 1u, row_b = inside ? h - 2u - k0 : 0u;
-                const uint32_t c = m0 * 16u + 4u * p;
-                if (c + 3u < w) {
-                    ra[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_a * pix_stride + c * 3u);
-                    rb[it] = *reinterpret_cast<const Px12*>(src + (uint64_t)row_b * pix_stride + c * 3u);
-                }
-            }
-        }
-    }
+    const uint32_t d4 = cnt * 4u, inv = (65536u + d4 - 1u) / d4;
 #pragma unroll
     for (int it = 0; it < kTrips; ++it) {
         const uint32_t t = lane + (uint32_t)it * kWave;
@@ -155,8 +179,8 @@ __device__ __forceinline__ void convert_segment(const Source& in, uint32_t f, co
             }
         } else if (c + 3u < w) {
             int a[12], b[12];
-            unpack12(ra[it], a);
-            unpack12(rb[it], b);
+            unpack12(px.a[it], a);
+            unpack12(px.b[it], b);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 ya[q] = luma(k, a[3 * q], a[3 * q + 1], a[3 * q + 2]);
@@ -201,6 +225,14 @@ __device__ __forceinline__ void convert_segment(const Source& in, uint32_t f, co
         *reinterpret_cast<uint32_t*>(s_cb + i2 * kPitchC + 2u * p) = ((uint32_t)u[0] & 0xffffu) | ((uint32_t)u[1] << 16);
         *reinterpret_cast<uint32_t*>(s_cr + i2 * kPitchC + 2u * p) = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
     }
+}
+
+template <bool kYuv>
+__device__ __forceinline__ void convert_segment(const Source& in, uint32_t f, const FrameGeom& g, uint32_t my, uint32_t m0, uint32_t cnt,
+                                                uint32_t lane, int16_t* s_y, int16_t* s_cb, int16_t* s_cr) {
+    Patches px;
+    if (!kYuv) load_patches(in, f, g, my, m0, cnt, lane, px);
+    convert_patches<kYuv>(in, px, f, g, my, m0, cnt, lane, s_y, s_cb, s_cr);
 }
 
 constexpr int natural_of_scan(int scan) {

@@ -234,11 +234,18 @@ __global__ __launch_bounds__(kLanes, 3) void amv_encode_frame_kernel(
     uint32_t out_pos = 2;                             // bytes of the chunk written so far (FF D8 first)
     __syncthreads();
 
+    // where segment s lies, and whether there is one (very wide pictures: the balanced split can leave the last segment empty)
+    auto place = [&](uint32_t s, uint32_t& my, uint32_t& m0, uint32_t& cnt) {
+        my = s / nseg;
+        m0 = (s - my * nseg) * per_seg;
+        const bool has = s < segs && m0 < g.mcu_cols;
+        cnt = has ? min(per_seg, g.mcu_cols - m0) : 0u;
+        return has;
+    };
     for (uint32_t s0 = 0, round = 0; s0 < segs; s0 += kWaves, ++round) {
         const uint32_t s = s0 + wave;
-        const uint32_t my = s / nseg, m0 = (s - my * nseg) * per_seg;
-        const bool has_seg = s < segs && m0 < g.mcu_cols;         // (very wide pictures: the balanced split can leave the last segment empty)
-        const uint32_t cnt = has_seg ? min(per_seg, g.mcu_cols - m0) : 0u;
+        uint32_t my, m0, cnt;
+        const bool has_seg = place(s, my, m0, cnt);
         const uint32_t nb = cnt * 6u;
         const bool live = lane < nb;
         const uint32_t k6 = lane % 6u;

@@ -658,7 +658,7 @@ extern "C" int amvhip_encode_coefs_dev(amvhip_ctx* c, const uint8_t* d_pix, uint
 }
 
 // dense coefficient lines the context keeps for frames that go through the two-stage route: a round's worth
-static uint32_t encode_round(uint32_t n) { return n <= 1024u ? n : (n / 4u > 1024u ? (n + 3u) / 4u : 1024u); }
+static uint32_t encode_round(uint32_t n) { return n <= 1024u ? n : (n / 2u > 1024u ? (n + 1u) / 2u : 1024u); }
 
 // Pixels -> chunks for n frames, RGB (yuv == nullptr) or planar YUVJ420P (the context is locked).  The one-kernel
 // encoder takes the batch; what it hands back -- and the whole batch in AMVHIP_ENTROPY_SERIAL mode -- goes through
