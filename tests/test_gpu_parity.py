@@ -1448,3 +1448,52 @@ def test_adpcm_index_chain_routes(pkg, orc):
         finally:
             ctx.close()
     assert seen_exhaustive == 3 and seen_settled == 1
+
+
+def test_encode_frame_kernel_paths(ctx, pkg, orc):
+    """amv_encode_frame_kernel's less travelled paths, every chunk against the oracle's encoder: runs of symbols that
+    overflow a lane's scratch and are coded a second time straight into the round's bit string (a few noisy blocks in a
+    flat picture); frames handed back to the two-stage route from a batch larger than one fall-back round (so that rounds
+    with base > 0 run), among frames that are not; three segments per MCU row (336 wide) and an uneven split (176 wide: 6 + 5 MCUs), with the MJPEG quantiser bias."""
+    import torch
+    rng = np.random.default_rng(41)
+    # (a) flat frames with islands of noise, 320x240 (two segments per row)
+    w, h = 320, 240
+    frames = []
+    for t in range(6):
+        f = orc.synth_frame(SEED, 11 * t, w, h)
+        f[:, :] = f[h // 2, w // 2]                              # flat
+        for _ in range(1 + t):
+            y, x = int(rng.integers(0, h - 8)) & ~7, int(rng.integers(0, w - 8)) & ~7
+            f[y:y + 8, x:x + 8] = rng.integers(0, 256, (8, 8, 3))
+        frames.append(f)
+    frames.append(rng.integers(0, 256, (h, w, 3)).astype(np.uint8))   # and one the window cannot hold
+    src = np.stack(frames)
+    n = len(frames)
+    cap = ctx.encode_bound(w, h) * n
+    blob, offs, lens = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    ctx.encode_batch(src, w * 3, 0, n, w, h, 0, blob, cap, offs, lens)
+    fat = 0
+    for i in range(n):
+        want, coef = orc.encode_frame(src[i], w, h, want_coef=True)
+        assert blob[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes() == want, i
+        fat += int(((coef[:, 1:] != 0).sum(axis=1) > 40).sum())
+    assert fat >= 10                                             # blocks of > 40 coefficients: > 256 bits each
+    # (b) 1 100 small frames, every 97th one noise: two fall-back rounds, hand-backs in both
+    w, h, n = 48, 32, 1100
+    src = np.stack([orc.synth_frame(SEED, t, w, h) if t % 97 else rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for t in range(n)])
+    cap = ctx.encode_bound(w, h) * n
+    blob, offs, lens = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    ctx.encode_batch(src, w * 3, 0, n, w, h, 0, blob, cap, offs, lens)
+    for i in list(range(0, n, 97)) + [1, 2, 500, 1023, 1024, 1025, 1067, 1099]:
+        assert blob[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes() == orc.encode_frame(src[i], w, h), i
+    assert int(offs[-1]) + int(lens[-1]) == int(lens.astype(np.int64).sum())
+    # (c) 336 x 32: 21 MCU columns = segments of 7 + 7 + 7; 176 x 144: 11 = 6 + 5
+    for w, h in ((336, 32), (176, 144)):
+        src = np.stack([orc.synth_frame(SEED, 5 * t, w, h) for t in range(3)])
+        n = 3
+        cap = ctx.encode_bound(w, h) * n
+        blob, offs, lens = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+        ctx.encode_batch(src, w * 3, 0, n, w, h, 128, blob, cap, offs, lens)
+        for i in range(n):
+            assert blob[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes() == orc.encode_frame(src[i], w, h, qbias=128), (w, h, i)
