@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
                 d += (uint32_t)__builtin_popcount(k4);
             }
             total += tile_total;
+            wave_sync();                                                  // every lane's bytes are in the ring
             // whole words leave, big-endian inside the word
             const uint32_t whole = total >> 2;
             for (uint32_t x = flushed + lane; x < whole; x += kWave) {
@@ -245,10 +246,12 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
                 out[x] = __builtin_amdgcn_perm(0u, v, 0x00010203u);
             }
             flushed = whole;
+            wave_sync();                                                  // ... and the words that left are clear again
             }
         }
         // the last, partial word and zeros up to the next 16-byte boundary: the decoder copies whole 16-byte pieces
         if (!retry) {
+            wave_sync();
             const uint32_t x = flushed + lane;
             if (x < ((total + 15u) & ~15u) >> 2) out[x] = __builtin_amdgcn_perm(0u, ring[x & (kRing - 1u)], 0x00010203u);
         }
@@ -912,7 +915,9 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
         for (uint32_t i = threadIdx.x; i < kFastTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_mem != 0u) __builtin_trap();   // see lds_load
+    // lds_load takes raw LDS addresses: the dynamic segment must begin at 0.  Should a toolchain ever put something in
+    // front of it, the kernel decodes nothing and hands its frames to the serial kernel instead.
+    const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_mem == 0u;
     const uint32_t stageb = kFastTableBytes + wave * fast_stage_bytes(kFlush) + lane * 4u;
     const uint32_t sumb = kFastTableBytes + nwaves * fast_stage_bytes(kFlush) + wave * kFastSumBytes + lane * 4u;
     const uint32_t ringb = kFastTableBytes + nwaves * (fast_stage_bytes(kFlush) + kFastSumBytes) + wave * kFastRingBytes + lane * 4u;
@@ -927,8 +932,13 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
         if (task >= ntasks) return;
         const uint32_t idx = task * kWave + lane;
         const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
-        const uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+        uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+        if (!lds_at_zero && total != kNever) {
+            out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
+            total = kNever;
+        }
         if (frame != kNever && total == kNever) out.rec_count[frame] = kNever;
+        if (!lds_at_zero) continue;
         const bool live = total != kNever;
         const uint32_t fsafe = live ? frame : 0u;
         uint32_t* const rec = out.rec + (uint64_t)fsafe * out.cap_rec;
@@ -1061,7 +1071,9 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
         for (uint32_t i = threadIdx.x; i < kFastTableBytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();   // the only workgroup-wide barrier; from here the waves are on their own
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_mem != 0u) __builtin_trap();   // see lds_load
+    // lds_load takes raw LDS addresses: the dynamic segment must begin at 0.  Should a toolchain ever put something in
+    // front of it, the kernel decodes nothing and hands its frames to the serial kernel instead.
+    const bool lds_at_zero = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_mem == 0u;
     const uint32_t stageb = kFastTableBytes + wave * fast_stage_bytes(kFlush) + lane * 4u;
     const uint32_t sumb = kFastTableBytes + nwaves * fast_stage_bytes(kFlush) + wave * kFastSumBytes + lane * 4u;
     const uint32_t ringb = kFastTableBytes + nwaves * (fast_stage_bytes(kFlush) + kFastSumBytes) + wave * kFastRingBytes + lane * 4u;
@@ -1081,8 +1093,13 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
 
         const uint32_t idx = task * kFrames + slot;
         const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
-        const uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+        uint32_t total = frame != kNever ? ws_bytes[frame] : kNever;   // kNever: handed to the serial kernel
+        if (!lds_at_zero && total != kNever) {
+            if (sub == 0) out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
+            total = kNever;
+        }
         if (frame != kNever && total == kNever && sub == 0) out.rec_count[frame] = kNever;
+        if (!lds_at_zero) continue;
         const bool live = total != kNever;
         const uint32_t fsafe = live ? frame : 0u;
         uint32_t* const rec = out.rec + (uint64_t)fsafe * out.cap_rec;

@@ -64,7 +64,8 @@ struct amvhip_ctx {
     std::vector<hipEvent_t> pool;
     uint64_t launches[AMVHIP_K_COUNT] = {};
     double total_ms[AMVHIP_K_COUNT] = {};
-    std::mutex mu;
+    std::mutex mu;    // the kernels' workspace: one _dev call enqueues at a time
+    std::mutex hmu;   // the host-buffer staging (h_*, a_*): one host-buffer call at a time; taken before mu, never after
 };
 
 namespace {
@@ -591,6 +592,9 @@ extern "C" int amvhip_decode_batch_async(amvhip_ctx* c, const uint8_t* blob, uin
     hipStream_t st;
     if (int r = host_stream(c, &st)) return r;
     const uint64_t fb = (flags & AMVHIP_FLAG_FFMPEG) ? amvhip_yuv420_frame_bytes(w, h) : amvhip_frame_bytes(w, h);
+    // the staging buffers belong to the context: one host-buffer call at a time grows and fills them (hmu orders the
+    // host-buffer entry points among themselves; mu, taken inside the _dev calls, orders the kernels' workspace)
+    std::lock_guard<std::mutex> hlk(c->hmu);
     if (int r = ensure(c, c->h_in, blob_bytes + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
@@ -759,6 +763,7 @@ extern "C" int amvhip_encode_batch(amvhip_ctx* c, const uint8_t* pix, uint32_t p
     hipStream_t hs;
     if (int r = host_stream(c, &hs)) return r;
     const size_t in_bytes = (size_t)pix_stride * h * n;
+    std::lock_guard<std::mutex> hlk(c->hmu);   // the staging buffers: one host-buffer call at a time
     if (int r = ensure(c, c->h_in, in_bytes)) return r;
     if (int r = ensure(c, c->h_out, blob_cap + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
@@ -785,6 +790,7 @@ extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const
     // staged tight: Y w*h, Cb, Cr (w/2 x h/2) per frame
     const uint32_t cw = w / 2, chh = h / 2;
     const uint64_t fb = (uint64_t)w * h + 2ull * cw * chh;
+    std::lock_guard<std::mutex> hlk(c->hmu);   // the staging buffers: one host-buffer call at a time
     if (int r = ensure(c, c->h_in, fb * n)) return r;
     if (int r = ensure(c, c->h_out, blob_cap + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
@@ -862,22 +868,21 @@ extern "C" int amvhip_encode_yuv420_scaled_batch_dev(amvhip_ctx* c, const uint8_
                                                      uint32_t w, uint32_t h, uint32_t qbias, uint8_t* d_blob, uint64_t blob_cap,
                                                      uint64_t* d_offs, uint32_t* d_lens, void* stream) {
     if (!c) return AMVHIP_ERR_ARG;
-    if ((w & 1) || (h & 1)) return fail(c, AMVHIP_ERR_ARG, "encode_scaled: width/height must be even");
+    if (!size_ok(w, h) || !size_ok(src_w, src_h) || (w & 1) || (h & 1) || qbias > 255 || (n && (!d_blob || !d_offs || !d_lens)))
+        return fail(c, AMVHIP_ERR_ARG, "encode_scaled: bad argument (width/height must be even)");
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
     const uint64_t fb = (uint64_t)w * h + 2ull * (w / 2) * (h / 2);
-    uint8_t* p;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        if (int r = ensure(c, c->scaled, fb * n)) return r;
-        p = (uint8_t*)c->scaled.p;
-    }
+    // the rescaled planes are the context's: the lock is held from their allocation to the last launch that reads them
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int r = ensure(c, c->scaled, fb * n)) return r;
+    uint8_t* p = (uint8_t*)c->scaled.p;
     if (int r = amvhip_resample_yuv420_dev(c, d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride, src_w, src_h, p,
                                            p + (uint64_t)w * h, p + (uint64_t)w * h + (uint64_t)(w / 2) * (h / 2), w, w / 2, fb, fb, w, h,
                                            n, stream))
         return r;
-    return amvhip_encode_yuv420_batch_dev(c, p, p + (uint64_t)w * h, p + (uint64_t)w * h + (uint64_t)(w / 2) * (h / 2), w, w / 2, fb, fb, n,
-                                          w, h, qbias, d_blob, blob_cap, d_offs, d_lens, stream);
+    const YuvSource yuv{p, p + (uint64_t)w * h, p + (uint64_t)w * h + (uint64_t)(w / 2) * (h / 2), w, w / 2, fb, fb};
+    return encode_core(c, nullptr, 0u, 0, &yuv, n, make_geom(w, h), qbias, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
 }
 
 // =============================================================================================
@@ -961,6 +966,7 @@ extern "C" int amvhip_adpcm_decode_batch_async(amvhip_ctx* c, const uint8_t* blo
     if (int r = host_stream(c, &st)) return r;
     // audio staging sits behind the video staging of the same stream: separate buffers, so that a video batch and the
     // audio batch that travels with it can both be in flight
+    std::lock_guard<std::mutex> hlk(c->hmu);   // the staging buffers: one host-buffer call at a time
     if (int r = ensure(c, c->a_in, blob_bytes + 16)) return r;
     if (int r = ensure(c, c->a_tab, (size_t)n * 28)) return r;
     if (int r = ensure(c, c->a_out, pcm_samples * 2)) return r;
@@ -1003,6 +1009,7 @@ extern "C" int amvhip_adpcm_encode_batch(amvhip_ctx* c, const int16_t* pcm, uint
     if (int r = use_device(c)) return r;
     hipStream_t hs;
     if (int r = host_stream(c, &hs)) return r;
+    std::lock_guard<std::mutex> hlk(c->hmu);   // the staging buffers: one host-buffer call at a time
     if (int r = ensure(c, c->h_in, pcm_samples * 2 + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
@@ -1072,6 +1079,7 @@ static int adpcm_encode_frame_impl(amvhip_ctx* c, const int16_t* samples, uint32
     hipStream_t hs;
     if (int r = host_stream(c, &hs)) return r;
     // staging: [pcm | chunk | scratch pcm] + small tables {pcm_off, chunk_off, nsamp, len, step, final[2]}
+    std::lock_guard<std::mutex> hlk(c->hmu);   // the staging buffers: one host-buffer call at a time
     if (int r = ensure(c, c->h_in, (size_t)nsamp * 2 + 16)) return r;
     if (int r = ensure(c, c->h_out, (size_t)len + 16 + (size_t)nsamp * 2 + 16)) return r;
     if (int r = ensure(c, c->h_aux, 64)) return r;
@@ -1133,6 +1141,7 @@ extern "C" int amvhip_adpcm_wav_encode_frame(amvhip_ctx* c, const int16_t* sampl
     hipStream_t hs;
     if (int r = host_stream(c, &hs)) return r;
     const size_t ns = (size_t)1 + 8 * (size_t)groups;
+    std::lock_guard<std::mutex> hlk(c->hmu);   // the staging buffers: one host-buffer call at a time
     if (int r = ensure(c, c->h_in, ns * 2)) return r;
     if (int r = ensure(c, c->h_out, 4 + 4 * (size_t)groups)) return r;
     if (int r = ensure(c, c->h_status, 8)) return r;

@@ -35,6 +35,7 @@ typedef struct AmvHipVideo {
     amvhip_ctx *ctx;
     AVFrame picture;        /* decoder: the buffer handed out last (mjpegdec.c keeps s->picture the same way) */
     uint8_t *own[3];        /* planes of our own when the caller installed no get_buffer */
+    size_t own_size[3];     /* ... and what each of them holds (the picture size may change between calls) */
     uint8_t *staging;       /* tight YUVJ420P frame from the library */
     size_t staging_size;
     uint8_t *chunk;         /* encoder: one chunk */
@@ -127,8 +128,14 @@ static int amvhip_video_decode_frame(AVCodecContext *avctx, void *data, int *dat
             return -1;
     } else {
         const int pw[3] = {w, cw, cw}, ph[3] = {h, ch, ch};
-        for (i = 0; i < 3; i++) {
-            if (!s->own[i] && !(s->own[i] = malloc((size_t)pw[i] * ph[i]))) return -1;
+        for (i = 0; i < 3; i++) {                             /* lavc lets width / height change between calls */
+            const size_t bytes = (size_t)pw[i] * ph[i];
+            if (bytes > s->own_size[i]) {
+                free(s->own[i]);
+                s->own[i] = malloc(bytes);
+                s->own_size[i] = s->own[i] ? bytes : 0;
+                if (!s->own[i]) return -1;
+            }
             s->picture.data[i] = s->own[i];
             s->picture.linesize[i] = pw[i];
         }

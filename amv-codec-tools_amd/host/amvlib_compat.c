@@ -332,16 +332,34 @@ static readahead *ra_get(AMVDecoder *amv)
     return r;
 }
 
+/* a window buffer that the FIRST frame of a window does not fit is replaced by a larger one (nothing is in it yet) */
+static int ra_grow(readahead *r, void **buf, size_t *cap, size_t need)
+{
+    void *p;
+    if (need <= *cap) return 0;
+    need += need / 2 + 64;
+    p = ra_alloc(r, need);
+    if (p == NULL) return -1;
+    ra_release(r, *buf);
+    *buf = p;
+    *cap = need;
+    return 0;
+}
+
 /* Fill the window with the frames that start at `pos`.  Returns the number of frames (0: none complete there),
- * -1 when `pos` holds the end marker. */
+ * -1 when `pos` holds the end marker.  The buffers are sized for the ~0.2 byte per pixel AMV streams run at; a window
+ * that meets fatter chunks ends early, and a frame that does not fit an EMPTY window (a noisy picture with
+ * AMVHIP_READAHEAD=1, an audio chunk of more than 8 KB) gets larger buffers: the reader has no size limit of its
+ * own, as the reference's has none (AMVDec.c:196-231 mallocs what the chunk header says). */
 static int ra_refill(readahead *r, long pos)
 {
     unsigned char hd[8];
-    size_t vo = 0, ao = 0;
+    size_t vo = 0, ao = 0, pcm = 0;
     if (ctx() != NULL && (r->vstate == 1 || r->astate == 1)) amvhip_sync(ctx());   /* nothing in flight into the buffers */
     r->n = r->cur = 0;
     r->last = -1;
     r->vstate = r->astate = 0;
+    r->vbytes = r->abytes = 0;
     if (fseek(r->fp, pos, SEEK_SET) != 0) return 0;
     while (r->n < r->cap_frames) {
         ra_entry *e = &r->e[r->n];
@@ -350,12 +368,17 @@ static int ra_refill(readahead *r, long pos)
         if (is4(hd, "AMV_") && is4(hd + 4, "END_")) return r->n ? (int)r->n : -1;       /* AMVDec.c:173-190 */
         if (!is4(hd, "00dc")) break;                                                     /* :171,196-208 */
         vlen = rd32(hd + 4);
-        if ((long)vlen > r->fsize - pos - 8 || vo + vlen + 16 > r->vblob_cap) break;     /* truncated file / window full */
+        if ((long)vlen > r->fsize - pos - 8) break;                                      /* truncated file */
+        if (vo + (size_t)round4(vlen) + 16 > r->vblob_cap &&                             /* window full -- or too small for any frame */
+            (r->n != 0 || ra_grow(r, (void **)&r->vblob, &r->vblob_cap, (size_t)round4(vlen) + 16) != 0)) break;
         if (fread(r->vblob + vo, 1, vlen, r->fp) != vlen) break;
         if (fread(hd, 1, 8, r->fp) != 8 || !is4(hd, "01wb")) break;                      /* :213-231 */
         alen = rd32(hd + 4);
+        if ((long)alen > r->fsize - pos - 16 - (long)vlen) break;
         slot = alen > 8 ? 8 + round4(alen - 8) : 8;
-        if ((long)alen > r->fsize - pos - 16 - (long)vlen || ao + slot + 16 > r->ablob_cap || slot > 8192) break;
+        if ((ao + slot + 16 > r->ablob_cap || pcm + 4u * (size_t)(slot - 8) > r->aout_cap) &&
+            (r->n != 0 || ra_grow(r, (void **)&r->ablob, &r->ablob_cap, (size_t)slot + 16) != 0 ||
+             ra_grow(r, (void **)&r->aout, &r->aout_cap, 4u * (size_t)(slot - 8)) != 0)) break;
         if (fread(r->ablob + ao, 1, alen, r->fp) != alen) break;
         memset(r->ablob + ao + alen, 0, slot - alen);       /* the bytes the reference's 4-byte loop reads past the chunk */
         e->pos = pos;
@@ -363,6 +386,7 @@ static int ra_refill(readahead *r, long pos)
         e->aoff = (uint32_t)ao; e->alen = alen;
         vo += round4(vlen);
         ao += slot;
+        pcm += 4u * (size_t)(slot - 8);
         pos += 16 + (long)vlen + (long)alen;
         r->n++;
         r->vbytes = vo;

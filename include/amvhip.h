@@ -193,9 +193,15 @@ uint32_t amvhip_jpeg_header(uint16_t height, uint16_t width, uint8_t *out, uint3
 /*
  * Video decode, device-resident.  Replaces a loop of AmvVideoDecode/AmvJpegDecode calls
  * (AMVDec.c:259-286, AmvJpeg.c:1515-1539) over n independent chunks.
- *   d_blob     : all chunks back to back (each "FF D8" scan "FF D9"), blob_bytes long
+ *   d_blob     : all chunks back to back (each "FF D8" scan "FF D9"); the pointer must be 4-byte aligned (AMVHIP_ERR_ARG
+ *                otherwise; chunks themselves may start at any byte)
+ *   blob_bytes : the bytes of d_blob the chunks OCCUPY (the end of the last chunk), not the capacity of a larger
+ *                buffer: chunks are bounds-checked against it, and the hand-over space between the two decode stages is
+ *                sized from blob_bytes / n (two records per byte of chunk, never under 8 per block) -- with a figure far
+ *                above the real mean, memory is wasted; with one below it (a few heavy frames among light ones), frames
+ *                that need more records than that are decoded by the one-lane-per-frame kernel: same bytes, slower
  *   d_offs[i]  : byte offset of chunk i in d_blob;  d_lens[i]: its length
- *   d_out      : n * amvhip_frame_bytes(w,h); frame i is BGR24, row 0 = top, rows padded to
+ *   d_out      : n * amvhip_frame_bytes(w,h), 4-byte aligned; frame i is BGR24, row 0 = top, rows padded to
  *                amvhip_stride(w); pixels of MCUs after a failing one are zero (AMVDec.c:283)
  *   d_status   : n int32, AMVHIP_ST_* bits
  *   stream     : hipStream_t (NULL = default stream).  Asynchronous: returns after enqueue.

@@ -1497,3 +1497,49 @@ def test_encode_frame_kernel_paths(ctx, pkg, orc):
         ctx.encode_batch(src, w * 3, 0, n, w, h, 128, blob, cap, offs, lens)
         for i in range(n):
             assert blob[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes() == orc.encode_frame(src[i], w, h, qbias=128), (w, h, i)
+
+
+def test_amvlib_reader_has_no_size_limit(ctx, pkg, orc, tmp_path):
+    """the read-ahead window's buffers are sized for ordinary AMV streams; a frame that does not fit an empty window --
+    a noise picture (its chunk is several times 0.2 byte per pixel) and an audio chunk of more than 8 KB, as the FIRST
+    frame of a window and as a later one, with every window size including AMVHIP_READAHEAD=1 -- is read and decoded
+    like any other (the reference's reader mallocs whatever the chunk header says, AMVDec.c:196-231)"""
+    import os
+    lib = pkg.load_library()
+    w, h = 160, 120
+    rng = np.random.default_rng(17)
+    noise = orc.encode_frame(rng.integers(0, 256, (h, w, 3)).astype(np.uint8), w, h)
+    noise = noise[:-2] + bytes(20000) + noise[-2:]                                 # what follows the last MCU is not read (AmvJpeg.c:1244-1287)
+    assert len(noise) > w * h // 2 + 4096 and orc.decode_frame(noise, w, h)[1] == 0   # fatter than a window slot, and valid
+    plain = [orc.encode_frame(orc.synth_frame(SEED, t, w, h), w, h) for t in range(6)]
+    long_pcm = orc.synth_audio(SEED, 0, 20000)
+    big_audio, _ = orc.adpcm_encode_chunk(long_pcm, 0)                             # 10 008 bytes
+    small_audio, _ = orc.adpcm_encode_chunk(long_pcm[:1378], 0)
+    video = [noise, plain[0], plain[1], noise, plain[2], plain[3]]
+    audio = [big_audio, small_audio, big_audio, small_audio, small_audio, big_audio]
+    path = str(tmp_path / "fat.amv").encode()
+    m = lib.amvhip_mux_open(path, w, h, 16, 22050, 200000, 64000)
+    for v, a in zip(video, audio):
+        vb, abuf = np.frombuffer(v, np.uint8), np.frombuffer(a, np.uint8)
+        assert lib.amvhip_mux_write_frame(m, vb.ctypes.data, vb.size, abuf.ctypes.data, abuf.size) == 0
+    assert lib.amvhip_mux_close(m) == 0
+    for window in ("1", "2", "256"):
+        os.environ["AMVHIP_READAHEAD"] = window
+        try:
+            amv = lib.AmvOpen(path)
+            d = amv.contents
+            for k, (v, a) in enumerate(zip(video, audio)):
+                assert lib.AmvReadNextFrame(amv) == 0, (window, k)
+                assert ctypes.string_at(d.framebuf.videobuff, d.framebuf.videobufflen) == v
+                assert ctypes.string_at(d.framebuf.audiobuff, d.framebuf.audiobufflen) == a
+                assert lib.AmvVideoDecode(amv) == 0
+                got = np.frombuffer(ctypes.string_at(d.videobuf.fbmpdat, d.videobuf.len), np.uint8)
+                assert (got == orc.decode_frame(v, w, h)[0].ravel()).all(), (window, k)
+                assert lib.AmvAudioDecode(amv) == 0
+                n4 = (len(a) - 8 + 3) & ~3
+                pcm = np.frombuffer(ctypes.string_at(d.audiobuf.audiodata, d.audiobuf.len), np.int16)
+                assert d.audiobuf.len == 4 * n4 and (pcm == orc.adpcm_decode_chunk(a + b"\0" * (n4 - (len(a) - 8)))[0]).all(), (window, k)
+            assert lib.AmvReadNextFrame(amv) == 0 and d.framebuf.framenum == -1
+            lib.AmvClose(amv)
+        finally:
+            os.environ.pop("AMVHIP_READAHEAD", None)
