@@ -1543,3 +1543,28 @@ def test_amvlib_reader_has_no_size_limit(ctx, pkg, orc, tmp_path):
             lib.AmvClose(amv)
         finally:
             os.environ.pop("AMVHIP_READAHEAD", None)
+
+
+def test_c_host_shards_a_stream_over_contexts(pkg, amv1, tmp_path):
+    """tests/c/shard_host.c: one process, one amvhip context + HIP stream per device (and, on a box with fewer devices
+    than contexts, several independent contexts per device), contiguous frame ranges, decoded frames gathered device to
+    device into one buffer on device 0 -- equal to a single-context decode and to the hash amvlib itself produced.
+    More than one DEVICE is exercised only where the box has them (this pool's test boxes have one)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "shard_host")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "c", "shard_host.c"), "-L", libdir, "-l:" + os.path.basename(pkg.LIB_PATH),
+                    "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    for contexts in (None, 2, 5):
+        cmd = [exe, amv1["path"]] + ([str(contexts)] if contexts else [])
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=300).stdout
+        f = dict(line.split(": ", 1) for line in out.strip().splitlines())
+        assert f["frames"] == "252" and f["failed frames"] == "0" and f["match"] == "yes", out
+        assert int(f["gathered fnv1a64"], 16) == AMVLIB_HASH and int(f["single fnv1a64"], 16) == AMVLIB_HASH
+        want = contexts if contexts else int(f["devices"])
+        assert int(f["contexts"]) == want
+        ranges = [f["context %d" % r] for r in range(want)]
+        assert ranges[0].endswith("frames 0..%d" % (252 // want)) and ranges[-1].endswith("..252")
