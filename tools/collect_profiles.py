@@ -9,7 +9,7 @@ import shutil
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 for name in ("bench", "bench_encode", "bench_coresident", "bench_adpcm", "bench_amvlib", "bench_decode320", "bench_decode10k",
@@ -32,5 +32,9 @@ for suffix in ("", "_encode"):
 sq = [os.path.join(src, "%ssq_pmc%d" % (tag, i)) for i in (1, 2, 3)]
 if all(os.path.isdir(d) for d in sq):
     with open(os.path.join(dst, "%s_sq_counters.json" % tag), "w") as out:
+        subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_sq.py")] + sq, check=True, stdout=out)
+sq = [os.path.join(src, "%ssqenc_pmc%d" % (tag, i)) for i in (1, 2, 3)]
+if all(os.path.isdir(d) for d in sq):
+    with open(os.path.join(dst, "%s_sq_counters_encode.json" % tag), "w") as out:
         subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_sq.py")] + sq, check=True, stdout=out)
 print("\n".join(sorted(os.listdir(dst))))

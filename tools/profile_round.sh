@@ -5,7 +5,7 @@
 # usage: tools/profile_round.sh <tag>      (outputs under gpurun_out/<tag>_*; tools/collect_profiles.py copies the
 #                                           summaries to profiles/)
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd $root
@@ -19,15 +19,16 @@ python3 bench.py --frames 10000 --no-cpu-baseline > $out/${tag}_bench_decode10k.
 python3 bench.py --strong --frames 20000 --no-cpu-baseline > $out/${tag}_bench_strong_world1.json 2>> $out/${tag}_bench.err
 echo "benches done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o run --output-format csv -- python3 $root/bench.py --no-cpu-baseline > $out/${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o run --output-format csv -- python3 $root/bench.py --no-cpu-baseline --no-secondary > $out/${tag}_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_encode -o run --output-format csv -- python3 $root/bench.py --workload encode --no-cpu-baseline > $out/${tag}_stats_encode.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_coresident -o run --output-format csv -- python3 $root/bench.py --workload coresident --no-cpu-baseline > $out/${tag}_stats_coresident.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_adpcm -o run --output-format csv -- python3 $root/bench.py --workload adpcm --no-cpu-baseline > $out/${tag}_stats_adpcm.log 2>&1
 echo "stats done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o run --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write -o run --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o run --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write -o run --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $out/${tag}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch_encode -o run --output-format csv -- python3 $root/bench.py --workload encode --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch_encode.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write_encode -o run --output-format csv -- python3 $root/bench.py --workload encode --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write_encode.log 2>&1
 echo "pmc done"
 bash $root/tools/pmc_sq.sh ${tag}sq 160000
+bash $root/tools/pmc_sq_bench.sh ${tag}sqenc --workload encode
 echo done
