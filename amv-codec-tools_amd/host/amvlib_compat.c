@@ -99,35 +99,62 @@ int AdpcmImaDecodeFrame(ADPCMContext *c, void *data, int *data_size, unsigned ch
 {
     amvhip_ctx *h;
     unsigned char *chunk;
-    uint64_t off = 0, pcm_off = 0;
-    uint32_t len;
-    int32_t fin[2] = { 0, 0 };
-    int n4, idx, rc;
+    uint64_t off[2], pcm_off[2];
+    uint32_t len[2];
+    int32_t fin[4] = { 0, 0, 0, 0 };
+    const int st = c != NULL && c->channel == 2;                  /* AdpcmIma.c:222 */
+    int n, half, ch, i, rc;
+    int16_t *pcm;
 
     if (data == NULL || !buf_size) return -1;                     /* AdpcmIma.c:216-217 */
     if (c == NULL || buf == NULL || buf_size < 0) return -1;
-    if (c->channel == 2) return -1;                               /* AMV audio is mono; no stereo path here */
     if ((h = ctx()) == NULL) return -1;
-    /* the reference consumes input 4 bytes at a time (AdpcmIma.c:225-237) and so reads up to 3
-     * bytes past buf_size; those bytes are taken as zero here */
-    n4 = (buf_size + 3) & ~3;
-    chunk = (unsigned char *)calloc(1, (size_t)n4 + 8);
-    if (chunk == NULL) return -1;
-    idx = c->status[0].step_index;
-    if (idx < 0) idx = 0;
-    if (idx > 88) idx = 88;
-    chunk[0] = (unsigned char)(c->status[0].predictor & 0xff);
-    chunk[1] = (unsigned char)((c->status[0].predictor >> 8) & 0xff);
-    chunk[2] = (unsigned char)idx;
-    memcpy(chunk + 8, buf, (size_t)buf_size);
-    len = (uint32_t)n4 + 8;
-    rc = amvhip_adpcm_decode_batch(h, chunk, len, &off, &len, 1, (int16_t *)data, 2ull * (uint64_t)n4, &pcm_off, fin);
+    /* The reference consumes input 4 bytes at a time, 8 when stereo (:225-237), and so reads up to 3 (7) bytes
+     * past buf_size; those bytes are taken as zero here.  Stereo is two mono streams side by side: of every 8 input
+     * bytes the first 4 are the left channel's nibbles, the last 4 the right's (src[4*i], :231-234), each channel
+     * with its own predictor and step index, and the samples leave interleaved L R.  So each channel's bytes go to
+     * the device as a chunk of their own (one batch call) and the host only interleaves. */
+    n = st ? (buf_size + 7) & ~7 : (buf_size + 3) & ~3;
+    half = st ? n / 2 : n;                                        /* bytes per channel */
+    chunk = (unsigned char *)calloc((size_t)(st + 1), (size_t)half + 8);
+    pcm = st ? (int16_t *)malloc(4u * (size_t)n) : (int16_t *)data;
+    if (chunk == NULL || pcm == NULL) { free(chunk); if (st) free(pcm); return -1; }
+    for (ch = 0; ch <= st; ch++) {
+        unsigned char *k = chunk + (size_t)ch * ((size_t)half + 8);
+        int idx = c->status[ch].step_index;
+        if (idx < 0) idx = 0;
+        if (idx > 88) idx = 88;
+        k[0] = (unsigned char)(c->status[ch].predictor & 0xff);
+        k[1] = (unsigned char)((c->status[ch].predictor >> 8) & 0xff);
+        k[2] = (unsigned char)idx;
+        if (!st) {
+            memcpy(k + 8, buf, (size_t)buf_size);
+        } else {
+            for (i = 0; i < buf_size; i++)
+                if (((i >> 2) & 1) == ch) k[8 + ((i >> 3) << 2) + (i & 3)] = buf[i];
+        }
+        off[ch] = (uint64_t)ch * ((uint64_t)half + 8);
+        len[ch] = (uint32_t)half + 8;
+        pcm_off[ch] = (uint64_t)ch * 2u * (uint64_t)half;
+    }
+    rc = amvhip_adpcm_decode_batch(h, chunk, (uint64_t)(st + 1) * ((uint64_t)half + 8), off, len, (uint32_t)(st + 1), pcm,
+                                   2ull * (uint64_t)n, pcm_off, fin);
     free(chunk);
-    if (rc != AMVHIP_OK) return -1;
-    c->status[0].predictor = fin[0];
-    c->status[0].step_index = (short)fin[1];
-    if (data_size) *data_size = 4 * n4;                           /* :239 */
-    return n4;                                                    /* :241 src - buf */
+    if (rc != AMVHIP_OK) { if (st) free(pcm); return -1; }
+    if (st) {
+        int16_t *out = (int16_t *)data;
+        for (i = 0; i < 2 * half; i++) {
+            out[2 * i] = pcm[i];
+            out[2 * i + 1] = pcm[2 * half + i];
+        }
+        free(pcm);
+    }
+    for (ch = 0; ch <= st; ch++) {
+        c->status[ch].predictor = fin[2 * ch];
+        c->status[ch].step_index = (short)fin[2 * ch + 1];
+    }
+    if (data_size) *data_size = 4 * n;                            /* :239 */
+    return n;                                                     /* :241 src - buf */
 }
 
 int AdpcmImaEncodeFrame(ADPCMContext *c, int channels, int frame_size, unsigned char *frame, int buf_size, void *data)
@@ -556,7 +583,7 @@ int AmvAudioDecode(AMVDecoder *amv)
     ab->len = rd32(fb->audiobuff + 4) * 2;                        /* :319-321 */
     if (ab->len < (fb->audiobufflen - 8) * 4) ab->len = (fb->audiobufflen - 8) * 4;  /* :322-323 */
     free(ab->audiodata);
-    ab->audiodata = (short *)malloc((size_t)ab->len + 16);        /* :326 */
+    ab->audiodata = (short *)malloc((size_t)ab->len + 32);        /* :326 (+ what the 4 / 8-byte loop writes past it) */
     if (ab->audiodata == NULL) return -2;
     memset(ab->audiodata, 0, ab->len);                            /* :329 */
     if (amv->amvinfo.nChannels != 2 && (r = ra_current(amv, 0)) != NULL && ra_decode_window(r, 0) == 1) {

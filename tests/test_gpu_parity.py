@@ -1568,3 +1568,46 @@ def test_c_host_shards_a_stream_over_contexts(pkg, amv1, tmp_path):
         assert int(f["contexts"]) == want
         ranges = [f["context %d" % r] for r in range(want)]
         assert ranges[0].endswith("frames 0..%d" % (252 // want)) and ranges[-1].endswith("..252")
+
+
+def test_amvlib_adpcm_stereo_decode(ctx, pkg, orc):
+    """AdpcmImaDecodeFrame with channel == 2 (AdpcmIma.c:222-237): of every 8 input bytes the first 4 are the left
+    channel's nibbles, the last 4 the right's, each channel with a state of its own, samples interleaved L R; the
+    8-byte stride reads up to 7 bytes past buf_size (taken as zero).  Against the reference's own AdpcmIma.c object
+    where it is built (oracle/_ref), and against the oracle's mono decoder channel by channel; the context's state
+    carries from call to call."""
+    lib = pkg.load_library()
+    R = orc.ref()
+    rng = np.random.default_rng(23)
+    for size in (8, 16, 689, 690, 1000, 1378, 5):
+        buf = rng.integers(0, 256, size, dtype=np.uint8)
+        n8 = (size + 7) & ~7
+        mine, ref = pkg.ADPCMContext(), orc.RefADPCMContext()
+        for c in (mine, ref):
+            c.channel = 2
+            c.status[0].predictor, c.status[0].step_index = -1234, 17
+            c.status[1].predictor, c.status[1].step_index = 30000, 80
+        for call in range(2):                                  # the second call starts from the state the first left
+            got = np.zeros(2 * n8 + 16, np.int16)
+            dl = ctypes.c_int(0)
+            start = [(mine.status[ch].predictor, mine.status[ch].step_index) for ch in (0, 1)]
+            rc = lib.AdpcmImaDecodeFrame(ctypes.byref(mine), got.ctypes.data, ctypes.byref(dl), buf.ctypes.data, size)
+            assert rc == n8 and dl.value == 4 * n8
+            padded = np.concatenate([buf, np.zeros(n8 - size, np.uint8)]).reshape(-1, 8)
+            want = np.zeros(2 * n8, np.int16)
+            ends = []
+            for ch in (0, 1):                                  # channel ch = a mono AMV chunk of its own
+                pred, idx = start[ch]
+                chunk = int(pred).to_bytes(2, "little", signed=True) + bytes([idx, 0, 0, 0, 0, 0]) + padded[:, 4 * ch: 4 * ch + 4].tobytes()
+                pcm, _ = orc.adpcm_decode_chunk(chunk)
+                want[ch::2] = pcm[:n8]
+                ends.append(int(pcm[n8 - 1]))
+            assert (got[: 2 * n8] == want).all(), (size, call)
+            assert [mine.status[0].predictor, mine.status[1].predictor] == ends
+            if R is not None:
+                theirs = np.zeros(2 * n8 + 16, np.int16)
+                dl2 = ctypes.c_int(0)
+                pad = np.concatenate([buf, np.zeros(16, np.uint8)])        # the reference reads past buf_size: give it zeros
+                assert R.AdpcmImaDecodeFrame(ctypes.byref(ref), theirs.ctypes.data, ctypes.byref(dl2), pad.ctypes.data, size) == n8
+                assert dl2.value == dl.value and (theirs[: 2 * n8] == got[: 2 * n8]).all(), (size, call)
+                assert all((ref.status[ch].predictor, ref.status[ch].step_index) == (mine.status[ch].predictor, mine.status[ch].step_index) for ch in (0, 1))
