@@ -104,7 +104,9 @@ SYMBOLS = {
     "amvhip_encode_batch_dev": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "amvhip_encode_batch": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp]),
     "amvhip_encode_yuv420_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
+    "amvhip_encode_yuv422_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "amvhip_encode_yuv420_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp]),
+    "amvhip_encode_yuv422_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp]),
     "amvhip_resample_yuv420_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _vp]),
     "amvhip_encode_yuv420_scaled_batch_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u64, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "amvhip_encode_coefs_dev": (_int, [_vp, _vp, _u32, _int, _u32, _u32, _u32, _u32, _vp, _vp]),
@@ -257,10 +259,21 @@ class Context:
                                                                    y_frame, c_frame, n, w, h, qbias, _ptr(blob), blob_cap,
                                                                    _ptr(offs), _ptr(lens), stream), "encode_yuv420_batch_dev")
 
+    def encode_yuv422_batch_dev(self, y, cb, cr, y_stride, c_stride, y_frame, c_frame, n, w, h, qbias, blob, blob_cap, offs,
+                                lens, stream=None):
+        return self._check(self.lib.amvhip_encode_yuv422_batch_dev(self.h, _ptr(y), _ptr(cb), _ptr(cr), y_stride, c_stride,
+                                                                   y_frame, c_frame, n, w, h, qbias, _ptr(blob), blob_cap,
+                                                                   _ptr(offs), _ptr(lens), stream), "encode_yuv422_batch_dev")
+
     def encode_yuv420_batch(self, y, cb, cr, y_stride, c_stride, y_frame, c_frame, n, w, h, qbias, blob, blob_cap, offs, lens):
         return self._check(self.lib.amvhip_encode_yuv420_batch(self.h, _ptr(y), _ptr(cb), _ptr(cr), y_stride, c_stride,
                                                                y_frame, c_frame, n, w, h, qbias, _ptr(blob), blob_cap,
                                                                _ptr(offs), _ptr(lens)), "encode_yuv420_batch")
+
+    def encode_yuv422_batch(self, y, cb, cr, y_stride, c_stride, y_frame, c_frame, n, w, h, qbias, blob, blob_cap, offs, lens):
+        return self._check(self.lib.amvhip_encode_yuv422_batch(self.h, _ptr(y), _ptr(cb), _ptr(cr), y_stride, c_stride,
+                                                               y_frame, c_frame, n, w, h, qbias, _ptr(blob), blob_cap,
+                                                               _ptr(offs), _ptr(lens)), "encode_yuv422_batch")
 
     def encode_coefs_dev(self, pix, pix_stride, is_bgr, n, w, h, qbias, coef, stream=None):
         return self._check(self.lib.amvhip_encode_coefs_dev(self.h, _ptr(pix), pix_stride, is_bgr, n, w, h, qbias,

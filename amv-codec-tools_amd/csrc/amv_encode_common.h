@@ -164,7 +164,11 @@ __device__ __forceinline__ void convert_patches(const Source& in, const Patches&
         if (kYuv) {
             const uint8_t* ya_p = yuv.y + (uint64_t)f * yuv.y_frame + (uint64_t)row_a * yuv.y_stride;
             const uint8_t* yb_p = yuv.y + (uint64_t)f * yuv.y_frame + (uint64_t)row_b * yuv.y_stride;
-            const uint64_t co = (uint64_t)f * yuv.c_frame + (uint64_t)(row_b >> 1) * yuv.c_stride;
+            // 4:2:0: the chroma row under both luma rows; 4:2:2: the rows of both, averaged (below the picture row_a, row_b
+            // are rows 1 and 0: the 4:2:0 picture's chroma row 0, which is what repeats there)
+            const uint32_t ca = yuv.c_rows422 ? row_a : row_b >> 1, cb_row = yuv.c_rows422 ? row_b : row_b >> 1;
+            const uint64_t co = (uint64_t)f * yuv.c_frame + (uint64_t)cb_row * yuv.c_stride;
+            const uint64_t co2 = (uint64_t)f * yuv.c_frame + (uint64_t)ca * yuv.c_stride;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t x = min(c + (uint32_t)q, w - 1u);
@@ -176,6 +180,10 @@ __device__ __forceinline__ void convert_patches(const Source& in, const Patches&
                 const uint32_t x = min((c >> 1) + (uint32_t)e, cw - 1u);
                 u[e] = (int)yuv.cb[co + x] - 128;
                 v[e] = (int)yuv.cr[co + x] - 128;
+                if (yuv.c_rows422) {
+                    u[e] = (((int)yuv.cb[co + x] + (int)yuv.cb[co2 + x] + 1) >> 1) - 128;
+                    v[e] = (((int)yuv.cr[co + x] + (int)yuv.cr[co2 + x] + 1) >> 1) - 128;
+                }
             }
         } else if (c + 3u < w) {
             int a[12], b[12];

@@ -79,13 +79,15 @@ bool yuv_store_covers_planes(const FrameGeom& g);
 
 // ---- encode -------------------------------------------------------------------------------
 // planar YUVJ420P source (what the reference's amv_encoder takes, mjpegenc.c:493): frame i's planes at
-// y + i*y_frame, cb/cr + i*c_frame (bytes); rows y_stride / c_stride apart
+// y + i*y_frame, cb/cr + i*c_frame (bytes); rows y_stride / c_stride apart.  c_rows422: the chroma planes have a row
+// per luma row (YUVJ422P, the other entry of pix_fmts); the two rows over a 4:2:0 sample are averaged, rounding up.
 struct YuvSource {
     const uint8_t* y;
     const uint8_t* cb;
     const uint8_t* cr;
     uint32_t y_stride, c_stride;
     uint64_t y_frame, c_frame;
+    uint32_t c_rows422;
 };
 // The whole encoder, one workgroup per frame (amv_encode_par.hip): pixels (RGB24/BGR24, or *yuv when not null) ->
 // FF D8 + escaped scan + FF D9 in tmp[i*bound..], lens[i].  Frames whose bits do not fit the kernel's LDS window are

@@ -722,20 +722,36 @@ extern "C" int amvhip_encode_batch_dev(amvhip_ctx* c, const uint8_t* d_pix, uint
                        (hipStream_t)stream);
 }
 
+static int encode_yuv_dev(amvhip_ctx* c, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr, uint32_t y_stride, uint32_t c_stride,
+                          uint64_t y_frame_stride, uint64_t c_frame_stride, uint32_t rows422, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
+                          uint8_t* d_blob, uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens, void* stream) {
+    if (!c) return AMVHIP_ERR_ARG;
+    if (!size_ok(w, h) || (w & 1) || (h & 1) || y_stride < w || c_stride < w / 2 || qbias > 255 ||
+        (n && (!d_y || !d_cb || !d_cr || !d_blob || !d_offs || !d_lens)))
+        return fail(c, AMVHIP_ERR_ARG, "encode_yuv: bad argument (width/height must be even)");
+    if (n == 0) return AMVHIP_OK;
+    if (int r = use_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const YuvSource yuv{d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride, rows422};
+    return encode_core(c, nullptr, 0u, 0, &yuv, n, make_geom(w, h), qbias, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
+}
+
 extern "C" int amvhip_encode_yuv420_batch_dev(amvhip_ctx* c, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
                                               uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
                                               uint64_t c_frame_stride, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
                                               uint8_t* d_blob, uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens,
                                               void* stream) {
-    if (!c) return AMVHIP_ERR_ARG;
-    if (!size_ok(w, h) || (w & 1) || (h & 1) || y_stride < w || c_stride < w / 2 || qbias > 255 ||
-        (n && (!d_y || !d_cb || !d_cr || !d_blob || !d_offs || !d_lens)))
-        return fail(c, AMVHIP_ERR_ARG, "encode_yuv420: bad argument (width/height must be even)");
-    if (n == 0) return AMVHIP_OK;
-    if (int r = use_device(c)) return r;
-    std::lock_guard<std::mutex> lk(c->mu);
-    const YuvSource yuv{d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride};
-    return encode_core(c, nullptr, 0u, 0, &yuv, n, make_geom(w, h), qbias, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
+    return encode_yuv_dev(c, d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride, 0u, n, w, h, qbias, d_blob, blob_cap, d_offs,
+                          d_lens, stream);
+}
+
+extern "C" int amvhip_encode_yuv422_batch_dev(amvhip_ctx* c, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
+                                              uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                              uint64_t c_frame_stride, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
+                                              uint8_t* d_blob, uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens,
+                                              void* stream) {
+    return encode_yuv_dev(c, d_y, d_cb, d_cr, y_stride, c_stride, y_frame_stride, c_frame_stride, 1u, n, w, h, qbias, d_blob, blob_cap, d_offs,
+                          d_lens, stream);
 }
 
 // the device-to-host half of the host-buffer encoders: offs/lens, then the chunks
@@ -776,10 +792,9 @@ extern "C" int amvhip_encode_batch(amvhip_ctx* c, const uint8_t* pix, uint32_t p
     return encode_fetch(c, hs, n, blob, blob_cap, offs, lens);
 }
 
-extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
-                                          uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
-                                          uint64_t c_frame_stride, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
-                                          uint8_t* blob, uint64_t blob_cap, uint64_t* offs, uint32_t* lens) {
+static int encode_yuv_host(amvhip_ctx* c, const uint8_t* y, const uint8_t* cb, const uint8_t* cr, uint32_t y_stride, uint32_t c_stride,
+                           uint64_t y_frame_stride, uint64_t c_frame_stride, uint32_t rows422, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
+                           uint8_t* blob, uint64_t blob_cap, uint64_t* offs, uint32_t* lens) {
     if (!c) return AMVHIP_ERR_ARG;
     if (!size_ok(w, h) || (w & 1) || (h & 1) || y_stride < w || c_stride < w / 2 || (n && (!y || !cb || !cr || !blob || !offs || !lens)))
         return fail(c, AMVHIP_ERR_ARG, "encode_yuv420: bad argument");
@@ -787,8 +802,8 @@ extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const
     if (int r = use_device(c)) return r;
     hipStream_t hs;
     if (int r = host_stream(c, &hs)) return r;
-    // staged tight: Y w*h, Cb, Cr (w/2 x h/2) per frame
-    const uint32_t cw = w / 2, chh = h / 2;
+    // staged tight: Y w*h, Cb, Cr (w/2 x h/2, or w/2 x h when the source is 4:2:2) per frame
+    const uint32_t cw = w / 2, chh = rows422 ? h : h / 2;
     const uint64_t fb = (uint64_t)w * h + 2ull * cw * chh;
     std::lock_guard<std::mutex> hlk(c->hmu);   // the staging buffers: one host-buffer call at a time
     if (int r = ensure(c, c->h_in, fb * n)) return r;
@@ -801,11 +816,24 @@ extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const
         HIP_TRY(c, hipMemcpy2DAsync(d + i * fb + (uint64_t)w * h, cw, cb + i * c_frame_stride, c_stride, cw, chh, hipMemcpyHostToDevice, hs));
         HIP_TRY(c, hipMemcpy2DAsync(d + i * fb + (uint64_t)w * h + (uint64_t)cw * chh, cw, cr + i * c_frame_stride, c_stride, cw, chh, hipMemcpyHostToDevice, hs));
     }
-    if (int r = amvhip_encode_yuv420_batch_dev(c, d, d + (uint64_t)w * h, d + (uint64_t)w * h + (uint64_t)cw * chh, w, cw, fb, fb, n, w, h,
-                                               qbias, (uint8_t*)c->h_out.p, blob_cap, (uint64_t*)c->h_offs.p,
-                                               (uint32_t*)c->h_lens.p, hs))
+    if (int r = encode_yuv_dev(c, d, d + (uint64_t)w * h, d + (uint64_t)w * h + (uint64_t)cw * chh, w, cw, fb, fb, rows422, n, w, h, qbias,
+                               (uint8_t*)c->h_out.p, blob_cap, (uint64_t*)c->h_offs.p, (uint32_t*)c->h_lens.p, hs))
         return r;
     return encode_fetch(c, hs, n, blob, blob_cap, offs, lens);
+}
+
+extern "C" int amvhip_encode_yuv420_batch(amvhip_ctx* c, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
+                                          uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                          uint64_t c_frame_stride, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
+                                          uint8_t* blob, uint64_t blob_cap, uint64_t* offs, uint32_t* lens) {
+    return encode_yuv_host(c, y, cb, cr, y_stride, c_stride, y_frame_stride, c_frame_stride, 0u, n, w, h, qbias, blob, blob_cap, offs, lens);
+}
+
+extern "C" int amvhip_encode_yuv422_batch(amvhip_ctx* c, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
+                                          uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                          uint64_t c_frame_stride, uint32_t n, uint32_t w, uint32_t h, uint32_t qbias,
+                                          uint8_t* blob, uint64_t blob_cap, uint64_t* offs, uint32_t* lens) {
+    return encode_yuv_host(c, y, cb, cr, y_stride, c_stride, y_frame_stride, c_frame_stride, 1u, n, w, h, qbias, blob, blob_cap, offs, lens);
 }
 
 // =============================================================================================
@@ -881,7 +909,7 @@ extern "C" int amvhip_encode_yuv420_scaled_batch_dev(amvhip_ctx* c, const uint8_
                                            p + (uint64_t)w * h, p + (uint64_t)w * h + (uint64_t)(w / 2) * (h / 2), w, w / 2, fb, fb, w, h,
                                            n, stream))
         return r;
-    const YuvSource yuv{p, p + (uint64_t)w * h, p + (uint64_t)w * h + (uint64_t)(w / 2) * (h / 2), w, w / 2, fb, fb};
+    const YuvSource yuv{p, p + (uint64_t)w * h, p + (uint64_t)w * h + (uint64_t)(w / 2) * (h / 2), w, w / 2, fb, fb, 0u};
     return encode_core(c, nullptr, 0u, 0, &yuv, n, make_geom(w, h), qbias, d_blob, blob_cap, d_offs, d_lens, (hipStream_t)stream);
 }
 

@@ -17,9 +17,11 @@
  *
  *   decode (video)  AMVHIP_FLAG_FFMPEG: FFmpeg's own AMV arithmetic (Q60 tables, simple_idct, flipped planes),
  *                   so a transcode through this plugin shows the pictures the reference's decoder shows.
- *   encode (video)  planar YUVJ420P in, as pix_fmts declares.  Differences from the reference's encoder are the
- *                   documented ones of DESIGN.md section 2 (amvlib's quantiser tables, true level shift): the
- *                   reference's own output does not survive any AMV decoder.
+ *   encode (video)  planar YUVJ420P or YUVJ422P in, as pix_fmts declares (mjpegenc.c:493).  Differences from the
+ *                   reference's encoder are the documented ones of DESIGN.md section 2 (amvlib's quantiser tables,
+ *                   true level shift): the reference's own output does not survive any AMV decoder (SURVEY.md fact
+ *                   2).  A 4:2:2 picture is coded as the 4:2:0 picture its chroma rows average to -- the reference
+ *                   would emit eight-block MCUs no AMV decoder reads (include/amvhip.h, amvhip_encode_yuv422_batch).
  *   audio           chunk layout, step index carried from call to call, odd-sample carry and 1 Hz resync of
  *                   adpcm.c:461-498; `-trellis N` runs the reference's beam search (:287-443) with N capped at 5.
  */
@@ -163,7 +165,7 @@ static int amvhip_video_encode_init(AVCodecContext *avctx)
 {
     AmvHipVideo *s = avctx->priv_data;
     memset(s, 0, sizeof *s);
-    if (avctx->pix_fmt != PIX_FMT_YUVJ420P)                  /* mpegvideo_enc.c:251-256 (422 is not built) */
+    if (avctx->pix_fmt != PIX_FMT_YUVJ420P && avctx->pix_fmt != PIX_FMT_YUVJ422P)   /* mpegvideo_enc.c:251-256 */
         return -1;
     if ((avctx->width & 1) || (avctx->height & 1) || avctx->width <= 0 || avctx->height <= 0)
         return -1;
@@ -201,8 +203,9 @@ static int amvhip_video_encode_frame(AVCodecContext *avctx, unsigned char *buf, 
         pic->linesize[1] != pic->linesize[2])
         return -1;
     /* the flip of mjpegenc.c:466-470 happens inside the kernel (bitstream row k = picture row h-1-k) */
-    if (amvhip_encode_yuv420_batch(s->ctx, pic->data[0], pic->data[1], pic->data[2], pic->linesize[0], pic->linesize[1], 0, 0, 1,
-                                   avctx->width, avctx->height, AMVHIP_QBIAS_AMV, s->chunk, s->chunk_cap, &off, &len) != AMVHIP_OK)
+    if ((avctx->pix_fmt == PIX_FMT_YUVJ422P ? amvhip_encode_yuv422_batch : amvhip_encode_yuv420_batch)(
+            s->ctx, pic->data[0], pic->data[1], pic->data[2], pic->linesize[0], pic->linesize[1], 0, 0, 1, avctx->width, avctx->height,
+            AMVHIP_QBIAS_AMV, s->chunk, s->chunk_cap, &off, &len) != AMVHIP_OK)
         return -1;
     if ((int)len > buf_size)
         return -1;
@@ -285,7 +288,7 @@ static int amvhip_audio_decode_frame(AVCodecContext *avctx, void *data, int *dat
 /* ---------------------------------------------------------------------------------------------
  * the tables, field for field as the reference declares them
  * ------------------------------------------------------------------------------------------- */
-static const enum PixelFormat amvhip_pix_fmts[] = {PIX_FMT_YUVJ420P, -1};   /* mjpegenc.c:493 lists 422 too; it is not built */
+static const enum PixelFormat amvhip_pix_fmts[] = {PIX_FMT_YUVJ420P, PIX_FMT_YUVJ422P, -1};   /* mjpegenc.c:493 */
 
 AVCodec amv_decoder = {                                             /* sp5xdec.c:203-212 */
     "amv",

@@ -323,6 +323,23 @@ int amvhip_encode_yuv420_batch(amvhip_ctx *ctx, const uint8_t *y, const uint8_t 
                                uint64_t c_frame_stride, uint32_t n, uint32_t width, uint32_t height,
                                uint32_t qbias, uint8_t *blob, uint64_t blob_cap, uint64_t *offs, uint32_t *lens);
 /*
+ * ... and from planar YUVJ422P, the other pixel format amv_encoder declares (mjpegenc.c:493; chroma planes (w/2) x h,
+ * mpegvideo_enc.c:534-543 h/v sampling 2x2 : 1x2).  The reference would code such a picture as MCUs of eight blocks
+ * (ff_mjpeg_encode_mb, mjpegenc.c:437-450, the CHROMA_420 test failing) -- a scan no AMV decoder can read: the container
+ * has no frame header, and both amvlib (AmvJpeg.c:1406-1420) and the reference's own amv decoder (sp5xdec.c:51-91, a
+ * fixed 4:2:0 SOF) take six blocks per MCU.  Here the two chroma rows over every 4:2:0 sample are averaged ((a + b + 1)
+ * >> 1) and the picture is coded as above: a valid AMV chunk.  Arguments as amvhip_encode_yuv420_batch(_dev).
+ */
+int amvhip_encode_yuv422_batch_dev(amvhip_ctx *ctx, const uint8_t *d_y, const uint8_t *d_cb, const uint8_t *d_cr,
+                                   uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                                   uint64_t c_frame_stride, uint32_t n, uint32_t width, uint32_t height,
+                                   uint32_t qbias, uint8_t *d_blob, uint64_t blob_cap, uint64_t *d_offs,
+                                   uint32_t *d_lens, void *stream);
+int amvhip_encode_yuv422_batch(amvhip_ctx *ctx, const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
+                               uint32_t y_stride, uint32_t c_stride, uint64_t y_frame_stride,
+                               uint64_t c_frame_stride, uint32_t n, uint32_t width, uint32_t height,
+                               uint32_t qbias, uint8_t *blob, uint64_t blob_cap, uint64_t *offs, uint32_t *lens);
+/*
  * The picture rescaler in front of the encoder: img_resample (libavcodec/imgresample.c:474-495), the arithmetic of
  * the sws_scale shim (:599) ffmpeg.c:757 runs when the source is not the target size (AMVmuxer/Makefile:15-17 asks for
  * -s 160x120): four-tap, 16-phase polyphase filter built as av_build_filter does (resample2.c:93-140), horizontal pass

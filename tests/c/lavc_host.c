@@ -188,6 +188,52 @@ static int encode_video_leg(const char *dir)
     close_codec(c);
     fclose(fs);
     fclose(fo);
+    {   /* the other pixel format of pix_fmts (mjpegenc.c:493): YUVJ422P, chroma planes W/2 x H */
+        enum { N2 = 6 };
+        AVCodecContext *c2 = open_codec(&amv_encoder);
+        FILE *fs2 = out_file(dir, "enc_src422.yuv"), *fo2 = out_file(dir, "enc_video422.bin");
+        uint8_t *cb = malloc(LC * H), *cr = malloc(LC * H);
+        if (!c2 || !fs2 || !fo2 || !cb || !cr) return -4;
+        c2->width = W;
+        c2->height = H;
+        c2->pix_fmt = PIX_FMT_YUVJ422P;
+        c2->time_base.num = 1;
+        c2->time_base.den = 16;
+        printf("pix_fmts: %d %d %d\n", amv_encoder.pix_fmts[0] == PIX_FMT_YUVJ420P, amv_encoder.pix_fmts[1] == PIX_FMT_YUVJ422P,
+               amv_encoder.pix_fmts[2] == -1);
+        if (amv_encoder.init(c2) < 0) return -5;
+        for (t = 0; t < N2; t++) {
+            AVFrame pic;
+            int len;
+            memset(&pic, 0, sizeof pic);
+            memset(cb, 0xEE, LC * H);
+            memset(cr, 0xEE, LC * H);
+            for (y = 0; y < H; y++)
+                for (x = 0; x < W; x++)
+                    planes[0][y * LY + x] = (uint8_t)(128 + ((x * 5 + t * 3) & 63) - ((y * 3 + t) & 31) + (int)(lcg(&seed) >> 28));
+            for (y = 0; y < H; y++)
+                for (x = 0; x < W / 2; x++) {
+                    cb[y * LC + x] = (uint8_t)(90 + ((x + 3 * y + t) & 127) + (int)(lcg(&seed) >> 30));
+                    cr[y * LC + x] = (uint8_t)(200 - ((x * 2 + y * 5 + 3 * t) & 127));
+                }
+            pic.data[0] = planes[0]; pic.linesize[0] = LY;
+            pic.data[1] = cb; pic.linesize[1] = LC;
+            pic.data[2] = cr; pic.linesize[2] = LC;
+            for (y = 0; y < H; y++) fwrite(planes[0] + y * LY, 1, W, fs2);
+            for (y = 0; y < H; y++) fwrite(cb + y * LC, 1, W / 2, fs2);
+            for (y = 0; y < H; y++) fwrite(cr + y * LC, 1, W / 2, fs2);
+            len = c2->codec->encode(c2, buf, 1 << 20, &pic);
+            if (len <= 4) return -6;
+            put_le32(fo2, (uint32_t)len);
+            fwrite(buf, 1, len, fo2);
+        }
+        printf("encoded 422 frames: %d\n", N2);
+        close_codec(c2);
+        fclose(fs2);
+        fclose(fo2);
+        free(cb);
+        free(cr);
+    }
     return 0;
 }
 

@@ -938,6 +938,24 @@ def test_avcodec_plugin_through_the_struct(ctx, pkg, orc, amv1, tmp_path):
             yy = (dec[:, : w * 3].reshape(h, w, 3).astype(np.int32) * np.array([117, 601, 306])).sum(2) >> 10
             assert np.abs(yy - Y[0].astype(np.int32)).mean() < 12
     assert pos == len(raw)
+    # ... and with PIX_FMT_YUVJ422P (the other entry of pix_fmts): the chunk of the 4:2:0 picture the chroma rows average to
+    assert f["pix_fmts"] == "1 1 1" and f["encoded 422 frames"] == "6"
+    n2 = 6
+    src = np.frombuffer(rd("enc_src422.yuv"), np.uint8).reshape(n2, -1)
+    Y = np.ascontiguousarray(src[:, : w * h]).reshape(n2, h, w)
+    C = src[:, w * h:].reshape(n2, 2, h, w // 2).astype(np.uint16)
+    C420 = ((C[:, :, 0::2] + C[:, :, 1::2] + 1) >> 1).astype(np.uint8)
+    cap = ctx.encode_bound(w, h) * n2
+    blob, offs, lens = np.zeros(cap, np.uint8), np.zeros(n2, np.uint64), np.zeros(n2, np.uint32)
+    ctx.encode_yuv420_batch(Y, np.ascontiguousarray(C420[:, 0]), np.ascontiguousarray(C420[:, 1]), w, w // 2, w * h, w * h // 4, n2, w, h, 0,
+                            blob, cap, offs, lens)
+    raw, pos = rd("enc_video422.bin"), 0
+    for t in range(n2):
+        (ln,) = struct.unpack_from("<I", raw, pos)
+        assert raw[pos + 4: pos + 4 + ln] == blob[int(offs[t]):int(offs[t]) + int(lens[t])].tobytes(), t
+        assert orc.decode_frame(raw[pos + 4: pos + 4 + ln], w, h)[1] == 0
+        pos += 4 + ln
+    assert pos == len(raw)
     # audio encode leg: both passes == the oracle's sequential encoder fed by the oracle's framing
     pcm = np.frombuffer(rd("enc_pcm.raw"), np.int16)
     raw, pos = rd("enc_audio.bin"), 0
@@ -1611,3 +1629,37 @@ def test_amvlib_adpcm_stereo_decode(ctx, pkg, orc):
                 assert R.AdpcmImaDecodeFrame(ctypes.byref(ref), theirs.ctypes.data, ctypes.byref(dl2), pad.ctypes.data, size) == n8
                 assert dl2.value == dl.value and (theirs[: 2 * n8] == got[: 2 * n8]).all(), (size, call)
                 assert all((ref.status[ch].predictor, ref.status[ch].step_index) == (mine.status[ch].predictor, mine.status[ch].step_index) for ch in (0, 1))
+
+
+def test_encode_yuv422_entry(ctx, orc):
+    """amvhip_encode_yuv422_batch(_dev): planar YUVJ422P in (chroma planes w/2 x h, padded strides) = the YUVJ420P entry
+    -- itself pinned to the oracle's encoder by test_encode_yuv420_entry_matches_rgb_path -- on the planes whose chroma
+    rows are the rounded-up averages of the 4:2:2 pairs; sizes with partial MCUs (rows below the picture repeat chroma
+    row 0 in both forms), device and host forms, and the frames the one-kernel encoder hands back (noise)"""
+    import torch
+    rng = np.random.default_rng(422)
+    for w, h, n in ((160, 120, 4), (130, 98, 3), (16, 16, 2), (320, 240, 2)):
+        cw = w // 2
+        ys, cs = w + 8, cw + 24
+        Y = rng.integers(0, 256, (n, h, ys), dtype=np.uint8)
+        C2 = rng.integers(0, 256, (2, n, h, cs), dtype=np.uint8)
+        smooth = (np.add.outer(np.arange(h) * 2, np.arange(cs) * 3) & 255).astype(np.uint8)
+        C2[:, : n - 1] = smooth                                   # all but the last frame: codable content; the last: noise
+        Y[: n - 1] = (np.add.outer(np.arange(h) * 3, np.arange(ys)) & 255).astype(np.uint8)
+        C0 = ((C2[:, :, 0::2].astype(np.uint16) + C2[:, :, 1::2] + 1) >> 1).astype(np.uint8)
+        cap = ctx.encode_bound(w, h) * n
+        want_blob, want_offs, want_lens = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+        ctx.encode_yuv420_batch(Y, np.ascontiguousarray(C0[0]), np.ascontiguousarray(C0[1]), ys, cs, h * ys, (h // 2) * cs, n, w, h, 0,
+                                want_blob, cap, want_offs, want_lens)
+        blob, offs, lens = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+        ctx.encode_yuv422_batch(Y, np.ascontiguousarray(C2[0]), np.ascontiguousarray(C2[1]), ys, cs, h * ys, h * cs, n, w, h, 0, blob, cap, offs, lens)
+        total = int(want_offs[-1] + want_lens[-1])
+        assert (lens == want_lens).all() and blob[:total].tobytes() == want_blob[:total].tobytes(), (w, h)
+        d_blob = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+        d_offs = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+        d_lens = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        ctx.encode_yuv422_batch_dev(_t(Y), _t(C2[0]), _t(C2[1]), ys, cs, h * ys, h * cs, n, w, h, 0, d_blob, cap, d_offs, d_lens)
+        torch.cuda.synchronize()
+        assert (d_lens.cpu().numpy().astype(np.uint32) == want_lens).all() and d_blob.cpu().numpy()[:total].tobytes() == want_blob[:total].tobytes()
+        for i in range(n):                                          # and every chunk is a valid AMV frame
+            assert orc.decode_frame(want_blob[int(want_offs[i]):int(want_offs[i]) + int(want_lens[i])].tobytes(), w, h)[1] == 0
