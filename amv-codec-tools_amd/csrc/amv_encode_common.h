@@ -243,15 +243,11 @@ __device__ __forceinline__ void convert_segment(const Source& in, uint32_t f, co
     convert_patches<kYuv>(in, px, f, g, my, m0, cnt, lane, s_y, s_cb, s_cr);
 }
 
-constexpr int natural_of_scan(int scan) {
-    for (int nat = 0; nat < 64; ++nat)
-        if (kScanOfNatural[nat] == scan) return nat;
-    return 0;
-}
-
 // Stage 2: lane's block (lane = 6 * MCU in segment + block in MCU) out of the planes, in registers: 8 row passes,
 // DCTELEM truncation, 8 column passes, dct_quantize_c.  out: the 64 quantised coefficients, scan order, int16 pairs;
-// nz_lo / nz_hi: bit k set where coefficient k (scan order, k >= 1) is not zero.
+// nz_lo / nz_hi: bit k set where coefficient k (scan order, k >= 1) is not zero.  Pairs and mask are put together
+// as the columns come out: holding all 64 values for a pass in scan order cost registers, spills and 8 % of the
+// one-kernel encoder's time (and sending them to the LDS line two bytes at a time instead of through out[] cost 3 %).
 // The AC quantiser (mpegvideo_enc.c:3702-3712) is sign(x) * ((|x| * m + bias) >> 22) with m = (1 << 22) / (8 * Q)
 // (ff_convert_matrix :80-91, qscale 8); for x < 0 that is ceil((x * m - bias) / 2^22) = (x * m + (2^22 - 1 - bias)) >> 22,
 // so both signs are one multiply-add and one arithmetic shift: (x * m + (bias ^ (sign & (2^22 - 1)))) >> 22.
@@ -275,7 +271,9 @@ __device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_
         for (int c = 0; c < 8; ++c) d[r][c] = (int16_t)d[r][c];    // DCTELEM is 16 bit (dsputil.h:38)
     }
     const int bias = (int)(qbias << 14);   // intra_quant_bias << (QMAT_SHIFT - QUANT_BIAS_SHIFT), :3679
-    int qv[64];                            // quantised values, natural order
+    nz_lo = nz_hi = 0u;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) out[i] = 0u;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {                                  // column pass + dct_quantize_c
         int col[8];
@@ -286,29 +284,23 @@ __device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_
         for (int r = 0; r < 8; ++r) {
             const int scan = kScanOfNatural[r * 8 + c];
             const int x = (int16_t)col[r];
+            int q;
             if (r == 0 && c == 0) {        // DC: (block[0] + q/2) / q with q = 8 * step, :3670-3676
                 constexpr int ql = 8 * kQuantLuma[0], qc = 8 * kQuantChroma[0];
                 const int ax = abs(x);
                 const int a = is_c ? (ax + (qc >> 1)) / qc : (ax + (ql >> 1)) / ql;
-                qv[0] = x < 0 ? -a : a;
+                q = x < 0 ? -a : a;
             } else {
                 const int ml = (int)((1u << 22) / (8u * kQuantLuma[scan])), mc = (int)((1u << 22) / (8u * kQuantChroma[scan]));
                 const int sign = x >> 31;
-                qv[r * 8 + c] = (x * (is_c ? mc : ml) + (bias ^ (sign & 0x3fffff))) >> 22;
+                q = (x * (is_c ? mc : ml) + (bias ^ (sign & 0x3fffff))) >> 22;
+                const uint32_t bit = q != 0 ? 1u : 0u;
+                if (scan >= 32) nz_hi |= bit << (scan - 32);
+                else nz_lo |= bit << scan;
             }
+            out[scan >> 1] |= ((uint32_t)q & 0xffffu) << (16 * (scan & 1));
         }
     }
-    nz_lo = nz_hi = 0u;
-#pragma unroll
-    for (int scan = 63; scan >= 0; --scan) {   // the mask is shifted up as the scan goes down
-        const uint32_t bit = qv[natural_of_scan(scan)] != 0 ? 1u : 0u;
-        if (scan >= 32) nz_hi = nz_hi + nz_hi + bit;
-        else nz_lo = nz_lo + nz_lo + bit;
-    }
-    nz_lo &= ~1u;                              // the DC coefficient is not a run/size symbol
-#pragma unroll
-    for (int i = 0; i < 32; ++i)
-        out[i] = ((uint32_t)qv[natural_of_scan(2 * i)] & 0xffffu) | ((uint32_t)qv[natural_of_scan(2 * i + 1)] << 16);
 }
 
 // coefficient k of lane `lane`'s 128-byte line in an LDS region of 64 lines: 16-byte granules XOR-swizzled by lane, so
