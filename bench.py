@@ -639,10 +639,13 @@ def run_secondary(E, args):
     stream on one GPU), 320x240 encode (configs[2]), video decode with co-resident ADPCM (configs[4]), ADPCM alone."""
     import copy
     out = {}
-    plan = (("decode_320x240", run_decode, {"width": 320, "height": 240, "frames": 32000}),
+    # batch sizes: what fills the chip with ONE entropy lane per frame (320x240: 32 000 / 64 000 / 128 000 frames per step
+    # decode at 5.9 / 6.6 / 7.7 M frames/s -- a small batch is cut into several speculative lanes per frame); the
+    # 10 000-frame line is there to show the other regime
+    plan = (("decode_320x240", run_decode, {"width": 320, "height": 240, "frames": 128000}),
             ("decode_160x120_10k_stream", run_decode, {"frames": 10000}),
             ("encode_320x240", run_encode, {}),
-            ("coresident_320x240_adpcm", lambda e, a: run_adpcm(e, a, with_video=True), {}),
+            ("coresident_320x240_adpcm", lambda e, a: run_adpcm(e, a, with_video=True), {"frames": 64000}),
             ("adpcm", lambda e, a: run_adpcm(e, a, with_video=False), {}))
     for name, fn, over in plan:
         a = copy.copy(args)
