@@ -230,14 +230,59 @@ constexpr uint32_t kChainBlock = 256;   // chunks whose maps one workgroup compo
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void amv_adpcm_decode_kernel(
+// Decode, a wave per chunk.  Both chains of AdpcmImaExpandNibble (AdpcmIma.c:170-204) are compositions of "add a constant,
+// clamp": the step index moves by index_table[nibble] inside 0..88 whatever the predictor does, and once the indices are
+// known the predictor moves by a known +-diff inside -32768..32767.  x -> clamp(x + a, lo, hi) composed with another of its
+// kind is of its kind again ((a1, lo1, hi1) then (a2, lo2, hi2) = (a1 + a2, clamp(lo1 + a2, lo2, hi2), clamp(hi1 + a2,
+// lo2, hi2))), so both chains are prefix scans: every lane takes a run of consecutive samples (22 of a 1378-sample chunk),
+// folds its run's index moves into one such triple, the wave scans the triples (six shuffle steps), every lane now knows the
+// index its run starts at and looks its steps up; the same again for the predictor.  2.5x the arithmetic of the serial walk,
+// but the chunk is read and written as the contiguous bytes it is (one lane per chunk read 16 bytes per 32 samples of its
+// own at a 697-byte stride and waited for each) and a chunk is ~1 100 instructions deep instead of 16 000.  For a
+// chip-filling batch that comes out even (0.42 ms per 200 000 chunks against 0.40: the kernel is bound by its 1 140
+// vector instructions per wave); a single chunk -- AmvAudioDecode, the AVCodec plugin -- is decoded in microseconds.
+namespace {
+
+constexpr uint32_t kPer = 12;                // nibble bytes (pairs of samples) per lane and tile: a compile-time run length
+constexpr uint32_t kTileBytes = 64 * kPer;   // nibble bytes a wave takes at a time (a chunk of 1378 samples has 689)
+constexpr uint32_t kDecodeWaves = 4;         // chunks per workgroup
+
+struct ClampAdd { int a, lo, hi; };          // x -> min(max(x + a, lo), hi)
+
+__device__ __forceinline__ ClampAdd then(const ClampAdd& f, const ClampAdd& g, int lo, int hi) {   // g after f
+    (void)lo; (void)hi;
+    return ClampAdd{f.a + g.a, min(max(f.lo + g.a, g.lo), g.hi), min(max(f.hi + g.a, g.lo), g.hi)};
+}
+
+// exclusive scan over the wave's lanes of the composition (lane 0 gets the identity on lo..hi), and the whole wave's
+template <int kLo, int kHi>
+__device__ __forceinline__ ClampAdd wave_compose_before(ClampAdd mine, uint32_t lane, ClampAdd& all) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const ClampAdd left{__shfl_up(mine.a, d), __shfl_up(mine.lo, d), __shfl_up(mine.hi, d)};
+        if (lane >= (uint32_t)d) mine = then(left, mine, kLo, kHi);
+    }
+    all = ClampAdd{__shfl(mine.a, 63), __shfl(mine.lo, 63), __shfl(mine.hi, 63)};
+    ClampAdd before{__shfl_up(mine.a, 1), __shfl_up(mine.lo, 1), __shfl_up(mine.hi, 1)};
+    if (lane == 0u) before = ClampAdd{0, kLo, kHi};
+    return before;
+}
+
+__device__ __forceinline__ int apply(const ClampAdd& f, int x) { return min(max(x + f.a, f.lo), f.hi); }
+
+}  // namespace
+
+__global__ __launch_bounds__(64 * kDecodeWaves) void amv_adpcm_decode_kernel(
     const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offs,
     const uint32_t* __restrict__ lens, uint32_t n, int16_t* __restrict__ pcm,
     const uint64_t* __restrict__ pcm_offs, int32_t* __restrict__ final_state) {
     __shared__ uint32_t s_step[96];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kDecodeWaves][kTileBytes + 16];
+    __shared__ __attribute__((aligned(16))) int16_t s_out[kDecodeWaves][2 * kTileBytes + 8];
     load_steps(s_step);
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * kDecodeWaves + wave;
+    if (i >= n) return;                               // (the whole wave; no workgroup barrier follows)
     const uint64_t off = offs[i];
     const uint32_t len = lens[i];
     if (len <= 8 || off > blob_bytes || len > blob_bytes - off) return;
@@ -247,57 +292,73 @@ __global__ __launch_bounds__(64) void amv_adpcm_decode_kernel(
     int16_t* o = pcm + pcm_offs[i];
     const uint8_t* p = c + 8;
     const uint32_t nb = len - 8u;
-    // AdpcmIma.c:225-237, 32 samples per 16 bytes
-    auto decode16 = [&](const Bytes16& in, int16_t* dst) {
-        Pcm32 out;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t nib[8];
-            int st[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {            // the index chain needs only the nibbles
-                nib[j] = (in.w[w] >> (8 * (j >> 1) + ((j & 1) ? 0 : 4))) & 15u;
-                st[j] = index;
-                index = clip_index(index + index_adjust(nib[j] & 7u));
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) st[j] = (int)s_step[st[j]];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int diff = ((2 * (int)(nib[j] & 7u) + 1) * st[j]) >> 3;
-                predictor = clip16((nib[j] & 8u) ? predictor - diff : predictor + diff);
-                if (j & 1) out.w[4 * w + (j >> 1)] |= (uint32_t)predictor << 16;
-                else out.w[4 * w + (j >> 1)] = (uint32_t)predictor & 0xffffu;
-            }
+    uint8_t* const in = s_in[wave];
+    int16_t* const outs = s_out[wave];
+    for (uint32_t t0 = 0; t0 < nb; t0 += kTileBytes) {
+        const uint32_t tile = min(kTileBytes, nb - t0);
+        // the tile's bytes, 16 per lane, as they lie in memory
+        if (lane * 16u + 16u <= tile) {
+            *reinterpret_cast<Bytes16*>(in + lane * 16u) = *reinterpret_cast<const Bytes16*>(p + t0 + lane * 16u);
+        } else if (lane * 16u < tile) {               // the chunk's last piece: not a byte past its end is read
+            for (uint32_t x = lane * 16u; x < tile; ++x) in[x] = p[t0 + x];
         }
-        *reinterpret_cast<Pcm32*>(dst) = out;
-    };
-    uint32_t k = 0;
-    if (nb >= 64u) {                                 // 64 bytes at a time, the next 64 requested before these are decoded
-        Bytes16 cur[4], nxt[4];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // this lane's run: kPer bytes = 2 * kPer samples, high nibble first (AdpcmIma.c:231-234); past the tile's end: none
+        const uint32_t b0 = lane * kPer;
+        uint32_t nib[2 * kPer];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const Bytes16*>(p + 16 * q);
-        for (; k + 64u <= nb; k += 64u) {
-            const bool more = k + 128u <= nb;
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const Bytes16*>(p + k + 64u + 16 * q);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) decode16(cur[q], o + 2u * k + 32 * q);
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
-            }
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t byte = b0 + k < tile ? in[b0 + k] : 0x100u;    // 0x100: no sample here
+            nib[2 * k] = byte >> 4;
+            nib[2 * k + 1] = byte & 0x10fu;
         }
+        // the run's index moves as one clamp-add
+        ClampAdd mine{0, 0, 88};
+#pragma unroll
+        for (uint32_t k = 0; k < 2u * kPer; ++k) {
+            const int adj = nib[k] < 16u ? index_adjust(nib[k] & 7u) : 0;
+            mine = ClampAdd{mine.a + adj, clip_index(mine.lo + adj), clip_index(mine.hi + adj)};
+        }
+        ClampAdd all;
+        const ClampAdd before = wave_compose_before<0, 88>(mine, lane, all);
+        int idx = apply(before, index);
+        index = apply(all, index);                   // where the tile ends: the next tile's (or the caller's) start
+        // the steps, hence the signed differences, hence the run's predictor moves as one clamp-add
+        int diff[2 * kPer];
+        ClampAdd mine_p{0, -32768, 32767};
+#pragma unroll
+        for (uint32_t k = 0; k < 2u * kPer; ++k) {
+            const bool there = nib[k] < 16u;
+            const int step = (int)s_step[idx];
+            const int mag = ((2 * (int)(nib[k] & 7u) + 1) * step) >> 3;
+            diff[k] = there ? ((nib[k] & 8u) ? -mag : mag) : 0;
+            idx = there ? clip_index(idx + index_adjust(nib[k] & 7u)) : idx;
+            mine_p = ClampAdd{mine_p.a + diff[k], clip16(mine_p.lo + diff[k]), clip16(mine_p.hi + diff[k])};
+        }
+        ClampAdd all_p;
+        const ClampAdd before_p = wave_compose_before<-32768, 32767>(mine_p, lane, all_p);
+        int pr = apply(before_p, predictor);
+        predictor = apply(all_p, predictor);
+        // the samples, to LDS in pairs, then out as the contiguous bytes they are
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const int s0 = clip16(pr + diff[2 * k]);
+            pr = clip16(s0 + diff[2 * k + 1]);
+            if (b0 + k < tile) *reinterpret_cast<uint32_t*>(outs + 2u * (b0 + k)) = ((uint32_t)s0 & 0xffffu) | ((uint32_t)pr << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int16_t* dst = o + 2u * t0;
+        const uint32_t out_bytes = 4u * tile;
+        for (uint32_t x = lane * 16u; x + 16u <= out_bytes; x += 64u * 16u)
+            *reinterpret_cast<Pcm8*>(reinterpret_cast<uint8_t*>(dst) + x) = *reinterpret_cast<const Pcm8*>(reinterpret_cast<const uint8_t*>(outs) + x);
+        if (lane < (out_bytes & 15u) / 2u)          // the tile's last 4, 8 or 12 bytes
+            dst[(out_bytes & ~15u) / 2u + lane] = outs[(out_bytes & ~15u) / 2u + lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();            // the tile's LDS is free again
     }
-    for (; k + 16u <= nb; k += 16u) decode16(*reinterpret_cast<const Bytes16*>(p + k), o + 2u * k);
-    for (; k < nb; ++k) {
-        const uint32_t byte = p[k];
-        o[2u * k] = (int16_t)expand(predictor, index, byte >> 4, s_step);
-        o[2u * k + 1u] = (int16_t)expand(predictor, index, byte & 15u, s_step);
-    }
-    if (final_state) { final_state[2 * i] = predictor; final_state[2 * i + 1] = index; }
+    if (final_state && lane == 0u) { final_state[2 * i] = predictor; final_state[2 * i + 1] = index; }
 }
 
 // amvlib's own encoder, AdpcmIma.c:43-160: IMA-WAV block layout (4-byte header, low nibble =
@@ -706,7 +767,7 @@ void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_
                          const uint32_t* lens, uint32_t n, int16_t* pcm, const uint64_t* pcm_offs,
                          int32_t* final_state, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(amv_adpcm_decode_kernel, dim3((n + 63) / 64), dim3(64), 0, s, blob, blob_bytes,
+    hipLaunchKernelGGL(amv_adpcm_decode_kernel, dim3((n + kDecodeWaves - 1u) / kDecodeWaves), dim3(64 * kDecodeWaves), 0, s, blob, blob_bytes,
                        offs, lens, n, pcm, pcm_offs, final_state);
 }
 
