@@ -321,7 +321,7 @@ class Context:
         out = (ctypes.c_uint64 * 10)()
         self._check(self.lib.amvhip_entropy_stats(self.h, 1 if enable else 0, out), "entropy_stats")
         waves = max(out[9], 1)
-        return {"frames": out[0], "rounds": out[1], "max_rounds": out[2], "waves": out[9],
+        return {"frames": out[0], "rounds": out[1], "max_rounds": out[2], "handed_to_serial": out[3], "waves": out[9],
                 "clocks_per_wave": {"zero": out[4] / waves, "first_walk": out[5] / waves, "sync_rounds": out[6] / waves,
                                     "write": out[7] / waves, "dc": out[8] / waves}}
 

@@ -1226,6 +1226,11 @@ extern "C" int amvhip_entropy_stats(amvhip_ctx* c, int enable, uint64_t out[10])
     if (out) {
         if (c->want_stats) HIP_TRY(c, hipMemcpy(out, c->stats.p, 80, hipMemcpyDeviceToHost));
         else memset(out, 0, 80);
+        // frames of the LAST decode call that the synchronising kernel handed to the one-lane-per-frame kernel (chunk
+        // over the workspace window, long FF run, more records than the record space holds: see blob_bytes in amvhip.h)
+        uint32_t handed = 0;
+        if (c->retry.p) HIP_TRY(c, hipMemcpy(&handed, c->retry.p, 4, hipMemcpyDeviceToHost));
+        out[3] = handed;
     }
     HIP_TRY(c, hipMemset(c->stats.p, 0, 128));
     c->want_stats = enable != 0;

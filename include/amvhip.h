@@ -267,7 +267,8 @@ void amvhip_host_free(amvhip_ctx *ctx, void *p);
 #define AMVHIP_ENTROPY_SERIAL 1
 int amvhip_set_entropy_mode(amvhip_ctx *ctx, int mode);
 /* Diagnostics of the synchronising entropy kernel: synchronises the device, returns the counters
- * gathered since the last call in out[] = {frames, sum of synchronisation rounds, max rounds, 0,
+ * gathered since the last call in out[] = {frames, sum of synchronisation rounds, max rounds, frames the LAST decode
+ * call handed to the one-lane-per-frame kernel (always reported, whether gathering is on or not),
  * then shader clocks summed over waves for: coefficient zeroing, first walk, synchronisation
  * rounds, writing pass, DC pass, and the number of waves}, clears them and switches gathering on
  * or off (off by default; costs a few atomics per frame). */

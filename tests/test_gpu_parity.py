@@ -1064,6 +1064,9 @@ def test_decode_fallback_rounds(ctx, pkg, orc):
     fresh = pkg.Context(0)   # buffers only grow: a context of its own shows what this batch needs
     _gpu_decode(fresh, chunks, w, h)
     assert 0 < fresh.decode_workspace_per_frame() < 16 * 1024
+    # the frames the synchronising kernel handed to the serial one are reported: the 5 of every 9 with the
+    # FF run, and a few of the noise frames (more records than their share of the record space)
+    assert sum(1 for i in range(n) if i % 9 < 5) <= fresh.entropy_stats(False)["handed_to_serial"] < n
     fresh.close()
 
 
