@@ -23,7 +23,7 @@ REF_FFMPEG = "/root/reference/AMVmuxer/ffmpeg"
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["csrc/amv_decode.hip", "csrc/amv_decode_sync.hip", "csrc/amv_reconstruct.hip", "csrc/amv_reconstruct_ff.hip", "csrc/amv_encode.hip", "csrc/amv_encode_par.hip", "csrc/amv_resample.hip", "csrc/amv_adpcm.hip", "csrc/amvhip_api.hip"]
+HIP_SOURCES = ["csrc/amv_decode.hip", "csrc/amv_decode_sync.hip", "csrc/amv_reconstruct.hip", "csrc/amv_reconstruct_ff.hip", "csrc/amv_encode.hip", "csrc/amv_encode_par.hip", "csrc/amv_resample.hip", "csrc/amv_adpcm.hip", "csrc/amv_synth.hip", "csrc/amvhip_api.hip"]
 C_SOURCES = ["host/amvlib_compat.c", "host/amv_container.c"]
 HEADERS = ["csrc/amv_tables.h", "csrc/amv_kernels.h", "csrc/amv_block_load.h", "csrc/amv_encode_common.h", "../include/amvhip.h"]
 
