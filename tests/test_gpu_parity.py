@@ -1035,10 +1035,10 @@ def test_amvlib_readahead_semantics(ctx, pkg, orc, amv1, tmp_path):
 
 def test_decode_fallback_rounds(ctx, pkg, orc):
     """frames that go through the serial kernel are reconstructed a round of dense lines at a time (the context keeps
-    lines for 4096 frames or a quarter of the batch, not for all of it): 9000 small frames, more than half of them
+    lines for 16 384 frames or a quarter of the batch, not for all of it): 20 000 small frames, more than half of them
     handed back by the unstuffer (a run of FF bytes longer than its look-back), and the whole batch again in
     AMVHIP_ENTROPY_SERIAL mode -- every frame and status against the oracle, in both output modes"""
-    w, h, n = 32, 16, 9000
+    w, h, n = 32, 16, 20000
     rng = np.random.default_rng(99)
     base = [orc.encode_frame(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), w, h) for _ in range(40)]
     chunks = []
