@@ -109,7 +109,9 @@ typedef struct ADPCMContext {
 void PrepareForVideoDecode(AMVInfo *info);
 int AmvJpegDecode(AMVInfo *info, FRAMEBUFF *inbuff, VIDEOBUFF *video);
 
-/* AdpcmIma.h:28-32 (AdpcmIma.c:206,92).  Decode: mono AMV nibble order (high nibble first),
+/* AdpcmIma.h:28-32 (AdpcmIma.c:206,92).  Decode: AMV nibble order (high nibble first); c->channel == 2 follows
+ * the reference's stereo branch (of every 8 bytes, 4 are the left channel's and 4 the right's; samples leave
+ * interleaved, each channel with the predictor and step index of c->status[ch]);
  * returns bytes consumed (>0) or -1.  Encode: the reference's IMA-WAV-layout routine, which
  * nothing in the reference calls; kept for ABI completeness. */
 int AdpcmImaDecodeFrame(ADPCMContext *c, void *data, int *data_size, unsigned char *buf, int buf_size);
