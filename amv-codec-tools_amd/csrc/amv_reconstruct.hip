@@ -32,7 +32,7 @@ constexpr int kSegMcus = 10;   // MCUs per wave: 60 of 64 lanes busy in the tran
 // Waves per workgroup: four consecutive MCU rows of a frame.  The waves share nothing (a segment's LDS is its wave's);
 // the workgroup only exists so that the chip launches a quarter as many of them -- 1.28 M single-wave workgroups per
 // 160 000 frames of 160x120 cost 8 % of the kernel's time in launches (profiles/r02_launch_rate.txt).
-constexpr int kRowsPerGroup = 4;
+constexpr int kRowsPerGroup = 4;   // (five where fours leave too many slots idle: launch_reconstruct)
 
 // 8-point inverse DCT of AmvJpeg.c: idctrow (:1082-1128) when kColumn == false, idctcol
 // (:1130-1175, without its final clamp) when true.  The reference's all-AC-zero shortcuts
@@ -125,17 +125,34 @@ __device__ __forceinline__ uint32_t sat_pair(uint32_t yy, uint32_t cc) {
 
 }  // namespace
 
+// Where a workgroup works, from its number alone.  The launch is one-dimensional and frame-major -- workgroup b is
+// piece b % per_frame of item b / per_frame, a piece being (row group, segment) with the segment running fastest -- so
+// that the workgroups of one frame are dispatched one after the other: the two segments of a 320-pixel row share a
+// 128-byte line of the picture (byte 480 of 960), and written seconds of work apart (all frames' first pieces, then all
+// second pieces: the order of a 3-D grid) that line went to memory twice, half-filled.  The divisions are by numbers the
+// host knows: it sends their reciprocals (floor(b / d) = high word of b * ceil(2^32 / d) while b * d < 2^32).
+struct PieceMap {
+    uint32_t per_frame, magic_pf;   // pieces per frame
+    uint32_t nseg, magic_ns;        // segments per MCU row
+    uint32_t item_base;             // first item of this launch (a default launch over very many pieces goes in parts)
+};
+__device__ __forceinline__ uint32_t div_by(uint32_t b, uint32_t d, uint32_t magic) { return d == 1u ? b : __umulhi(b, magic); }
+
 // kRound: a round launch (FrameSel::round != 0), whose workgroups walk the items of the round
-template <bool kRound>
-__global__ __launch_bounds__(kWave * kRowsPerGroup) void amv_reconstruct_kernel(
+template <bool kRound, int kRows>
+__global__ __launch_bounds__(kWave * kRows) void amv_reconstruct_kernel(
     SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameSel sel,
-    FrameGeom g, uint32_t nseg, uint32_t flags, uint8_t* __restrict__ out) {
+    FrameGeom g, PieceMap pm, uint32_t flags, uint8_t* __restrict__ out) {
     constexpr uint32_t kPitchY = kSegMcus * 16, kPitchC = kSegMcus * 8;   // int16 units
     // 7 680 bytes (+ the scatter's spare slots): first the records' image of the 60 blocks (128 bytes each), then the three planes
-    __shared__ __attribute__((aligned(16))) int16_t s_all[kRowsPerGroup][16 * kPitchY + 2 * 8 * kPitchC + 64];
+    __shared__ __attribute__((aligned(16))) int16_t s_all[kRows][16 * kPitchY + 2 * 8 * kPitchC + 64];
     static_assert((16 * kPitchY + 2 * 8 * kPitchC) * 2 == kSegImageBytes, "the planes reuse the image");
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t my = blockIdx.y * kRowsPerGroup + wave, seg = blockIdx.z;   // no integer division to find them
+    const uint32_t nseg = pm.nseg;
+    const uint32_t local = div_by(blockIdx.x, pm.per_frame, pm.magic_pf), piece = blockIdx.x - local * pm.per_frame;
+    const uint32_t item0 = pm.item_base + local;
+    const uint32_t row_group = div_by(piece, nseg, pm.magic_ns), seg = piece - row_group * nseg;
+    const uint32_t my = row_group * kRows + wave;
     if (my >= g.mcu_rows) return;                   // (the whole wave)
     int16_t* const s_mem = s_all[wave];
     int16_t* const s_y = s_mem;
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(kWave * kRowsPerGroup) void amv_reconstruct_kernel(
             qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
         }
     }
-    for (uint32_t item = blockIdx.x;; item += gridDim.x) {
+    for (uint32_t item = item0;; item += gridDim.x / pm.per_frame) {
     uint32_t f, slot;
     if (!select_frame(sel, n, item, f, slot)) return;
     const uint32_t m0 = seg * kSegMcus;
@@ -275,18 +292,39 @@ __global__ __launch_bounds__(kWave * kRowsPerGroup) void amv_reconstruct_kernel(
     }   // next item of the round
 }
 
+template <int kRows>
+static void launch_rows(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameSel& sel, uint32_t items, const FrameGeom& g,
+                        uint32_t flags, uint8_t* out, hipStream_t s) {
+    const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
+    const uint32_t row_groups = (g.mcu_rows + kRows - 1) / kRows;
+    auto magic = [](uint32_t d) { return (uint32_t)((0x100000000ull + d - 1u) / d); };   // (d = 1: unused)
+    PieceMap pm{row_groups * nseg, magic(row_groups * nseg), nseg, magic(nseg), 0u};
+    if (sel.round) {   // a round launch is small: its workgroups walk
+        const uint32_t walkers = items > 512u ? 512u : items;
+        hipLaunchKernelGGL((amv_reconstruct_kernel<true, kRows>), dim3(walkers * pm.per_frame), dim3(kWave * kRows), 0, s, sinks, nmcu_ok, n,
+                           sel, g, pm, flags, out);
+        return;
+    }
+    const uint32_t most = 0xffffffffu / (pm.per_frame * pm.per_frame);   // (workgroup number) * per_frame stays below 2^32
+    for (uint32_t base = 0; base < items; base += most) {
+        const uint32_t part = items - base < most ? items - base : most;
+        pm.item_base = base;
+        hipLaunchKernelGGL((amv_reconstruct_kernel<false, kRows>), dim3(part * pm.per_frame), dim3(kWave * kRows), 0, s, sinks, nmcu_ok, n,
+                           sel, g, pm, flags, out);
+    }
+}
+
 void launch_reconstruct(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_t n, const FrameSel& sel, uint32_t items,
                         const FrameGeom& g, uint32_t flags, uint8_t* out, hipStream_t s) {
     if (items == 0) return;
-    const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
-    const uint32_t row_groups = (g.mcu_rows + kRowsPerGroup - 1) / kRowsPerGroup;
-    if (sel.round) {
-        hipLaunchKernelGGL(amv_reconstruct_kernel<true>, dim3(items > 512u ? 512u : items, row_groups, nseg), dim3(kWave * kRowsPerGroup), 0, s,
-                           sinks, nmcu_ok, n, sel, g, nseg, flags, out);
-    } else {
-        hipLaunchKernelGGL(amv_reconstruct_kernel<false>, dim3(items, row_groups, nseg), dim3(kWave * kRowsPerGroup), 0, s, sinks, nmcu_ok, n,
-                           sel, g, nseg, flags, out);
-    }
+    // A workgroup's waves are consecutive MCU rows of one frame, and the last workgroup of a frame has idle slots unless
+    // the rows divide.  Fives only where fours waste a tenth of the slots more than fives do (176x144, 9 rows: 4.80 ms
+    // per 100 000 frames against 5.04): five waves do not spread evenly over a CU's four SIMDs, and 320x240 (15 rows,
+    // one slot in sixteen idle in fours) takes 6.29 ms per 64 000 frames in fives against 5.87 in fours.
+    const uint32_t slots4 = (g.mcu_rows + 3u) / 4u * 4u, slots5 = (g.mcu_rows + 4u) / 5u * 5u;
+    const uint32_t waste4 = slots4 - g.mcu_rows, waste5 = slots5 - g.mcu_rows;
+    if (10u * waste4 * slots5 >= 10u * waste5 * slots4 + slots4 * slots5) launch_rows<5>(sinks, nmcu_ok, n, sel, items, g, flags, out, s);
+    else launch_rows<kRowsPerGroup>(sinks, nmcu_ok, n, sel, items, g, flags, out, s);
 }
 
 }  // namespace amv
