@@ -125,23 +125,6 @@ __device__ __forceinline__ uint32_t sat_pair(uint32_t yy, uint32_t cc) {
 
 }  // namespace
 
-// Where a workgroup works, from its number alone.  The launch is one-dimensional.  A unit is a workgroup's rows of
-// one item, (item, row group), numbered item-major; a unit's segments are workgroups b, b + 8, b + 16, ...:
-//     b = ((unit / 8) * nseg + segment) * 8 + unit % 8.
-// Why: the two segments of a 320-pixel row share a 128-byte line of the picture (byte 480 of 960).  Written seconds of
-// work apart -- all frames' first segments, then all second ones: the order of a 3-D grid with the item in x -- that
-// line went to memory twice, half-filled (320x240: 5.84 ms per 64 000 frames; side by side in time: 5.66); and blocks b
-// and b + 8 share an XCD, hence an L2, so side by side in the same L2 the halves meet before they leave it.
-// The divisions are by numbers the host knows: it sends their reciprocals (floor(b / d) is the high word of
-// b * ceil(2^32 / d) while b * d < 2^32; the launch goes in parts where that would not hold).
-struct PieceMap {
-    uint32_t row_groups, magic_rg;   // workgroups of an item along its MCU rows
-    uint32_t nseg, magic_8ns;        // segments per MCU row; reciprocal of 8 * nseg
-    uint32_t units;                  // of this launch
-    uint32_t item_base;              // first item of this launch
-};
-__device__ __forceinline__ uint32_t div_by(uint32_t b, uint32_t d, uint32_t magic) { return d == 1u ? b : __umulhi(b, magic); }
-
 // kRound: a round launch (FrameSel::round != 0), whose workgroups walk the items of the round
 template <bool kRound, int kRows>
 __global__ __launch_bounds__(kWave * kRows) void amv_reconstruct_kernel(
@@ -153,12 +136,8 @@ __global__ __launch_bounds__(kWave * kRows) void amv_reconstruct_kernel(
     static_assert((16 * kPitchY + 2 * 8 * kPitchC) * 2 == kSegImageBytes, "the planes reuse the image");
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t nseg = pm.nseg;
-    const uint32_t octet = nseg == 1u ? blockIdx.x >> 3 : __umulhi(blockIdx.x, pm.magic_8ns);   // unit / 8
-    const uint32_t within = blockIdx.x - octet * 8u * nseg, seg = within >> 3;
-    const uint32_t unit = octet * 8u + (within & 7u);
-    if (unit >= pm.units) return;                   // (the launch is rounded up to whole octets of units)
-    const uint32_t local = div_by(unit, pm.row_groups, pm.magic_rg), row_group = unit - local * pm.row_groups;
-    const uint32_t item0 = pm.item_base + local;
+    uint32_t item0, row_group, seg;
+    if (!locate_piece(pm, blockIdx.x, item0, row_group, seg)) return;
     const uint32_t my = row_group * kRows + wave;
     if (my >= g.mcu_rows) return;                   // (the whole wave)
     int16_t* const s_mem = s_all[wave];
@@ -176,7 +155,7 @@ __global__ __launch_bounds__(kWave * kRows) void amv_reconstruct_kernel(
             qw[4 * i] = q.x; qw[4 * i + 1] = q.y; qw[4 * i + 2] = q.z; qw[4 * i + 3] = q.w;
         }
     }
-    for (uint32_t item = item0;; item += pm.units / pm.row_groups) {
+    for (uint32_t item = item0;; item += piece_stride(pm)) {
     uint32_t f, slot;
     if (!select_frame(sel, n, item, f, slot)) return;
     const uint32_t m0 = seg * kSegMcus;
@@ -304,24 +283,17 @@ static void launch_rows(const SyncSinks& sinks, const uint32_t* nmcu_ok, uint32_
                         uint32_t flags, uint8_t* out, hipStream_t s) {
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
     const uint32_t row_groups = (g.mcu_rows + kRows - 1) / kRows;
-    auto magic = [](uint32_t d) { return (uint32_t)((0x100000000ull + d - 1u) / d); };   // (d = 1: unused)
-    PieceMap pm{row_groups, magic(row_groups), nseg, magic(8u * nseg), 0u, 0u};
-    auto grid = [&](uint32_t walkers) {   // whole octets of units, nseg workgroups each
-        pm.units = walkers * row_groups;
-        return dim3((pm.units + 7u) / 8u * 8u * nseg);
-    };
+    PieceMap pm = make_piece_map(row_groups, nseg);
     if (sel.round) {   // a round launch is small: its workgroups walk
-        hipLaunchKernelGGL((amv_reconstruct_kernel<true, kRows>), grid(items > 512u ? 512u : items), dim3(kWave * kRows), 0, s, sinks, nmcu_ok,
-                           n, sel, g, pm, flags, out);
+        const uint32_t grid = set_walkers(pm, items > 512u ? 512u : items);
+        hipLaunchKernelGGL((amv_reconstruct_kernel<true, kRows>), dim3(grid), dim3(kWave * kRows), 0, s, sinks, nmcu_ok, n, sel, g, pm, flags, out);
         return;
     }
-    // (workgroup number) * 8 * nseg and (unit number) * row_groups stay below 2^32
-    const uint32_t widest = 8u * nseg > row_groups ? 8u * nseg : row_groups;
-    const uint32_t most = (0xffffffffu / widest - 8u * nseg) / (row_groups * nseg);
+    const uint32_t most = most_items(pm);
     for (uint32_t base = 0; base < items; base += most) {
         pm.item_base = base;
-        hipLaunchKernelGGL((amv_reconstruct_kernel<false, kRows>), grid(items - base < most ? items - base : most), dim3(kWave * kRows), 0, s,
-                           sinks, nmcu_ok, n, sel, g, pm, flags, out);
+        const uint32_t grid = set_walkers(pm, items - base < most ? items - base : most);
+        hipLaunchKernelGGL((amv_reconstruct_kernel<false, kRows>), dim3(grid), dim3(kWave * kRows), 0, s, sinks, nmcu_ok, n, sel, g, pm, flags, out);
     }
 }
 

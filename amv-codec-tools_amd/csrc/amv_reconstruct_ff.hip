@@ -68,12 +68,13 @@ __device__ __forceinline__ void sidct_col(int& c0, int& c1, int& c2, int& c3, in
 // kRound: a round launch (FrameSel::round != 0), whose workgroups walk the items of the round
 template <bool kRound>
 __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
-    SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameSel sel, FrameGeom g, uint64_t yuv_frame_bytes,
+    SyncSinks in, const uint32_t* __restrict__ nmcu_ok, uint32_t n, FrameSel sel, FrameGeom g, PieceMap pm, uint64_t yuv_frame_bytes,
     uint8_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_img[kSegImageBytes + 128];   // + a spare slot per lane (load_segment_blocks)
     const uint32_t lane = threadIdx.x;
-    const uint32_t my = blockIdx.y, seg = blockIdx.z;
-    for (uint32_t item = blockIdx.x;; item += gridDim.x) {
+    uint32_t item0, my, seg;   // (one MCU row per workgroup: the row group is the row)
+    if (!locate_piece(pm, blockIdx.x, item0, my, seg)) return;
+    for (uint32_t item = item0;; item += piece_stride(pm)) {
     uint32_t f, slot;
     if (!select_frame(sel, n, item, f, slot)) return;
     const uint32_t m0 = seg * kSegMcus;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
 
     uint32_t c[32];
     bool skip;
-    if (load_segment_blocks(in, f, slot, kRound, g, my * gridDim.z + seg, gridDim.y * gridDim.z, mcu0, cnt, ok, lane, s_img, c, skip)) {
+    if (load_segment_blocks(in, f, slot, kRound, g, my * pm.nseg + seg, g.mcu_rows * pm.nseg, mcu0, cnt, ok, lane, s_img, c, skip)) {
     const uint32_t m = lane / 6u, k6 = lane % 6u;
     const bool chroma = k6 >= 4u;
     const bool decoded = mcu0 + m < ok;
@@ -153,12 +154,17 @@ void launch_reconstruct_yuv(const SyncSinks& sinks, const uint32_t* nmcu_ok, uin
                             const FrameGeom& g, uint64_t yuv_frame_bytes, uint8_t* out, hipStream_t s) {
     if (items == 0) return;
     const uint32_t nseg = (g.mcu_cols + kSegMcus - 1) / kSegMcus;
+    PieceMap pm = make_piece_map(g.mcu_rows, nseg);   // (the launch order of amv_reconstruct_kernel: amv_block_load.h)
     if (sel.round) {
-        hipLaunchKernelGGL(amv_reconstruct_yuv_kernel<true>, dim3(items > 512u ? 512u : items, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks,
-                           nmcu_ok, n, sel, g, yuv_frame_bytes, out);
-    } else {
-        hipLaunchKernelGGL(amv_reconstruct_yuv_kernel<false>, dim3(items, g.mcu_rows, nseg), dim3(kWave), 0, s, sinks, nmcu_ok, n, sel, g,
-                           yuv_frame_bytes, out);
+        const uint32_t grid = set_walkers(pm, items > 512u ? 512u : items);
+        hipLaunchKernelGGL(amv_reconstruct_yuv_kernel<true>, dim3(grid), dim3(kWave), 0, s, sinks, nmcu_ok, n, sel, g, pm, yuv_frame_bytes, out);
+        return;
+    }
+    const uint32_t most = most_items(pm);
+    for (uint32_t base = 0; base < items; base += most) {
+        pm.item_base = base;
+        const uint32_t grid = set_walkers(pm, items - base < most ? items - base : most);
+        hipLaunchKernelGGL(amv_reconstruct_yuv_kernel<false>, dim3(grid), dim3(kWave), 0, s, sinks, nmcu_ok, n, sel, g, pm, yuv_frame_bytes, out);
     }
 }
 
