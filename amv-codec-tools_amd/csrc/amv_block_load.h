@@ -6,6 +6,8 @@
 // granules XOR-swizzled by block so that the per-lane 128-byte reads do not collide on banks) and added the DC base
 // of the entropy lane that decoded the block (SyncSinks::lane_tab).
 #pragma once
+#include <cstdlib>
+
 #include "amv_kernels.h"
 
 namespace amv {
@@ -79,7 +81,12 @@ inline uint32_t set_walkers(PieceMap& pm, uint32_t walkers) {
 }
 inline uint32_t most_items(const PieceMap& pm) {
     const uint32_t widest = 8u * pm.nseg > pm.row_groups ? 8u * pm.nseg : pm.row_groups;
-    return (0xffffffffu / widest - 8u * pm.nseg) / (pm.row_groups * pm.nseg);
+    const uint32_t most = (0xffffffffu / widest - 8u * pm.nseg) / (pm.row_groups * pm.nseg);
+    if (const char* e = getenv("AMVHIP_RECON_MOST")) {   // test knob: launch in parts of this many items
+        const long v = atol(e);
+        if (v > 0 && (unsigned long)v < most) return (uint32_t)v;
+    }
+    return most;
 }
 
 // dense_only: a round launch -- the frame's lines are in slot `slot` whatever rec_count says.  A default launch over

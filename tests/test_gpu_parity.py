@@ -549,6 +549,31 @@ def test_decode_fuzz_geometries_and_damage(ctx, orc):
         assert (got == want).all(), (case, w, h)
 
 
+def test_reconstruction_launch_in_parts_and_extreme_shapes(ctx, pkg, orc, monkeypatch):
+    """the reconstruction's one-dimensional launch (amv_block_load.h: PieceMap): shapes whose piece counts are not
+    powers of two (13 segments per MCU row; 40 MCU rows = 10 row groups; 9 rows = the five-row workgroups), and the
+    same batches launched in parts of 3 frames (what a batch too large for the reciprocal division gets) -- every
+    byte as the oracle's, in both output modes"""
+    rng = np.random.default_rng(5)
+    for w, h, n in ((2048, 16, 7), (16, 640, 7), (176, 144, 11), (320, 240, 10), (160, 120, 9)):
+        chunks = [orc.encode_frame(orc.synth_frame(SEED, 3 * t, w, h), w, h) for t in range(n)]
+        c = bytearray(chunks[n // 2])
+        c[len(c) // 2] ^= 0x10                                    # one damaged frame
+        chunks[n // 2] = bytes(c)
+        for most in (None, "3"):
+            if most:
+                monkeypatch.setenv("AMVHIP_RECON_MOST", most)
+            else:
+                monkeypatch.delenv("AMVHIP_RECON_MOST", raising=False)
+            got, st = _gpu_decode(ctx, chunks, w, h)              # (the knob is read at every launch)
+            want, wst = _oracle_decode(orc, chunks, w, h)
+            assert (st == wst).all() and (got == want).all(), (w, h, most)
+            got, st = _gpu_decode_ffmpeg(ctx, pkg, chunks, w, h)
+            want, wst = _oracle_decode_ffmpeg(orc, chunks, w, h)
+            assert (st == wst).all() and (got == want).all(), (w, h, most, "compat")
+    monkeypatch.delenv("AMVHIP_RECON_MOST", raising=False)
+
+
 def test_encode_fuzz_geometries(ctx, orc):
     """random even geometries (right and bottom edge replication, widths that are not 0 mod 4 or mod 16),
     padded source rows, both channel orders and both quantiser biases: chunks byte-identical to the oracle's"""
