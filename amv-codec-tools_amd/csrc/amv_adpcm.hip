@@ -110,20 +110,23 @@ __device__ const AdpcmTables kAdpcmTables = make_adpcm_tables();
 
 // LDS image of a workgroup that encodes: the rows, the reciprocals and the steps themselves.  Lanes look up rows of
 // their own, so a plain [89][32 bytes] table would put lanes whose indices differ by 8 on the same banks (a row is
-// an eighth of the 256-byte bank row).  Every half row exists sixteen times instead, once per 16-byte slot of the
-// bank row, and lane l reads slot l & 15: the sixteen lanes ds_read_b128 serves together ({0-3, 12-15, 20-27}, ...)
-// have sixteen different l & 15, so no look-up ever meets a conflict, whatever the indices.
-constexpr uint32_t kEncodeBlock = 256;   // 45 KB of tables per workgroup: three workgroups = twelve waves per CU
+// an eighth of the 256-byte bank row).  Every half row exists four times instead, and lane l reads copy l & 3: lanes
+// that ds_read_b128 serves together and that sit on different step indices meet on a bank only when their copies are
+// the same AND their indices differ by a multiple of four.  (Sixteen copies -- no conflict whatever the indices --
+// measured the same to the percent, alone and beside the video kernels: the walk waits for the look-up's latency, not
+// for its banks; 45 KB of LDS per workgroup kept a CU from taking the entropy kernel's workgroup next to this one.)
+constexpr uint32_t kEncodeBlock = 256;
+constexpr uint32_t kRowCopies = 4;       // 11 KB of tables per workgroup
 struct EncodeLds {
-    uint4 row[2][89][16];
+    uint4 row[2][89][kRowCopies];
     float rcp[96];
     uint32_t step[96];
 };
 
 __device__ __forceinline__ void load_encode_tables(EncodeLds& l) {
     const uint4* src = reinterpret_cast<const uint4*>(kAdpcmTables.row);
-    for (uint32_t i = threadIdx.x; i < 2u * 89u * 16u; i += blockDim.x) {
-        const uint32_t half = i / (89u * 16u), row = (i / 16u) % 89u;
+    for (uint32_t i = threadIdx.x; i < 2u * 89u * kRowCopies; i += blockDim.x) {
+        const uint32_t half = i / (89u * kRowCopies), row = (i / kRowCopies) % 89u;
         (&l.row[0][0][0])[i] = src[2u * row + half];
     }
     for (uint32_t i = threadIdx.x; i < 89u; i += blockDim.x) {
@@ -146,7 +149,7 @@ __device__ __forceinline__ EncodeState encode_state(int prev, int index, const E
 
 // one sample (biased by 32768) -> its nibble
 __device__ __forceinline__ uint32_t compress(EncodeState& s, uint32_t sample, const EncodeLds& l) {
-    const uint32_t slot = threadIdx.x & 15u;
+    const uint32_t slot = threadIdx.x & (kRowCopies - 1u);
     const uint4 ra = l.row[0][s.index][slot], rb = l.row[1][s.index][slot];
     uint32_t ad;
     asm("v_sad_u32 %0, %1, %2, 0" : "=v"(ad) : "v"(sample), "v"(s.prev));
