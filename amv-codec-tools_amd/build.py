@@ -25,7 +25,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = ["csrc/amv_decode.hip", "csrc/amv_decode_sync.hip", "csrc/amv_reconstruct.hip", "csrc/amv_reconstruct_ff.hip", "csrc/amv_encode.hip", "csrc/amv_encode_par.hip", "csrc/amv_resample.hip", "csrc/amv_adpcm.hip", "csrc/amv_synth.hip", "csrc/amvhip_api.hip"]
 C_SOURCES = ["host/amvlib_compat.c", "host/amv_container.c"]
-HEADERS = ["csrc/amv_tables.h", "csrc/amv_kernels.h", "csrc/amv_block_load.h", "csrc/amv_encode_common.h", "../include/amvhip.h"]
+HEADERS = ["csrc/amv_tables.h", "csrc/amv_kernels.h", "csrc/amv_block_load.h", "csrc/amv_piece_map.h", "csrc/amv_encode_common.h", "../include/amvhip.h"]
 
 # -fwrapv: the codec's integer pipeline is defined on two's-complement wrap (see amv_decode.hip)
 HIPFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fwrapv", "-fno-strict-aliasing", f"--offload-arch={ARCH}",

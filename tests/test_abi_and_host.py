@@ -252,3 +252,14 @@ def test_adpcm_float_quotient_is_exact(pkg):
     for i, s in enumerate(steps):                      # adpcm.c:66-76 step_table
         got = np.minimum((ad.astype(np.float32) * r[i]).astype(np.uint32), 7)
         assert (got == np.minimum(ad.astype(np.int64) * 4 // s, 7)).all(), s
+
+
+def test_reconstruction_piece_map_arithmetic(tmp_path):
+    """amv_piece_map.h (workgroup number -> item, row group, segment; the host's launch sizes): every workgroup of a
+    launch names a piece exactly once, a unit's segments are eight workgroups apart, and the divisions by reciprocal
+    hold up to the largest launch the host makes -- checked on the CPU by tests/c/piece_map_test.cc"""
+    exe = str(tmp_path / "piece_map_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "amv-codec-tools_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "c", "piece_map_test.cc"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
