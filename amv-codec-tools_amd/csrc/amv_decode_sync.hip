@@ -704,6 +704,9 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
 //     counter, every step adds (value AND "this is a DC symbol");
 //   * a record is written to the next staging slot at every step and counted by adding the entry's "carries a value"
 //     bit (which sits at the stride of a staging slot);
+//   * the records leave stride-aligned: a stride of eight symbols owns eight record positions (8 * stride + slot), its
+//     records in front, fillers behind, and every fourth stride all 64 lanes store their 32 positions as one 128-byte
+//     line each (see the loop);
 //   * the frame's end: once the blocks-to-go counter reaches 0 the looked-up entry is ANDed to zero: the lane stands
 //     still, consuming and emitting nothing, until the wave's slowest lane is done;
 //   * errors raise no branch: the entries are OR-ed along (one of their bits says "no such code") and a running unsigned
@@ -898,8 +901,8 @@ __device__ __forceinline__ void fast_skip(Stream& win, uint32_t ringb, FastState
 
 }  // namespace
 
-// dynamic LDS: [ the four tables, 32 KB | staged records, 2 * kFlush slots per wave | DC sums, 4 slots per wave |
-//                rings, 17 slots per wave ]
+// dynamic LDS: [ the four tables, 32 KB | staged records, 2 * kFlush slots per wave (a stride's eight, alternating) |
+//                DC sums, 4 slots per wave | rings, 17 slots per wave ]
 template <uint32_t kFlush>
 __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
@@ -953,78 +956,80 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
         FastState s{0xffffffffu, 0u, 5u, live ? 0u - (blocks_per_frame << 6) : 0u, 0u, ~0u};
         bool alive = live;
         uint32_t stop = 0;           // 1 no such code, 2 index past 63, 3 the frame's last block is done
-        uint32_t flushed = 0;        // records before this one have left for memory (a multiple of kFlush)
+        // The lane's records go out stride-aligned: record position 8 * stride + slot.  A stride's records (one per
+        // symbol that carries a value: <= 8) fill the front of its eight staging slots, fillers the rest, and after
+        // every fourth stride each lane's 32 slots leave as one 128-byte line -- all lanes in the same stride, so the
+        // eight store instructions of a line are issued once per four strides with every lane in them, not in every
+        // stride with the quarter of the lanes whose line happened to be full (and the registers a line waits in
+        // are filled by plain assignment: which quarter is the wave's business, not the lane's).  ~12 % of the
+        // stream are fillers (the end-of-block symbols' slots); the reader skips them as it skips the padding.
+        // (Records packed densely per lane, lines leaving whenever a lane had 32: 2.10 ms per 160 000 frames, this:
+        // 1.94; the stores moved a stride later, behind the next stream service's s_waitcnt: no different -- what that
+        // wait waits for is the stream words the OTHER lanes asked for a stride ago, profiles/r03_kernel_phases.txt.)
+        uint32_t stride_no = 0;      // (wave-uniform)
+        uint32_t recpos = 0;         // end of the last line this lane wrote
         uint32_t seg_next = 0, seg_col = 0, seg_blk = 0;   // the next MCU-row segment whose first DC symbol has not come yet
         uint32_t end_blocks = 0;     // whole blocks when the walk stopped
-        // records [flushed, flushed + 8) leave the staging area: the first three quarters of a 128-byte line wait in
-        // registers for the fourth, so that memory sees whole lines (a lane's staging column holds two bursts of 8)
-        uint4 held[6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) held[q] = make_uint4(0, 0, 0, 0);
-        auto flush = [&]() {
-            const uint32_t* p = stage + (flushed & (2u * kFlush - 1u)) * kWave;
-            const uint4 v0 = make_uint4(p[0], p[kWave], p[2 * kWave], p[3 * kWave]);
-            const uint4 v1 = make_uint4(p[4 * kWave], p[5 * kWave], p[6 * kWave], p[7 * kWave]);
-            const uint32_t quarter = (flushed >> 3) & 3u;
-            if (quarter == 3u && flushed + 8u <= out.cap_rec) {   // never past the frame's record space (a multiple of 32); an overfull frame is redone densely
-                uint4* d = reinterpret_cast<uint4*>(rec + flushed - 24u);
+        for (uint32_t q = 0; q < 2u * kFlush; ++q) stage_put<kFlush>(stage, q, kDummyRecord);
+        if (__ballot(alive) != 0ull) do {
+            const bool line_live = alive;   // records of this lane may come in these four strides
+            uint4 line[8];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) d[q] = held[q];
-                d[6] = v0; d[7] = v1;
-            }
-            // (selects in place: with a branch per quarter the compiler shuffled all 24 registers around the loop)
-#pragma unroll
-            for (uint32_t q = 0; q < 3u; ++q) {
-                const bool mine = quarter == q;
-                held[2u * q].x = mine ? v0.x : held[2u * q].x; held[2u * q].y = mine ? v0.y : held[2u * q].y;
-                held[2u * q].z = mine ? v0.z : held[2u * q].z; held[2u * q].w = mine ? v0.w : held[2u * q].w;
-                held[2u * q + 1u].x = mine ? v1.x : held[2u * q + 1u].x; held[2u * q + 1u].y = mine ? v1.y : held[2u * q + 1u].y;
-                held[2u * q + 1u].z = mine ? v1.z : held[2u * q + 1u].z; held[2u * q + 1u].w = mine ? v1.w : held[2u * q + 1u].w;
-            }
-            flushed += 8u;
-        };
-        if (__ballot(alive) != 0ull) do {   // (bottom-tested: with the test on top the compiler copies the 24 held registers at every loop entry)
-            if (alive) fast_service(win, (s.t + 1u) >> 5);
-            if ((s.rp8 >> 8) - flushed >= 8u) flush();
-            const bool running = alive;
-            const FastState start = s;
-            uint32_t worst = ~0u, seen = 0u;
-            fast_stride<kFlush, false>(ringb, stageb, sumb, 0u, s, seen, worst);
-            const bool trouble = alive && (worst < 15u || (seen & kFastInvalid) != 0u);
-            if (__ballot(trouble) != 0ull) {   // a damaged stream
-                if (trouble) {
-                    s = start;
-                    stop = fast_replay<false>(ringb, 0u, s);
-                    alive = false;
+            for (int quarter = 0; quarter < 4; ++quarter) {
+                if (alive) fast_service(win, (s.t + 1u) >> 5);
+                const bool running = alive;
+                s.rp8 = stride_no << 11;     // this stride's eight slots
+                const FastState start = s;
+                uint32_t worst = ~0u, seen = 0u;
+                fast_stride<kFlush, false>(ringb, stageb, sumb, 0u, s, seen, worst);
+                const bool trouble = alive && (worst < 15u || (seen & kFastInvalid) != 0u);
+                if (__ballot(trouble) != 0ull) {   // a damaged stream
+                    if (trouble) {
+                        s = start;
+                        stop = fast_replay<false>(ringb, 0u, s);
+                        alive = false;
+                        for (uint32_t q = s.rp8 >> 8; q < stride_no * 8u + 8u; ++q) stage_put<kFlush>(stage, q, kDummyRecord);   // what the stride staged past the stop
+                    }
                 }
-            }
-            if (alive && s.togo6 == 0u) { stop = 3u; alive = false; }
-            bool hit = false;
-            uint32_t blocks = 0;
-            if (running) {
-                blocks = blocks_per_frame + (uint32_t)((int32_t)s.togo6 >> 6);   // whole blocks so far
-                // blocks whose DC symbol is out: did the next segment's first one come in this stride?  (At most one
-                // does: a segment is >= 6 blocks = 12 symbols.)
-                hit = seg_next < sg.count && blocks + (s.k ? 1u : 0u) > seg_blk;
-                if (!alive) { end_blocks = blocks; s.togo6 = 0u; }   // stands still from here on
-            }
-            if (__ballot(hit) != 0ull) {
-                if (hit) {
-                    seg_out[seg_next++] = make_uint2(start.rp8 >> 8, s.rp8 >> 8);
-                    const bool last = seg_col + 1u == sg.per_row;
-                    seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
-                    seg_col = last ? 0u : seg_col + 1u;
+                if (alive && s.togo6 == 0u) { stop = 3u; alive = false; }
+                stage_put<kFlush>(stage, s.rp8 >> 8, kDummyRecord);   // the slot behind the last record (every symbol writes the next slot, counted or not)
+                {   // the stride's slots -> a quarter of the line; fillers take their place for the stride after the next
+                    uint32_t* p = stage + ((stride_no & 1u) * kFlush) * kWave;
+                    line[2 * quarter] = make_uint4(p[0], p[kWave], p[2 * kWave], p[3 * kWave]);
+                    line[2 * quarter + 1] = make_uint4(p[4 * kWave], p[5 * kWave], p[6 * kWave], p[7 * kWave]);
+#pragma unroll
+                    for (uint32_t q = 0; q < 8u; ++q) p[q * kWave] = kDummyRecord;
                 }
+                bool hit = false;
+                uint32_t blocks = 0;
+                if (running) {
+                    blocks = blocks_per_frame + (uint32_t)((int32_t)s.togo6 >> 6);   // whole blocks so far
+                    // blocks whose DC symbol is out: did the next segment's first one come in this stride?  (At most one
+                    // does: a segment is >= 6 blocks = 12 symbols.)
+                    hit = seg_next < sg.count && blocks + (s.k ? 1u : 0u) > seg_blk;
+                    if (!alive) { end_blocks = blocks; s.togo6 = 0u; }   // stands still from here on
+                }
+                if (__ballot(hit) != 0ull) {
+                    if (hit) {
+                        seg_out[seg_next++] = make_uint2(start.rp8 >> 8, s.rp8 >> 8);
+                        const bool last = seg_col + 1u == sg.per_row;
+                        seg_blk += 6u * (last ? sg.mcu_cols - seg_col * kSegMcus : kSegMcus);
+                        seg_col = last ? 0u : seg_col + 1u;
+                    }
+                }
+                ++stride_no;
+            }
+            if (line_live) {
+                const uint32_t at = (stride_no - 4u) * 8u;
+                if (at + 32u <= out.cap_rec) {   // never past the frame's record space (a multiple of 32); an overfull frame is redone densely
+                    uint4* d = reinterpret_cast<uint4*>(rec + at);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) d[q] = line[q];
+                }
+                recpos = at + 32u;
             }
         } while (__ballot(alive) != 0ull);
-        const uint32_t recpos = s.rp8 >> 8;
-        {   // what is still staged leaves padded to a whole line with records no block owns
-            const uint32_t end = (recpos + 31u) & ~31u;
-            while (flushed < end) {
-                for (uint32_t q = flushed < recpos ? recpos : flushed; q < flushed + 8u; ++q) stage_put<kFlush>(stage, q, kDummyRecord);
-                flush();
-            }
-        }
         if (live) {
             const uint32_t bits = s.t + 1u + (stop == 1u ? 17u : 0u);   // FORMAT: the reference has read 17 bits by then
             uint32_t st = stop == 1u ? kStFormat : (stop == 2u ? kStOverrun : 0u);
