@@ -908,8 +908,10 @@ __device__ __forceinline__ void fast_skip(Stream& win, uint32_t ringb, FastState
     bool active = (int32_t)(s.t - lim1) < 0;
     if (!__ballot(active)) return;
     fast_open_at(win, active ? (s.t + 1u) >> 5 : 0u);
+    bool have = true;            // fast_open_at asked for the next eight words
+    uint32_t stride_no = 1u;     // (the first request stride is three strides away: the ring was just filled)
     while (__ballot(active) != 0ull) {
-        if (active) fast_service(win, (s.t + 1u) >> 5);
+        fast_service_paced<kServicePace>(win, (s.t + 1u) >> 5, active, have, stride_no++);
 #pragma unroll
         for (int it = 0; it < kStrideWrite; ++it) {
             const uint32_t v = fast_window(ringb, s.t);
@@ -1208,8 +1210,10 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
         }
         if (__ballot(alive) != 0ull) {
         fast_open_at(win, alive ? (s.t + 1u) >> 5 : 0u);
+        bool have_words = true;      // fast_open_at asked for the next eight words
+        uint32_t stride_no = 1u;
         do {   // (bottom-tested, as in amv_huffman_fast_kernel)
-            if (alive) fast_service(win, (s.t + 1u) >> 5);
+            fast_service_paced<kServicePace>(win, (s.t + 1u) >> 5, alive, have_words, stride_no++);
             if ((s.rp8 >> 8) - flushed >= kFlush) {
                 stage_flush<kFlush>(stage, rec, flushed, out.cap_rec);
                 flushed += kFlush;
