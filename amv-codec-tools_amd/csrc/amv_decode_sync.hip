@@ -770,18 +770,9 @@ __device__ __forceinline__ void fast_open(Stream& s) {   // the ring holds words
     stream_request(s);
 }
 
-// before a stride: eight symbols of <= 27 bits starting in word w read words w .. w + 7 (and the one before w, whose
-// bits are all behind the position, at a word boundary: any content will do)
-__device__ __forceinline__ void fast_service(Stream& s, uint32_t w) {
-    while (w + 9u > s.hi) {
-        fast_ring_put(s, s.hi, s.pf0);
-        fast_ring_put(s, s.hi + 4u, s.pf1);
-        s.hi += 8u;
-        stream_request(s);
-    }
-}
-
-// The one-lane kernel's service: a lane puts its requested words into the ring when it needs them (any stride), but ASKS
+// Before a stride: eight symbols of <= 27 bits starting in word w read words w .. w + 7 (and the one before w, whose
+// bits are all behind the position, at a word boundary: any content will do), so the ring must reach word w + 8.
+// A lane puts its requested words into the ring when it needs them (any stride), but ASKS
 // for the next eight only in every kPace-th stride.  The wait in front of a put is s_waitcnt vmcnt(0): it is the wave's
 // and in order, so it waits for whatever any lane asked for last -- with requests in every stride that is always one
 // stride ago, HBM's latency under load; with requests kept to every kPace-th stride most strides find nothing young in
