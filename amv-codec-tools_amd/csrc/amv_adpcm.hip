@@ -184,35 +184,26 @@ __device__ __forceinline__ Bytes8 compress16(EncodeState& s, const uint32_t* w, 
 }
 
 // A chunk's samples from state s (m is even).  One lane owns the chunk, so what it waits for is its own memory
-// latency: the samples come a 128-byte line (64 samples) at a time, and the line after is requested before the
-// current one is worked on -- one exposed round trip per chunk instead of one per sixteen samples (the sweeps of the
-// index chain run a wave per SIMD or less: 130 us per sweep before, the chain itself takes half of that).
+// latency: the samples come a 128-byte line (64 samples) at a time -- one exposed round trip per 64 samples instead of
+// one per sixteen (the sweeps of the index chain run a wave per SIMD or less: 130 us per sweep before, the chain itself
+// takes most of that).  No look-ahead: with the next line requested a line ahead (and really in flight during the
+// arithmetic: requested without a branch, so that the compiler waits by count) the chain was 10 % slower -- 32 more
+// registers and their moves inside the dependent chain's code cost more than half a microsecond of waiting per line.
 template <bool kWrite>
 __device__ __forceinline__ void encode_run(const int16_t* __restrict__ x, uint32_t m, EncodeState& s,
                                            uint8_t* __restrict__ d, const EncodeLds& l) {
     uint32_t k = 0;
-    if (m >= 64u) {
-        Pcm8 cur[8], nxt[8];
+    for (; k + 64u <= m; k += 64u) {   // a 128-byte line (64 samples) at a time
+        Pcm8 cur[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cur[i] = *reinterpret_cast<const Pcm8*>(x + 8 * i);
-        for (; k + 64u <= m; k += 64u) {
-            const bool more = k + 128u <= m;
-            if (more) {
+        for (int i = 0; i < 8; ++i) cur[i] = *reinterpret_cast<const Pcm8*>(x + k + 8 * i);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) nxt[i] = *reinterpret_cast<const Pcm8*>(x + k + 64u + 8 * i);
-            }
+        for (int i = 0; i < 4; ++i) {
+            uint32_t w[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t w[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) w[j] = cur[2 * i + (j >> 2)].w[j & 3];
-                const Bytes8 o = compress16(s, w, l);
-                if (kWrite) *reinterpret_cast<Bytes8*>(d + (k >> 1) + 8 * i) = o;
-            }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-            }
+            for (int j = 0; j < 8; ++j) w[j] = cur[2 * i + (j >> 2)].w[j & 3];
+            const Bytes8 o = compress16(s, w, l);
+            if (kWrite) *reinterpret_cast<Bytes8*>(d + (k >> 1) + 8 * i) = o;
         }
     }
     for (; k + 16u <= m; k += 16u) {
