@@ -271,7 +271,8 @@ def run_decode(E, args):
         result["config"]["one_call_form"] = one_call   # amvhip_decode_batch_dev, one batch at a time, same stream
     result["roofline"] = roofline(
         kern, stream_bytes + n * 3 * w * h, elapsed / args.steps,
-        (lambda dom: profiled_traffic("", dom)) if (w, h, n) == (160, 120, DECODE_FRAMES) else None,
+        (lambda dom: profiled_traffic("", dom)) if (w, h, n) == (160, 120, DECODE_FRAMES) else
+        ((lambda dom: profiled_traffic("_decode320", dom)) if (w, h, n) == (320, 240, 128000) else None),
         {"entropy_sync_rounds": {"mean": sync["rounds"] / max(sync["frames"], 1), "max": sync["max_rounds"]}})
 
     if E.dist:          # config 4 as BASELINE.json states it, beside the weak-scaling line above

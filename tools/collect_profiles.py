@@ -21,7 +21,7 @@ for kind in ("stats", "stats_encode", "stats_coresident", "stats_adpcm"):
     hits = glob.glob(os.path.join(src, "%s_%s" % (tag, kind), "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, kind.replace("stats", "bench").replace("bench_", "bench_") if kind != "stats" else "bench")))
-for suffix in ("", "_encode"):
+for suffix in ("", "_encode", "_decode320"):
     f, w = os.path.join(src, "%s_pmc_fetch%s" % (tag, suffix)), os.path.join(src, "%s_pmc_write%s" % (tag, suffix))
     if os.path.isdir(f) and os.path.isdir(w):
         subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_pmc.py"), f, w, os.path.join(dst, tag + suffix)], check=True,

@@ -28,6 +28,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o run --outp
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write -o run --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $out/${tag}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch_encode -o run --output-format csv -- python3 $root/bench.py --workload encode --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch_encode.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write_encode -o run --output-format csv -- python3 $root/bench.py --workload encode --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write_encode.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch_decode320 -o run --output-format csv -- python3 $root/bench.py --width 320 --height 240 --frames 128000 --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch_decode320.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write_decode320 -o run --output-format csv -- python3 $root/bench.py --width 320 --height 240 --frames 128000 --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write_decode320.log 2>&1
 echo "pmc done"
 bash $root/tools/pmc_sq.sh ${tag}sq 160000
 bash $root/tools/pmc_sq_bench.sh ${tag}sqenc --workload encode
