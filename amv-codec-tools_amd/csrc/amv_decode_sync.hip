@@ -721,7 +721,7 @@ namespace {
 
 constexpr uint32_t kFastRegion = kFastWords * 4u;            // bytes per table in LDS
 constexpr uint32_t kFastTableBytes = 4u * kFastRegion;
-constexpr uint32_t kServicePace = 4u;                         // strides between the one-lane kernel's stream requests (fast_service_paced)
+constexpr uint32_t kServicePace = 4u;                         // strides between a wave's stream requests (fast_service_paced)
 constexpr uint32_t kSlot = kWave * 4u;                       // bytes between a lane's consecutive slots
 constexpr uint32_t kFastRingBytes = (kRingWords + 1u) * kSlot;   // slot 16 mirrors slot 0
 constexpr uint32_t kFastSumBytes = 4u * kSlot;                   // three sums; aligned to its size
