@@ -141,9 +141,27 @@ def profiled_traffic(tag, dom):
     return None, None
 
 
+def profiled_path_traffic(tag, names, min_bytes=1e8):
+    """the same passes, summed over every kernel of the path (the largest grid of each): what the path moves per step"""
+    path = os.path.join(ROOT, "profiles", "%s_traffic%s.json" % (TRAFFIC_ROUND, tag))
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    total = 0.0
+    for name in names:
+        hits = [rec["hbm_corrected"] for kname, rec in prof["kernels"].items()
+                if kname.split(" grid=")[0].split("<")[0].endswith(name) and rec["hbm_corrected"] > min_bytes]
+        total += max(hits) if hits else 0.0
+    return total or None
+
+
 def cpu_cores():
-    # a one-GPU box owns a 16-core share of the host whatever cpu_count says
-    return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("AMV_BENCH_CORES", "16"))))
+    """threads of the CPU leg = the cores this process may run on (its affinity mask, what `nproc` prints);
+    AMV_BENCH_CORES caps it from outside"""
+    avail = len(os.sched_getaffinity(0))
+    cap = os.environ.get("AMV_BENCH_CORES")
+    return max(1, min(avail, int(cap))) if cap else max(1, avail)
 
 
 def base_result(E, args, metric, unit, units_per_step_per_gpu, elapsed):
@@ -200,14 +218,20 @@ def run_decode(E, args):
             raise SystemExit("device-made stream differs from the oracle's encoder at frame %d" % (first + i))
 
     # ... and EVERY frame of the batch against a second decode of it with the other entropy kernel (the serial one-lane
-    # walk, amv_huffman_kernel + dense coefficient lines): two independent routes to the same bytes, compared on the device
-    d_ref = torch.empty_like(d_out)
-    d_st2 = torch.empty_like(d_st)
+    # walk, amv_huffman_kernel + dense coefficient lines): two independent routes to the same bytes, compared on the
+    # device, a slice of the batch at a time so that the gate holds one slice of reference frames, not a second batch
+    piece = max(1, min(n, (1 << 30) // (h * ctx.stride(w))))
+    d_ref = torch.empty((piece, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
+    d_st2 = torch.empty(piece, dtype=torch.int32, device=dev)
     ctx.set_entropy_mode(pkg.ENTROPY_SERIAL)
-    ctx.decode_batch_dev(d_blob, cap, d_offs, d_lens, n, w, h, 0, d_ref, d_st2, stream)
+    same = True
+    for lo in range(0, n, piece):
+        k = min(piece, n - lo)
+        ctx.decode_batch_dev(d_blob, cap, d_offs[lo:lo + k], d_lens[lo:lo + k], k, w, h, 0, d_ref, d_st2, stream)
+        torch.cuda.synchronize()
+        same = same and torch.equal(d_ref[:k], d_out[lo:lo + k]) and int((d_st2[:k] != 0).sum().item()) == 0
     ctx.set_entropy_mode(pkg.ENTROPY_AUTO)
-    torch.cuda.synchronize()
-    if not torch.equal(d_ref, d_out) or int((d_st2 != 0).sum().item()) != 0:
+    if not same:
         raise SystemExit("the batch decodes differently through the serial entropy kernel")
     del d_ref, d_st2
 
@@ -275,6 +299,12 @@ def run_decode(E, args):
         ((lambda dom: profiled_traffic("_decode320", dom)) if (w, h, n) == (320, 240, 128000) else None),
         {"entropy_sync_rounds": {"mean": sync["rounds"] / max(sync["frames"], 1), "max": sync["max_rounds"]}})
 
+    if (w, h, n) == (160, 120, DECODE_FRAMES):
+        pt = profiled_path_traffic("", ("amv_unstuff_kernel", "amv_huffman_fast_kernel", "amv_reconstruct_kernel"))
+        if pt:
+            result["roofline"]["path_traffic"] = pt            # all three decode kernels, counter bytes per step
+            result["config"]["decode_traffic_ratio"] = pt / (stream_bytes + n * 3 * w * h)
+
     if E.dist:          # config 4 as BASELINE.json states it, beside the weak-scaling line above
         result["config"]["scaling_modes"] = {"weak": "value / ms_per_step of this line: every GPU decodes its own %d frames" % n,
                                              "strong": "config4_strong_10k"}
@@ -290,7 +320,7 @@ def run_decode(E, args):
         _, st1 = orc.decode_batch(blob_h, o64, l32, w, h, 0, threads=1)
         t1 = time.perf_counter() - t
         reps, tn = 0, 0.0
-        while tn < 5.0 and reps < 64:         # bounded: a few seconds of all-core work
+        while tn < args.cpu_seconds and reps < 64:         # bounded: a few seconds of all-core work
             t = time.perf_counter()
             orc.decode_batch(blob_h, o64, l32, w, h, 0, threads=cores)
             tn += time.perf_counter() - t
@@ -299,7 +329,7 @@ def run_decode(E, args):
         result["cpu_baseline"] = {"value": m * reps / tn, "unit": "frames/s", "cores": cores, "kind": "port",
                                   "sample": "first %d frames of the same stream, CPU oracle (amvlib algorithm restated in C), "
                                             "frame-sharded over %d OpenMP threads, %d passes" % (m, cores, reps),
-                                  "single_thread_value": m / t1}
+                                  "single_thread_value": m / t1, "host_cpus_online": os.cpu_count()}
     return result
 
 
@@ -425,15 +455,22 @@ def run_encode(E, args):
                                   (lambda dom: profiled_traffic("_encode", dom)) if (w, h, n) == (320, 240, 8000) else None)
 
     if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
+        import concurrent.futures
         m = min(256, n)
         src = d_rgb[:m].cpu().numpy()
         t = time.perf_counter()
         for i in range(m):
             orc.encode_frame(src[i], w, h)
         t1 = time.perf_counter() - t
-        result["cpu_baseline"] = {"value": m / t1, "unit": "frames/s", "cores": 1, "kind": "port",
-                                  "sample": "first %d frames of the same source, CPU oracle (the reference build's encoder "
-                                            "algorithm restated in C), one thread" % m}
+        cores = cpu_cores()
+        with concurrent.futures.ThreadPoolExecutor(cores) as ex:      # the ctypes call drops the interpreter lock
+            t = time.perf_counter()
+            list(ex.map(lambda i: orc.encode_frame(src[i % m], w, h), range(4 * m)))
+            tn = time.perf_counter() - t
+        result["cpu_baseline"] = {"value": 4 * m / tn, "unit": "frames/s", "cores": cores, "kind": "port",
+                                  "sample": "first %d frames of the same source x4, CPU oracle (the reference build's encoder "
+                                            "algorithm restated in C), one frame per call over %d threads" % (m, cores),
+                                  "single_thread_value": m / t1}
     return result
 
 
@@ -555,6 +592,31 @@ def run_adpcm(E, args, with_video=False):
         result["cpu_baseline"] = {"value": 2 * m * spf / t1, "unit": "samples/s", "cores": 1, "kind": "port",
                                   "sample": "first %d chunks of the same audio, CPU oracle encode + decode, one thread "
                                             "(includes the ctypes call per chunk)" % m}
+    if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline and with_video:
+        # the CPU path for the same unit of work: one 320x240 frame decoded + its audio chunk encoded and decoded
+        m = min(n, args.cpu_sample, 512)
+        blob_h = d_blob[: int(offs_h[m - 1]) + int(lens_h[m - 1]) + 16].cpu().numpy()
+        o64, l32 = offs_h[:m].astype(np.uint64), lens_h[:m].astype(np.uint32)
+        pcm = d_pcm[: m * spf].cpu().numpy()
+        ch = d_chunks[: m * clen].cpu().numpy()
+        cores = cpu_cores()
+        t = time.perf_counter()
+        orc.decode_batch(blob_h, o64, l32, w, h, 0, threads=1)
+        tv1 = time.perf_counter() - t
+        t = time.perf_counter()
+        orc.decode_batch(blob_h, o64, l32, w, h, 0, threads=cores)
+        tvn = time.perf_counter() - t
+        t = time.perf_counter()
+        idx = 0
+        for i in range(m):
+            _, idx = orc.adpcm_encode_chunk(pcm[i * spf:(i + 1) * spf], idx)
+            orc.adpcm_decode_chunk(ch[i * clen:(i + 1) * clen])
+        ta = time.perf_counter() - t
+        result["cpu_baseline"] = {"value": m / (tvn + ta), "unit": "frames/s", "cores": cores, "kind": "port",
+                                  "sample": "first %d frames: CPU oracle video decode frame-sharded over %d threads, then the "
+                                            "frames' audio chunks encoded (index carried: a serial chain) and decoded on one "
+                                            "thread" % (m, cores),
+                                  "single_thread_value": m / (tv1 + ta)}
     if with_video:
         E.extra_ctx = []
         actx.close()
@@ -650,21 +712,28 @@ def run_secondary(E, args):
             ("adpcm", lambda e, a: run_adpcm(e, a, with_video=False), {}))
     for name, fn, over in plan:
         a = copy.copy(args)
-        a.no_cpu_baseline, a.steps, a.warmup = True, min(args.steps, 10), min(args.warmup, 2)
+        a.steps, a.warmup = min(args.steps, 10), min(args.warmup, 2)
+        a.cpu_sample, a.cpu_seconds = 512, 1.0     # bounded CPU legs: every entry carries the CPU path beside it
         for k, v in over.items():
             setattr(a, k, v)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         t0 = time.perf_counter()
-        r = fn(E, a)
+        try:
+            r = fn(E, a)
+        except torch.OutOfMemoryError as e:        # a smaller part than the 288 GB this is sized for: say so, keep the line
+            E.extra_ctx = []
+            out[name] = {"skipped": "out of device memory: %s" % str(e).splitlines()[0]}
+            continue
         E.extra_ctx = []
         roof = r["roofline"]
         entry_ = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
                   "workload": r["config"]["workload"], "kernels": roof["kernels"],
                   "roofline": {k: roof[k] for k in ("kernel", "achieved", "frac", "path_achieved", "path_frac", "traffic", "traffic_source",
                                                     "algorithmic_bytes_per_launch")},
-                  "wall_s": None}
-        for k in ("mean_chunk_bytes", "round_trip_psnr_db", "psnr_floor_db", "bit_exact_vs_cpu_encoder", "adpcm_samples_per_s", "gate"):
+                  "cpu_baseline": r.get("cpu_baseline"), "wall_s": None}
+        for k in ("mean_chunk_bytes", "round_trip_psnr_db", "psnr_floor_db", "bit_exact_vs_cpu_encoder", "adpcm_samples_per_s", "gate",
+                  "handed_to_serial", "stream"):
             if k in r["config"]:
                 entry_[k] = r["config"][k]
         if "co_resident_audio_kernels" in roof:
@@ -672,6 +741,36 @@ def run_secondary(E, args):
         entry_["wall_s"] = time.perf_counter() - t0
         out[name] = entry_
     return out
+
+
+def flat_secondary(sec):
+    """the secondary entries once more as flat scalars of `config`: a record that keeps scalars only still carries every
+    BASELINE config's rate, roofline fraction and the CPU path beside it"""
+    names = {"decode_320x240": "c320_decode", "decode_160x120_10k_stream": "stream10k", "encode_320x240": "enc320",
+             "coresident_320x240_adpcm": "coresident", "adpcm": "adpcm", "decode_160x120_mixed": "mixed160",
+             "decode_amv1_looped": "amv1"}
+    flat = {}
+    for name, e in sec.items():
+        p = names.get(name, name)
+        if "skipped" in e:
+            flat[p + "_skipped"] = e["skipped"]
+            continue
+        unit = "sps" if e["unit"].startswith("samples") else "fps"
+        flat["%s_%s" % (p, unit)] = e["value"]
+        flat[p + "_ms"] = e["ms_per_step"]
+        flat[p + "_frac"] = e["roofline"]["frac"]
+        flat[p + "_path_frac"] = e["roofline"]["path_frac"]
+        cb = e.get("cpu_baseline")
+        if cb:
+            flat["%s_cpu_%s" % (p, unit)] = cb["value"]
+            flat[p + "_cpu_cores"] = cb["cores"]
+            if "single_thread_value" in cb:
+                flat["%s_cpu1_%s" % (p, unit)] = cb["single_thread_value"]
+        if "handed_to_serial" in e:
+            flat[p + "_handed_to_serial"] = e["handed_to_serial"]
+        if "adpcm_samples_per_s" in e:
+            flat[p + "_adpcm_sps"] = e["adpcm_samples_per_s"]
+    return flat
 
 
 def main():
@@ -695,6 +794,7 @@ def main():
                     help="decode: also run configs[3] as stated (one 10 000-frame stream scattered from rank 0, decoded, gathered "
                          "back) and report it under config.config4_strong_10k; always on when WORLD_SIZE > 1")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="frames of the stream the CPU baseline decodes")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="bound on the all-core part of the CPU baseline")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default line only: skip the other BASELINE configs (config.secondary)")
     args = ap.parse_args()
@@ -727,7 +827,9 @@ def main():
         result = run_decode(E, args)
         plain = not (args.frames or args.width or args.height or args.pipelined or args.strong)
         if plain and E.world == 1 and not args.no_secondary:
-            result["config"]["secondary"] = run_secondary(E, args)
+            sec = run_secondary(E, args)
+            result["config"].update(flat_secondary(sec))
+            result["config"]["secondary"] = sec
     elif args.workload == "encode":
         result = run_encode(E, args)
     elif args.workload == "coresident":
