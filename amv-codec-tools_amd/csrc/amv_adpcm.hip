@@ -64,26 +64,33 @@ __device__ __forceinline__ int expand(int& predictor, int& index, uint32_t nibbl
     return predictor;
 }
 
-// adpcm_ima_compress_sample, adpcm.c:219-227, shaped for a lane that is alone on its SIMD (the sweeps of the index chain
-// are as long as one chunk's serial chain, so what counts is the length of the dependency chain per sample, not the
-// instruction count):
-//   * samples and predictor are kept biased by 32768, so |delta| is one v_sad_u32 and the clip is a med3 to 0..65535;
-//   * min(7, |delta| * 4 / step) is one float multiply: trunc(float(|delta|) * r) with r = 4 / step nudged up by 2^-20.
-//     Exact for every |delta| < 65536 and every step of the table: the nudge outweighs the two roundings (2^-23 each) so
-//     exact multiples do not fall short, and 7 * (2^-20 + 2^-22) < 1 / 32767, the closest a quotient below 8 comes to the
-//     next integer from underneath (tests/test_abi_and_host.py checks all 89 x 65536 cases against the integer division
-//     with the table amvhip_adpcm_quotient_table hands out);
-//   * the table look-up for the NEXT step leaves the chain: the index moves by -1, +2, +4, +6 or +8, so the five steps it
-//     can arrive at and their reciprocals (a 32-byte row per index: AdpcmRow) are requested as soon as the index is
-//     known, a sample ahead of their use, and the quotient picks among them (one byte permute + selects).
-struct AdpcmRow {
-    uint32_t s12, s34, s0;   // the step after a move of +2 | +4 << 16, of +6 | +8 << 16, of -1
-    float r0, r1, r2, r3, r4;  // reciprocals (4 / step, nudged) in the order -1, +2, +4, +6, +8
+// adpcm_ima_compress_sample, adpcm.c:219-227, shaped for a lane that is alone on its SIMD.  The sweeps of the index chain are
+// as long as ONE chunk's serial chain, and a lone wave on gfx950 pays 9 cycles per dependent vector instruction, 5.4 - 6.3
+// per independent one and ~60 per LDS read (tools/microbench_lone_wave.hip, profiles/r04_lone_wave.txt): what counts is the
+// number of instructions per sample AND the length of the two loops that run through them (predictor -> predictor,
+// quantiser factor -> nibble -> next factor).  Everything is float arithmetic on exactly representable values:
+//   * d = sample - predictor; min(7, |d| * 4 / step) + 8 = min(15, trunc(fma(|d|, r, 8))) with r = 4 / step nudged up by 2^-20:
+//     exact for every |d| < 65536 and every step of the table -- the nudge (<= 2^-17 on a quotient below 8) plus the roundings
+//     of r and of the fma (2^-21 each) stay under 1 / 32767, the closest a quotient comes to the next integer from underneath,
+//     and an exact multiple k >= 1 lands at k + 0.9 * 2^-20 - 2^-21 > k (tests/test_abi_and_host.py checks all 89 x 65536
+//     cases against the integer division with the table amvhip_adpcm_quotient_table hands out, product and fma form);
+//   * the + 8 is there for its bit pattern: a float in [8, 16) is 0x41000000 | q << 20, so byte 2 of it is 16 * q -- the offset
+//     of cell q in a row of 16-byte cells (one SDWA add makes the LDS address, no conversion) and the nibble's magnitude in
+//     place for the output byte (one SDWA move);
+//   * (step * (2 q + 1)) >> 3 = trunc(fma(q + 8, step / 4, step / 8 - 2 step)): a multiple of 1/8 below 2^16, exact;
+//   * the table is indexed by (step index, q) and holds the state AFTER that move -- step / 4, step / 8 - 2 step, r and the row
+//     of the new index (AdpcmCell, 89 x 8 cells of 16 bytes): index_table, the clamp to 0..88 and the step look-up are one
+//     ds_read_b128 whose address is row + byte 2 of (q + 8).
+// 15 vector instructions per sample with output, 12 without (27 with the integer form of round 3); the predictor loop is nine
+// instructions long, the factor loop four + the LDS read.
+struct AdpcmCell {
+    float s4, s8m, rcp;   // step / 4, step / 8 - 2 * step, quotient factor of the index this cell leads to
+    uint32_t row;         // byte offset of that index's row of cells
 };
-static_assert(sizeof(AdpcmRow) == 32, "two 16-byte LDS reads per row");
+static_assert(sizeof(AdpcmCell) == 16, "one ds_read_b128 per sample");
 
 struct AdpcmTables {
-    AdpcmRow row[89];
+    AdpcmCell cell[89][8];
     float rcp[89];
 };
 
@@ -92,15 +99,14 @@ constexpr int clip_index_c(int v) { return v < 0 ? 0 : (v > 88 ? 88 : v); }
 constexpr AdpcmTables make_adpcm_tables() {
     AdpcmTables t{};
     for (int i = 0; i < 89; ++i) {
-        const int to[5] = {clip_index_c(i - 1), clip_index_c(i + 2), clip_index_c(i + 4), clip_index_c(i + 6), clip_index_c(i + 8)};
-        t.row[i].s0 = (uint32_t)kImaStep[to[0]];
-        t.row[i].s12 = (uint32_t)kImaStep[to[1]] | ((uint32_t)kImaStep[to[2]] << 16);
-        t.row[i].s34 = (uint32_t)kImaStep[to[3]] | ((uint32_t)kImaStep[to[4]] << 16);
-        t.row[i].r0 = quotient_factor(kImaStep[to[0]]);
-        t.row[i].r1 = quotient_factor(kImaStep[to[1]]);
-        t.row[i].r2 = quotient_factor(kImaStep[to[2]]);
-        t.row[i].r3 = quotient_factor(kImaStep[to[3]]);
-        t.row[i].r4 = quotient_factor(kImaStep[to[4]]);
+        for (int q = 0; q < 8; ++q) {
+            const int to = clip_index_c(i + (q < 4 ? -1 : 2 * q - 6));       // kImaIndexAdjust
+            const int step = kImaStep[to];
+            t.cell[i][q].s4 = (float)(step / 4.0);
+            t.cell[i][q].s8m = (float)(step / 8.0 - 2.0 * step);
+            t.cell[i][q].rcp = quotient_factor(step);
+            t.cell[i][q].row = (uint32_t)to * 128u;
+        }
         t.rcp[i] = quotient_factor(kImaStep[i]);
     }
     return t;
@@ -108,85 +114,113 @@ constexpr AdpcmTables make_adpcm_tables() {
 static constexpr AdpcmTables kAdpcmHost = make_adpcm_tables();
 __device__ const AdpcmTables kAdpcmTables = make_adpcm_tables();
 
-// LDS image of a workgroup that encodes: the rows, the reciprocals and the steps themselves.  Lanes look up rows of
-// their own, so a plain [89][32 bytes] table would put lanes whose indices differ by 8 on the same banks (a row is
-// an eighth of the 256-byte bank row).  Every half row exists four times instead, and lane l reads copy l & 3: lanes
-// that ds_read_b128 serves together and that sit on different step indices meet on a bank only when their copies are
-// the same AND their indices differ by a multiple of four.  (Sixteen copies -- no conflict whatever the indices --
-// measured the same to the percent, alone and beside the video kernels: the walk waits for the look-up's latency, not
-// for its banks; 45 KB of LDS per workgroup kept a CU from taking the entropy kernel's workgroup next to this one.)
-constexpr uint32_t kEncodeBlock = 256;
-constexpr uint32_t kRowCopies = 4;       // 11 KB of tables per workgroup
+// LDS image of a workgroup that encodes: the cells (11.4 KB)
+constexpr uint32_t kEncodeBlock = 128;   // two waves share the cells: 19.6 KB of LDS, eight workgroups per CU
 struct EncodeLds {
-    uint4 row[2][89][kRowCopies];
-    float rcp[96];
-    uint32_t step[96];
+    uint4 cell[89 * 8];
 };
 
 __device__ __forceinline__ void load_encode_tables(EncodeLds& l) {
-    const uint4* src = reinterpret_cast<const uint4*>(kAdpcmTables.row);
-    for (uint32_t i = threadIdx.x; i < 2u * 89u * kRowCopies; i += blockDim.x) {
-        const uint32_t half = i / (89u * kRowCopies), row = (i / kRowCopies) % 89u;
-        (&l.row[0][0][0])[i] = src[2u * row + half];
-    }
-    for (uint32_t i = threadIdx.x; i < 89u; i += blockDim.x) {
-        l.rcp[i] = kAdpcmTables.rcp[i];
-        l.step[i] = (uint32_t)kImaStep[i];
-    }
+    const uint4* src = reinterpret_cast<const uint4*>(&kAdpcmTables.cell[0][0]);
+    for (uint32_t i = threadIdx.x; i < 89u * 8u; i += blockDim.x) l.cell[i] = src[i];
     __syncthreads();
 }
 
 struct EncodeState {
-    uint32_t prev;   // predictor + 32768
-    uint32_t index;
-    uint32_t step;   // kImaStep[index]
-    float rcp;       // its quotient factor
+    float prev;            // predictor
+    float s4, s8m, rcp;    // of the current step index
+    uint32_t row;          // 128 * step index
 };
 
+__device__ __forceinline__ void take_cell(EncodeState& s, const uint4& c) {
+    s.s4 = __uint_as_float(c.x);
+    s.s8m = __uint_as_float(c.y);
+    s.rcp = __uint_as_float(c.z);
+    s.row = c.w;
+}
+
 __device__ __forceinline__ EncodeState encode_state(int prev, int index, const EncodeLds& l) {
-    return EncodeState{(uint32_t)(prev + 32768), (uint32_t)index, l.step[index], l.rcp[index]};
+    EncodeState s;
+    s.prev = (float)prev;
+    take_cell(s, index < 88 ? l.cell[(index + 1) * 8] : l.cell[88 * 8 + 4]);   // a cell that leads to `index`
+    return s;
 }
 
-// one sample (biased by 32768) -> its nibble
-__device__ __forceinline__ uint32_t compress(EncodeState& s, uint32_t sample, const EncodeLds& l) {
-    const uint32_t slot = threadIdx.x & (kRowCopies - 1u);
-    const uint4 ra = l.row[0][s.index][slot], rb = l.row[1][s.index][slot];
-    uint32_t ad;
-    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(ad) : "v"(sample), "v"(s.prev));
-    const uint32_t sign = sample < s.prev ? 1u : 0u;
-    const uint32_t q = min((uint32_t)((float)ad * s.rcp), 7u);
-    const uint32_t mag = __umul24(s.step, 2u * q + 1u) >> 3;                      // step * yamaha_difflookup[nibble] / 8
-    const int moved = (int)(s.prev + (mag ^ (0u - sign)) + sign);                 // prev -+ mag
-    s.prev = (uint32_t)min(max(moved, 0), 65535);
-    const uint32_t up = __builtin_amdgcn_ubfe(0x97530000u, q * 4u, 4u);           // kImaIndexAdjust[q] + 1
-    s.index = (uint32_t)min(max((int)(s.index + up) - 1, 0), 88);
-    const bool low = q < 4u, odd = (q & 1u) != 0u;
-    const uint32_t hop = __builtin_amdgcn_perm(ra.y, ra.x, __umul24(q, 0x0202u) + 0x0c0bf8f8u);   // halves 0..3 of {s12, s34} for q = 4..7
-    s.step = low ? ra.z : hop;
-    const float r12 = odd ? __uint_as_float(rb.y) : __uint_as_float(rb.x);
-    const float r34 = odd ? __uint_as_float(rb.w) : __uint_as_float(rb.z);
-    s.rcp = low ? __uint_as_float(ra.w) : (q < 6u ? r12 : r34);
-    return q | (sign << 3);
+__device__ __forceinline__ int state_index(const EncodeState& s) { return (int)(s.row >> 7); }
+
+// One sample.  kSlot < 4 (kWrite): the nibble goes to byte kSlot of the pair (qb, sb) as magnitude << 4 and sign << 7.
+template <bool kWrite, int kSlot>
+__device__ __forceinline__ void compress(EncodeState& s, float sample, const EncodeLds& l, uint32_t& qb, uint32_t& sb, uint32_t& tick) {
+    const float d = sample - s.prev;
+    const float q8 = fminf(truncf(__builtin_fmaf(__builtin_fabsf(d), s.rcp, 8.0f)), 15.0f);
+    const float mag = truncf(__builtin_fmaf(q8, s.s4, s.s8m));                      // step * yamaha_difflookup[nibble] / 8
+    s.prev = __builtin_amdgcn_fmed3f(s.prev + __builtin_copysignf(mag, d), -32768.0f, 32767.0f);
+    uint32_t addr;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"
+        : "=v"(addr) : "v"(s.row), "v"(q8));
+    take_cell(s, *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(l.cell) + addr));
+    tick = __float_as_uint(q8);     // known before the cell is asked for: what the next sample's conversion is tied behind
+    if (kWrite) {
+        const uint32_t c80 = 0x80u;
+        if (kSlot == 0) {
+            asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(qb) : "v"(q8));
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(sb) : "v"(d), "v"(c80));
+        } else if (kSlot == 1) {
+            asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(qb) : "v"(q8));
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(sb) : "v"(d), "v"(c80));
+        } else if (kSlot == 2) {
+            asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(qb) : "v"(q8));
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(sb) : "v"(d), "v"(c80));
+        } else {
+            asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(qb) : "v"(q8));
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(sb) : "v"(d), "v"(c80));
+        }
+    }
 }
 
-// sixteen samples (eight words, biased here) -> eight bytes
+// the two samples of a word as floats (one SDWA conversion each).  `after` is not read: it ties the conversion behind the
+// state it names, or the scheduler converts a whole line's 64 samples ahead and the kernel needs 140 registers
+__device__ __forceinline__ float sample_lo(uint32_t w, uint32_t after) {
+    float f;
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f) : "v"(w), "v"(after));
+    return f;
+}
+__device__ __forceinline__ float sample_hi(uint32_t w, uint32_t after) {
+    float f;
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(w), "v"(after));
+    return f;
+}
+
+// eight samples (four words) -> four bytes: every byte of (qb | sb) holds one nibble << 4; :489-493 high nibble = earlier sample
+template <bool kWrite>
+__device__ __forceinline__ uint32_t compress8(EncodeState& s, const uint32_t* w, const EncodeLds& l) {
+    uint32_t q0 = 0u, s0 = 0u, q1 = 0u, s1 = 0u, tick = s.row;
+    compress<kWrite, 0>(s, sample_lo(w[0], tick), l, q0, s0, tick);
+    compress<kWrite, 1>(s, sample_hi(w[0], tick), l, q0, s0, tick);
+    compress<kWrite, 2>(s, sample_lo(w[1], tick), l, q0, s0, tick);
+    compress<kWrite, 3>(s, sample_hi(w[1], tick), l, q0, s0, tick);
+    compress<kWrite, 0>(s, sample_lo(w[2], tick), l, q1, s1, tick);
+    compress<kWrite, 1>(s, sample_hi(w[2], tick), l, q1, s1, tick);
+    compress<kWrite, 2>(s, sample_lo(w[3], tick), l, q1, s1, tick);
+    compress<kWrite, 3>(s, sample_hi(w[3], tick), l, q1, s1, tick);
+    if (!kWrite) return 0u;
+    const uint32_t a = q0 | s0, b = q1 | s1;
+    const uint32_t even = __builtin_amdgcn_perm(b, a, 0x06040200u), odd = __builtin_amdgcn_perm(b, a, 0x07050301u);
+    return even | (odd >> 4);
+}
+
+// sixteen samples (eight words) -> eight bytes
+template <bool kWrite>
 __device__ __forceinline__ Bytes8 compress16(EncodeState& s, const uint32_t* w, const EncodeLds& l) {
     Bytes8 o;
-    o.w[0] = 0u;
-    o.w[1] = 0u;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t word = w[j >> 1] ^ 0x80008000u;
-        const uint32_t nib = compress(s, (j & 1) ? word >> 16 : word & 0xffffu, l);
-        o.w[j >> 3] |= nib << (8 * ((j >> 1) & 3) + ((j & 1) ? 0 : 4));   // :489-493 high nibble = earlier sample
-    }
+    o.w[0] = compress8<kWrite>(s, w, l);
+    o.w[1] = compress8<kWrite>(s, w + 4, l);
     return o;
 }
 
 // A chunk's samples from state s (m is even).  One lane owns the chunk, so what it waits for is its own memory
 // latency: the samples come a 128-byte line (64 samples) at a time -- one exposed round trip per 64 samples instead of
-// one per sixteen (the sweeps of the index chain run a wave per SIMD or less: 130 us per sweep before, the chain itself
-// takes most of that).  No look-ahead: with the next line requested a line ahead (and really in flight during the
+// one per sixteen.  No look-ahead: with the next line requested a line ahead (and really in flight during the
 // arithmetic: requested without a branch, so that the compiler waits by count) the chain was 10 % slower -- 32 more
 // registers and their moves inside the dependent chain's code cost more than half a microsecond of waiting per line.
 template <bool kWrite>
@@ -202,7 +236,7 @@ __device__ __forceinline__ void encode_run(const int16_t* __restrict__ x, uint32
             uint32_t w[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) w[j] = cur[2 * i + (j >> 2)].w[j & 3];
-            const Bytes8 o = compress16(s, w, l);
+            const Bytes8 o = compress16<kWrite>(s, w, l);
             if (kWrite) *reinterpret_cast<Bytes8*>(d + (k >> 1) + 8 * i) = o;
         }
     }
@@ -210,14 +244,148 @@ __device__ __forceinline__ void encode_run(const int16_t* __restrict__ x, uint32
         const Pcm8 a = *reinterpret_cast<const Pcm8*>(x + k);
         const Pcm8 b = *reinterpret_cast<const Pcm8*>(x + k + 8u);
         const uint32_t w[8] = {a.w[0], a.w[1], a.w[2], a.w[3], b.w[0], b.w[1], b.w[2], b.w[3]};
-        const Bytes8 o = compress16(s, w, l);
+        const Bytes8 o = compress16<kWrite>(s, w, l);
         if (kWrite) *reinterpret_cast<Bytes8*>(d + (k >> 1)) = o;
     }
     for (; k < m; k += 2u) {
-        const uint32_t hi = compress(s, (uint32_t)(x[k] + 32768), l);
-        const uint32_t lo = compress(s, (uint32_t)(x[k + 1u] + 32768), l);
-        if (kWrite) d[k >> 1] = (uint8_t)((hi << 4) | lo);
+        uint32_t qb = 0u, sb = 0u, tick;
+        compress<kWrite, 1>(s, (float)x[k], l, qb, sb, tick);
+        compress<kWrite, 0>(s, (float)x[k + 1u], l, qb, sb, tick);
+        if (kWrite) d[k >> 1] = (uint8_t)((((qb | sb) >> 8) & 0xf0u) | (((qb | sb) >> 4) & 0x0fu));
     }
+}
+
+// ---- a wave's 64 chunks at a time, samples and bytes staged through LDS ---------------------------------------------
+// One lane per chunk makes every lane read and write lines of its own: 64 lines per memory instruction, 16 bytes of each
+// read and 8 written at a time.  Measured on the guess pass over 200 000 chunks (variant builds, tools/time_adpcm.py):
+// 572 us as that, 249 with the stores left out, 210 with the loads aimed at one line, 154 with neither -- the arithmetic
+// is a quarter of the kernel, the rest is the shape of its memory accesses.  Here the WAVE moves the data: a tile of 32
+// samples per row is fetched as 64-byte pieces (four lanes to a row, sixteen rows to an instruction) a tile ahead of
+// the arithmetic, into sixteen registers that go to LDS when the tile's turn comes; every lane then reads its own row.
+// The bytes a lane makes collect in registers for four tiles and leave through the same LDS tile as 64-byte pieces,
+// again four lanes to a row.  (16-byte pieces of a row sit XOR-ed with bits of the row number: the lanes one ds pass
+// serves meet on a bank two at a time.)  All 64 lanes of a wave call encode_rows together; a lane without work passes
+// m = 0.  LDS-DMA for the fetch (global_load_lds_dwordx4 into a second buffer, no registers) was slower: a wave that is
+// alone on its SIMD -- the sweeps -- pays 100+ cycles to issue each piece, and hipcc follows the builtin with
+// s_waitcnt vmcnt(0) as soon as any LDS read comes behind it.
+constexpr uint32_t kTile = 32;               // samples per row and tile (64 bytes in, 16 bytes out)
+struct StageLds {
+    uint4 buf[64 * 4];                       // 64 rows of 64 bytes: 4 KB per wave
+};
+
+// LDS hand-over between the lanes of ONE wave: its DS instructions execute in issue order, so all it takes is that the
+// compiler keeps them in program order (a fence would also drain the vector-memory counter: the fetch ahead, the stores)
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// 16 bytes at any even (load) or any (store) address, as GLOBAL accesses: through a generic pointer they would be flat_*
+// instructions, which count on both memory counters and complete out of order -- every wait would be for everything
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+typedef U32x4 U32x4Align2 __attribute__((aligned(2)));
+typedef U32x4 U32x4Align1 __attribute__((aligned(1)));
+__device__ __forceinline__ Pcm8 global_load_16(uint64_t p) {
+    const U32x4 v = *(const __attribute__((address_space(1))) U32x4Align2*)p;
+    return Pcm8{{v.x, v.y, v.z, v.w}};
+}
+__device__ __forceinline__ void global_store_16(uint64_t p, const uint4& v) {
+    U32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *(__attribute__((address_space(1))) U32x4Align1*)p = t;
+}
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t from) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)from), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)from);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t swz(uint32_t row) { return (row >> 1) & 3u; }
+
+template <bool kWrite>
+__device__ __forceinline__ void encode_rows(const int16_t* __restrict__ x, uint32_t m, EncodeState& s, uint8_t* __restrict__ d,
+                                            const EncodeLds& l, StageLds& st) {
+    const uint32_t lane = threadIdx.x & 63u, piece = lane & 3u, r0 = lane >> 2;
+    const uint32_t mine = m / kTile;
+    // the wave's longest row: its tile count bounds the loop, its start is the address rows without a tile read
+    uint32_t key = (mine << 6) | lane;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, off));
+    key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    const uint32_t most = key >> 6;
+    if (most) {
+        const uint64_t safe = shfl64(reinterpret_cast<uint64_t>(x), key & 63u);
+        // the four rows this lane fetches for (and stores for): r0 + 16 j
+        uint64_t rp[4], rd[4];
+        uint32_t rt[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            rp[j] = shfl64(reinterpret_cast<uint64_t>(x), r0 + 16u * j);
+            rd[j] = kWrite ? shfl64(reinterpret_cast<uint64_t>(d), r0 + 16u * j) : 0u;
+            rt[j] = (uint32_t)__shfl((int)mine, (int)(r0 + 16u * j));
+        }
+        auto fetch = [&](uint32_t t, Pcm8* r) {      // a row that has no tile t reads `safe`: no branch, never a byte past anybody's samples
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j)
+                r[j] = global_load_16((t < rt[j] ? rp[j] + (uint64_t)t * (2u * kTile) : safe) + (piece << 4));
+        };
+        uint4 acc[4];                                 // the lane's bytes of four tiles
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = make_uint4(0u, 0u, 0u, 0u);
+        auto flush = [&](uint32_t g) {                // tiles 4 g .. 4 g + 3 of every row that has all four: 64 bytes per row
+            wave_sync();
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) st.buf[lane * 4u + (k ^ swz(lane))] = acc[k];
+            wave_sync();
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t row = r0 + 16u * j;
+                const uint4 v = st.buf[row * 4u + (piece ^ swz(row))];
+                if (4u * g + 4u <= rt[j])
+                    global_store_16(rd[j] + (uint64_t)g * 64u + (piece << 4), v);
+            }
+        };
+        Pcm8 next[4];
+        fetch(0u, next);
+        for (uint32_t t = 0; t < most; ++t) {
+            wave_sync();                              // the tile before has been read
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t row = r0 + 16u * j;
+                st.buf[row * 4u + (piece ^ swz(row))] = make_uint4(next[j].w[0], next[j].w[1], next[j].w[2], next[j].w[3]);
+            }
+            wave_sync();
+            if (t + 1u < most) fetch(t + 1u, next);
+            uint4 cur[4];
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; ++c) cur[c] = st.buf[lane * 4u + (c ^ swz(lane))];
+            // the four tiles before leave now, through the tile's LDS (free until the next trip), ahead of this tile's
+            // arithmetic: the next wait on the vector-memory counter finds these stores a tile old
+            if (kWrite && t && (t & 3u) == 0u) flush(t / 4u - 1u);
+            if (t < mine) {
+                const uint32_t w0[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+                const uint32_t w1[8] = {cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w};
+                const Bytes8 a = compress16<kWrite>(s, w0, l), b = compress16<kWrite>(s, w1, l);
+                const uint4 o = make_uint4(a.w[0], a.w[1], b.w[0], b.w[1]);
+                if ((t & 3u) == 0u) acc[0] = o;       // (t is the wave's: these are not per-lane selects)
+                else if ((t & 3u) == 1u) acc[1] = o;
+                else if ((t & 3u) == 2u) acc[2] = o;
+                else acc[3] = o;
+            }
+        }
+        if (kWrite) {
+            if ((most & 3u) == 0u) flush(most / 4u - 1u);
+            // the tiles behind a row's last full group of four: the lane's own 16-byte stores
+            const uint32_t lo = mine & ~3u;
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k)
+                if (k < (mine & 3u)) *reinterpret_cast<Bytes16*>(d + (uint64_t)(lo + k) * 16u) = Bytes16{{acc[k].x, acc[k].y, acc[k].z, acc[k].w}};
+        }
+        wave_sync();
+    }
+    const uint32_t done = mine * kTile;               // what is left of the row: fewer than 32 samples, read directly
+    encode_run<kWrite>(x + done, m - done, s, kWrite ? d + (done >> 1) : d, l);
 }
 
 constexpr uint32_t kChainBlock = 256;   // chunks whose maps one workgroup composes through LDS (24 KB)
@@ -397,19 +565,39 @@ __global__ void amv_adpcm_wav_encode_kernel(const int16_t* __restrict__ x, int g
 __device__ __forceinline__ uint32_t peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void poke(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// the chunks of a wave's 64 lanes (live: this lane has one), each from its start index; returns the end index
 __device__ __forceinline__ int encode_chunk(const int16_t* __restrict__ x, uint32_t nsamp, int start, uint8_t* __restrict__ d,
-                                            const EncodeLds& l) {
-    const uint32_t pairs = nsamp >> 1;
+                                            bool live, const EncodeLds& l, StageLds& st) {
+    const uint32_t pairs = live ? nsamp >> 1 : 0u;
     const int prev = pairs ? x[0] : 0;              // adpcm.c:464
-    d[0] = (uint8_t)(prev & 0xff);                  // :465 le16 first sample
-    d[1] = (uint8_t)((prev >> 8) & 0xff);
-    d[2] = (uint8_t)start;                          // :466 le16 step index
-    d[3] = 0;
     const uint32_t cnt = pairs << 1;                // :479 le32 sample count
+    if (live) {
+        d[0] = (uint8_t)(prev & 0xff);              // :465 le16 first sample
+        d[1] = (uint8_t)((prev >> 8) & 0xff);
+        d[2] = (uint8_t)start;                      // :466 le16 step index
+        d[3] = 0;
+        d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
+    }
+    EncodeState s = encode_state(prev, start, l);
+    encode_rows<true>(x, cnt, s, d + 8, l, st);
+    return state_index(s);
+}
+
+// ... and one lane's chunk by itself (the sweeps over short lists: a wave with a handful of live lanes is as long as one
+// chunk's serial chain, and staging costs that chain a fifth more than reading the lane's own lines as they come)
+__device__ __forceinline__ int encode_chunk_alone(const int16_t* __restrict__ x, uint32_t nsamp, int start, uint8_t* __restrict__ d,
+                                                  const EncodeLds& l) {
+    const uint32_t pairs = nsamp >> 1;
+    const int prev = pairs ? x[0] : 0;
+    const uint32_t cnt = pairs << 1;
+    d[0] = (uint8_t)(prev & 0xff);
+    d[1] = (uint8_t)((prev >> 8) & 0xff);
+    d[2] = (uint8_t)start;
+    d[3] = 0;
     d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
     EncodeState s = encode_state(prev, start, l);
     encode_run<true>(x, cnt, s, d + 8, l);
-    return (int)s.index;
+    return state_index(s);
 }
 
 constexpr uint32_t kGuessTail = 128;    // samples of the chunk before that the guess is run over
@@ -421,19 +609,22 @@ __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_guess_kernel(
     const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
     uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state) {
     __shared__ EncodeLds s_tab;
+    __shared__ StageLds s_stage[kEncodeBlock / 64u];
     load_encode_tables(s_tab);
+    StageLds& st = s_stage[threadIdx.x >> 6];
     const uint32_t i = blockIdx.x * kEncodeBlock + threadIdx.x;
-    if (i >= n) return;
+    const bool live = i < n;
     int start = 0;                                  // chunk 0: the encoder context starts zeroed
-    if (i) {
-        const uint32_t mp = nsamp[i - 1u] & ~1u, tail = min(mp, kGuessTail);
-        const int16_t* t = pcm + pcm_offs[i - 1u] + (mp - tail);
+    {
+        const bool has = live && i > 0u;
+        const uint32_t mp = has ? nsamp[i - 1u] & ~1u : 0u, tail = min(mp, kGuessTail);
+        const int16_t* t = has ? pcm + pcm_offs[i - 1u] + (mp - tail) : pcm;
         EncodeState s = encode_state(tail ? t[0] : 0, 0, s_tab);
-        encode_run<false>(t, tail, s, nullptr, s_tab);
-        start = (int)s.index;
+        encode_rows<false>(t, tail, s, nullptr, s_tab, st);
+        if (has) start = state_index(s);
     }
-    const int end = encode_chunk(pcm + pcm_offs[i], nsamp[i], start, blob + offs[i], s_tab);
-    state[i] = make_uint2((uint32_t)start, (uint32_t)end);
+    const int end = encode_chunk(live ? pcm + pcm_offs[i] : pcm, live ? nsamp[i] : 0u, start, live ? blob + offs[i] : blob, live, s_tab, st);
+    if (live) state[i] = make_uint2((uint32_t)start, (uint32_t)end);
 }
 
 // the chunks whose predecessor ended elsewhere than they assumed
@@ -456,33 +647,57 @@ __global__ __launch_bounds__(256) void amv_adpcm_mismatch_kernel(const uint2* __
 // its own end moves, its successor is listed for the next sweep.  A chunk is listed by its predecessor only, so no list
 // holds it twice.  Predecessor and successor may be in the same list: whichever of the predecessor's ends the successor
 // reads, it is listed again when that end moved, and skips the work then if it had read the new one already.
+template <bool kStaged>
 __device__ __forceinline__ void sweep_one(const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs,
                                           const uint32_t* __restrict__ nsamp, uint32_t n, uint8_t* __restrict__ blob,
-                                          const uint64_t* __restrict__ offs, uint2* __restrict__ state, uint32_t i,
-                                          uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out, const EncodeLds& s_tab) {
-    uint32_t* st = reinterpret_cast<uint32_t*>(state);
-    const uint32_t start = peek(st + 2u * (i - 1u) + 1u);
-    if (start == peek(st + 2u * i)) return;
-    const uint32_t end = (uint32_t)encode_chunk(pcm + pcm_offs[i], nsamp[i], (int)start, blob + offs[i], s_tab);
-    poke(st + 2u * i, start);
-    if (end == peek(st + 2u * i + 1u)) return;
-    poke(st + 2u * i + 1u, end);
+                                          const uint64_t* __restrict__ offs, uint2* __restrict__ state, uint32_t i, bool listed,
+                                          uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out, const EncodeLds& s_tab,
+                                          StageLds& st) {
+    // (kStaged: all 64 lanes of the wave come here together; `listed`: this lane has an entry i of the list)
+    uint32_t* sw = reinterpret_cast<uint32_t*>(state);
+    uint32_t start = 0u;
+    bool todo = false;
+    if (listed) {
+        start = peek(sw + 2u * (i - 1u) + 1u);
+        todo = start != peek(sw + 2u * i);
+    }
+    uint32_t end;
+    if (kStaged) {
+        end = (uint32_t)encode_chunk(todo ? pcm + pcm_offs[i] : pcm, todo ? nsamp[i] : 0u, (int)start, todo ? blob + offs[i] : blob, todo,
+                                     s_tab, st);
+        if (!todo) return;
+    } else {
+        if (!todo) return;
+        end = (uint32_t)encode_chunk_alone(pcm + pcm_offs[i], nsamp[i], (int)start, blob + offs[i], s_tab);
+    }
+    poke(sw + 2u * i, start);
+    if (end == peek(sw + 2u * i + 1u)) return;
+    poke(sw + 2u * i + 1u, end);
     if (i + 1u < n) list_out[atomicAdd(count_out, 1u)] = i + 1u;
 }
+
+constexpr uint32_t kStagedAbove = 32768;   // list entries from which a sweep is bound by its memory accesses, not by one chunk's chain
 
 __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_sweep_kernel(
     const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
     uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state, const uint32_t* __restrict__ list_in,
     const uint32_t* __restrict__ count_in, uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out) {
     __shared__ EncodeLds s_tab;
+    __shared__ StageLds s_stage[kEncodeBlock / 64u];
     const uint32_t count = *count_in;
     if (blockIdx.x * kEncodeBlock >= count) return;
     // a sweep is as long as one chunk's serial chain and occupies a wave per SIMD or less: beside another stream's
     // kernels (the co-resident video decode) its waves should issue whenever they can
     __builtin_amdgcn_s_setprio(3);
     load_encode_tables(s_tab);
-    for (uint32_t k = blockIdx.x * kEncodeBlock + threadIdx.x; k < count; k += gridDim.x * kEncodeBlock)
-        sweep_one(pcm, pcm_offs, nsamp, n, blob, offs, state, list_in[k], list_out, count_out, s_tab);
+    StageLds& st = s_stage[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = blockIdx.x * kEncodeBlock + (threadIdx.x & ~63u); base < count; base += gridDim.x * kEncodeBlock) {
+        const bool listed = base + lane < count;
+        const uint32_t i = listed ? list_in[base + lane] : 1u;
+        if (count > kStagedAbove) sweep_one<true>(pcm, pcm_offs, nsamp, n, blob, offs, state, i, listed, list_out, count_out, s_tab, st);
+        else sweep_one<false>(pcm, pcm_offs, nsamp, n, blob, offs, state, i, listed, list_out, count_out, s_tab, st);
+    }
 }
 
 // What the sweeps left, in one workgroup: rounds over the list until it is empty.  If it holds too much or does not
@@ -492,8 +707,11 @@ __global__ __launch_bounds__(256) void amv_adpcm_settle_kernel(
     uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state, uint32_t* __restrict__ list_a,
     uint32_t* __restrict__ count_a, uint32_t* __restrict__ list_b, uint32_t* __restrict__ count_b, uint32_t* __restrict__ need_map) {
     __shared__ EncodeLds s_tab;
+    __shared__ StageLds s_stage[4];
     __builtin_amdgcn_s_setprio(3);
     load_encode_tables(s_tab);
+    StageLds& st = s_stage[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t round = 0;; ++round) {
         const uint32_t count = peek(count_a);
         if (count == 0u) return;
@@ -501,8 +719,10 @@ __global__ __launch_bounds__(256) void amv_adpcm_settle_kernel(
             if (threadIdx.x == 0) *need_map = 1u;
             return;
         }
-        for (uint32_t k = threadIdx.x; k < count; k += 256u)
-            sweep_one(pcm, pcm_offs, nsamp, n, blob, offs, state, peek(list_a + k), list_b, count_b, s_tab);
+        for (uint32_t base = threadIdx.x & ~63u; base < count; base += 256u) {
+            const bool listed = base + lane < count;
+            sweep_one<false>(pcm, pcm_offs, nsamp, n, blob, offs, state, listed ? peek(list_a + base + lane) : 1u, listed, list_b, count_b, s_tab, st);
+        }
         __threadfence();
         __syncthreads();                            // everyone has read count_a and finished its appends
         if (threadIdx.x == 0) poke(count_a, 0u);
@@ -529,7 +749,7 @@ __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_map_kernel(
         const uint32_t m = nsamp[i] & ~1u;
         EncodeState s = encode_state(m ? x[0] : 0, (int)(pair % 89u), s_tab);
         encode_run<false>(x, m, s, nullptr, s_tab);
-        map[(uint64_t)i * 96u + (uint32_t)(pair % 89u)] = (uint8_t)s.index;
+        map[(uint64_t)i * 96u + (uint32_t)(pair % 89u)] = (uint8_t)state_index(s);
     }
 }
 
@@ -599,11 +819,13 @@ __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_encode_kernel(
     const uint32_t* __restrict__ nsamp, uint32_t n, const int32_t* __restrict__ step_in,
     uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, const uint32_t* __restrict__ need) {
     __shared__ EncodeLds s_tab;
+    __shared__ StageLds s_stage[kEncodeBlock / 64u];
     if (need && *need == 0u) return;
     load_encode_tables(s_tab);
     const uint32_t i = blockIdx.x * kEncodeBlock + threadIdx.x;
-    if (i >= n) return;
-    encode_chunk(pcm + pcm_offs[i], nsamp[i], clip_index(step_in[i]), blob + offs[i], s_tab);
+    const bool live = i < n;
+    encode_chunk(live ? pcm + pcm_offs[i] : pcm, live ? nsamp[i] : 0u, live ? clip_index(step_in[i]) : 0, live ? blob + offs[i] : blob, live,
+                 s_tab, s_stage[threadIdx.x >> 6]);
 }
 
 // The reference's trellis search (adpcm_compress_trellis, adpcm.c:287-443, IMA branch; `-trellis N`): a beam of the

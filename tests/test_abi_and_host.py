@@ -238,8 +238,8 @@ def test_avcodec_plugin_tables(pkg):
 
 
 def test_adpcm_float_quotient_is_exact(pkg):
-    """The encode kernels take min(7, |delta| * 4 / step) (adpcm.c:221) as trunc(float(|delta|) * r[index]): one float
-    multiply, round to nearest, then truncation -- exactly what numpy's float32 does.  Every |delta| a pair of 16-bit
+    """The encode kernels take min(7, |delta| * 4 / step) (adpcm.c:221) as trunc(float(|delta|) * r[index]) (round 3) or
+    trunc(fma(|delta|, r[index], 8)) - 8 (round 4): one rounding to nearest, then truncation -- what numpy's float32 does.  Every |delta| a pair of 16-bit
     samples can have, every step of the table: equal to the integer division."""
     lib = pkg.load_library()
     r = np.zeros(89, np.float32)
@@ -250,8 +250,20 @@ def test_adpcm_float_quotient_is_exact(pkg):
              7132, 7845, 8630, 9493, 10442, 11487, 12635, 13899, 15289, 16818, 18500, 20350, 22385, 24623, 27086, 29794, 32767]
     ad = np.arange(65536, dtype=np.uint32)
     for i, s in enumerate(steps):                      # adpcm.c:66-76 step_table
+        want = np.minimum(ad.astype(np.int64) * 4 // s, 7)
         got = np.minimum((ad.astype(np.float32) * r[i]).astype(np.uint32), 7)
-        assert (got == np.minimum(ad.astype(np.int64) * 4 // s, 7)).all(), s
+        assert (got == want).all(), s
+        # the form the kernels use since round 4: min(15, trunc(fma(|delta|, r, 8))) - 8, one rounding (the product and
+        # the sum are exact in float64, so one conversion to float32 is the fused operation's rounding)
+        fused = (ad.astype(np.float64) * np.float64(r[i]) + 8.0).astype(np.float32)
+        q8 = np.minimum(np.trunc(fused), np.float32(15.0))
+        assert (q8.astype(np.int64) - 8 == want).all(), s
+        # ... whose bit pattern carries the quotient where the kernels read it: byte 2 of a float in [8, 16) is 16 * q
+        assert (((q8.view(np.uint32) >> 16) & 0xff) == 16 * want).all(), s
+        # (step * (2 q + 1)) >> 3 as trunc(fma(q + 8, step / 4, step / 8 - 2 * step)), float32
+        for q in range(8):
+            m = np.float32(np.float64(np.float32(q + 8)) * np.float64(np.float32(s / 4.0)) + np.float64(np.float32(s / 8.0 - 2.0 * s)))
+            assert int(np.trunc(m)) == (s * (2 * q + 1)) >> 3, (s, q)
 
 
 def test_reconstruction_piece_map_arithmetic(tmp_path):
