@@ -2,11 +2,26 @@
 
 Every video chunk and every audio chunk decodes on its own (intra-only video, each audio chunk
 carries predictor + step index), so a stream shards by contiguous frame range with no exchange
-inside the codec path.  The only collectives are the ones either side of it: rank 0 hands each rank
-its slice of the compressed stream (scatter-v), and fixed-size decoded frames come back (gather).
+inside the codec path.  The only moves are the ones either side of it: rank 0 hands each rank its
+slice of the compressed stream (scatter-v), and fixed-size decoded frames come back (gather).
 torch.distributed is plumbing here: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" in the
-CPU tests.  At ~0.6 GB/s of payload per GPU these moves are three orders of magnitude below one
-xGMI link, so a plain scatter/gather is the right shape (no ring tuning, no overlap machinery).
+CPU tests.
+
+Shape of the exchange (round 4; the round-3 form built zero-padded copies on both sides -- four passes
+over the frames, more time than the decode at world size one):
+
+* nothing is padded and nothing is copied that does not cross a link: the source SENDS SLICES of its own
+  blob / offset / length tensors (point to point, one grouped call: `batch_isend_irecv`) and keeps its own
+  range as views; the destination RECEIVES STRAIGHT INTO slices of one [n_total, ...] buffer, and its own
+  rank's decoder writes into its slice of that buffer in place (`into=`);
+* the split table (4 numbers per rank) is made on the device that holds the stream -- two gathers over
+  offs / lens -- and broadcast; every rank reads it back once (the receive sizes are data);
+* a rank's range can go out in k sub-batches, the send of sub-batch j posted (on RCCL's own stream) while
+  sub-batch j + 1 decodes.  xGMI is point to point -- seven links of ~153 GB/s per GPU, one per peer --
+  so the gather into rank 0 runs on seven links at once and is bound by each sender's ONE link:
+  BASELINE configs[3] at 8 ranks moves 7 x 72 MB = 504 MB into rank 0, 72 MB / 153 GB/s = 0.47 ms per
+  link in parallel, against ~0.45 ms for the decode of a rank's 1 250 frames (a launch one wave deep);
+  DESIGN.md section 10 has the arithmetic.  No 1 -> 8 run has been measured.
 """
 import numpy as np
 import torch
@@ -19,7 +34,7 @@ def frame_range(n_total, rank, world):
 
 
 def shard_tables(offs, lens, rank, world):
-    """(lo, hi, byte_lo, byte_hi) of this rank's chunks inside the stream's blob"""
+    """(lo, hi, byte_lo, byte_hi) of this rank's chunks inside the stream's blob (host arrays)"""
     lo, hi = frame_range(len(lens), rank, world)
     if hi == lo:
         return lo, hi, 0, 0
@@ -37,67 +52,157 @@ def _as_tensor(x, dtype):
     return x if x.dtype == dtype else x.to(dtype)
 
 
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _exchange(ops):
+    """one grouped point-to-point call (RCCL: one fused launch); returns when the transfers are done or, on a device,
+    ordered on the current stream"""
+    if not ops:
+        return
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
+_INDEX_CACHE = {}
+
+
+def _range_ends(n, world, device):
+    """device indices [lo_0 .. lo_{w-1}, last_0 .. last_{w-1}] of the ranks' first and last chunks (made once per stream
+    length: building them is a host-to-device copy)"""
+    key = (n, world, str(device))
+    if key not in _INDEX_CACHE:
+        los = [min(frame_range(n, r, world)[0], max(n - 1, 0)) for r in range(world)]
+        lasts = [max(frame_range(n, r, world)[1] - 1, 0) for r in range(world)]
+        if len(_INDEX_CACHE) > 64:
+            _INDEX_CACHE.clear()
+        _INDEX_CACHE[key] = torch.tensor(los + lasts, dtype=torch.int64, device=device)
+    return _INDEX_CACHE[key]
+
+
+def split_probe(offs, lens, world):
+    """[3 * world + 1] int64 on the tensors' device: offs at every rank's first chunk, offs and lens at its last one, and
+    the chunk count -- all the split table needs from the stream, picked by two gathers, no host round trip"""
+    n = int(lens.numel())
+    if n == 0:
+        return torch.zeros(3 * world + 1, dtype=torch.int64, device=offs.device)
+    idx = _range_ends(n, world, offs.device)
+    return torch.cat([offs.index_select(0, idx), lens.index_select(0, idx[world:]).to(torch.int64),
+                      torch.full((1,), n, dtype=torch.int64, device=offs.device)])
+
+
+def split_table(probe, world):
+    """host side of it: rows (lo, hi, byte_lo, byte_hi) per rank from split_probe's numbers"""
+    p = probe.tolist() if hasattr(probe, "tolist") else list(probe)
+    n = p[3 * world]
+    rows = []
+    for r in range(world):
+        lo, hi = frame_range(n, r, world)
+        rows.append((lo, hi, 0, 0) if hi == lo else (lo, hi, p[r], p[world + r] + p[2 * world + r]))
+    return rows
+
+
 def scatter_stream(blob, offs, lens, device, src=0):
-    """rank `src` holds the stream (blob uint8, offs, lens) as numpy arrays or as torch tensors (host or
-    already on `device`: then every move is device to device); every rank returns its own
+    """rank `src` holds the stream (blob uint8, offs, lens) as numpy arrays or as torch tensors (host or already on
+    `device`: then every move is device to device); every rank returns its own
     (blob tensor on `device`, offs int64 rebased to 0, lens int32, first_frame).  Other ranks pass None.
-    One broadcast of the split table (4 numbers per rank), then one scatter each for bytes, offsets, lengths."""
-    rank, world = dist.get_rank(), dist.get_world_size()
-    meta = torch.zeros(2 + 4 * world, dtype=torch.int64)
+    One broadcast of the numbers the split table is made of, then one grouped point-to-point call: the source sends
+    slices of its own tensors (its own range stays a view), the others receive exactly their bytes."""
+    rank, world = _world()
+    probe = torch.zeros(3 * world + 1, dtype=torch.int64, device=device)
     if rank == src:
-        blob, offs, lens = _as_tensor(blob, torch.uint8), _as_tensor(offs, torch.int64), _as_tensor(lens, torch.int32)
-        n = int(lens.numel())
-        o_h, l_h = offs.cpu().numpy(), lens.cpu().numpy()          # the split table is made on the host
-        rows = [shard_tables(o_h, l_h, r, world) for r in range(world)]
-        meta[0], meta[1] = n, max(1, max(b1 - b0 for _, _, b0, b1 in rows))
-        meta[2:] = torch.tensor(rows, dtype=torch.int64).flatten()
-    meta = meta.to(device)
-    dist.broadcast(meta, src)
-    m = meta.cpu().tolist()
-    n, maxb = m[0], m[1]
-    lo, hi, b0, b1 = m[2 + 4 * rank: 6 + 4 * rank]
-    maxf = max(1, max(m[3 + 4 * r] - m[2 + 4 * r] for r in range(world)))
-    my_blob = torch.zeros(maxb, dtype=torch.uint8, device=device)
-    my_offs = torch.zeros(maxf, dtype=torch.int64, device=device)
-    my_lens = torch.zeros(maxf, dtype=torch.int32, device=device)
+        blob = _as_tensor(blob, torch.uint8).to(device)
+        offs, lens = _as_tensor(offs, torch.int64).to(device), _as_tensor(lens, torch.int32).to(device)
+        probe = split_probe(offs, lens, world)
+    if world > 1:
+        dist.broadcast(probe, src)
+    m = split_table(probe.cpu(), world)             # the one read-back: receive sizes are data
+    lo, hi, b0, b1 = m[rank]
     if rank == src:
-        blob, offs, lens = blob.to(device), offs.to(device), lens.to(device)
-        bl, ol, ll = [], [], []
+        ops = []
         for r in range(world):
-            rlo, rhi, rb0, rb1 = m[2 + 4 * r: 6 + 4 * r]
-            b = torch.zeros(maxb, dtype=torch.uint8, device=device)
-            b[: rb1 - rb0] = blob[rb0:rb1]
-            o = torch.zeros(maxf, dtype=torch.int64, device=device)
-            o[: rhi - rlo] = offs[rlo:rhi] - rb0
-            ln = torch.zeros(maxf, dtype=torch.int32, device=device)
-            ln[: rhi - rlo] = lens[rlo:rhi]
-            bl.append(b); ol.append(o); ll.append(ln)
-        dist.scatter(my_blob, bl, src)
-        dist.scatter(my_offs, ol, src)
-        dist.scatter(my_lens, ll, src)
-    else:
-        dist.scatter(my_blob, None, src)
-        dist.scatter(my_offs, None, src)
-        dist.scatter(my_lens, None, src)
-    return my_blob[: max(b1 - b0, 0)], my_offs[: hi - lo], my_lens[: hi - lo], lo
+            rlo, rhi, rb0, rb1 = m[r]
+            if r == src or rhi == rlo:
+                continue
+            ops += [dist.P2POp(dist.isend, blob[rb0:rb1], r), dist.P2POp(dist.isend, offs[rlo:rhi], r),
+                    dist.P2POp(dist.isend, lens[rlo:rhi], r)]
+        _exchange(ops)
+        return blob[b0:b1], (offs[lo:hi] - b0 if b0 else offs[lo:hi]), lens[lo:hi], lo
+    my_blob = torch.empty(max(b1 - b0, 0), dtype=torch.uint8, device=device)
+    my_offs = torch.empty(hi - lo, dtype=torch.int64, device=device)
+    my_lens = torch.empty(hi - lo, dtype=torch.int32, device=device)
+    if hi > lo:
+        _exchange([dist.P2POp(dist.irecv, my_blob, src), dist.P2POp(dist.irecv, my_offs, src), dist.P2POp(dist.irecv, my_lens, src)])
+        my_offs -= b0
+    return my_blob, my_offs, my_lens, lo
 
 
-def gather_frames(local, n_total, dst=0):
-    """local: [n_local, ...] uint8 frames of this rank's range; rank `dst` gets [n_total, ...]"""
-    rank, world = dist.get_rank(), dist.get_world_size()
-    maxf = max(frame_range(n_total, r, world)[1] - frame_range(n_total, r, world)[0] for r in range(world))
-    pad = torch.zeros((maxf,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    if rank == dst:
-        parts = [torch.zeros_like(pad) for _ in range(world)]
-        dist.gather(pad, parts, dst)
-        out = []
-        for r in range(world):
-            lo, hi = frame_range(n_total, r, world)
-            out.append(parts[r][: hi - lo])
-        return torch.cat(out)
-    dist.gather(pad, None, dst)
-    return None
+def sub_ranges(lo, hi, k):
+    """[lo, hi) cut into k contiguous pieces (the last ones may be empty)"""
+    n = hi - lo
+    return [(lo + (j * n) // k, lo + ((j + 1) * n) // k) for j in range(k)]
+
+
+class FrameGather:
+    """Fixed-size decoded frames back to rank `dst`, straight into slices of ONE [n_total, ...] buffer there.
+
+    g = FrameGather(n_total, frame_shape, dtype, device, dst, k)
+    for j, (a, b) in enumerate(g.pieces):          # this rank's sub-batches, global frame numbers
+        frames = decode(..., into=g.slot(j))       # on dst: a view of the buffer, decode writes in place; elsewhere None
+        g.post(j, frames)                          # send (or receive) sub-batch j; returns at once on a device
+    full = g.finish()                              # on dst: the buffer, every range in place; elsewhere None
+    """
+
+    def __init__(self, n_total, frame_shape, dtype, device, dst=0, k=1, out=None):
+        self.rank, self.world = _world()
+        self.n_total, self.dst, self.k = n_total, dst, max(1, int(k))
+        self.pieces = sub_ranges(*frame_range(n_total, self.rank, self.world), self.k)
+        self.works = []
+        self.out = None
+        if self.rank == dst:
+            shape = (n_total,) + tuple(frame_shape)
+            self.out = out if out is not None and tuple(out.shape) == shape else torch.empty(shape, dtype=dtype, device=device)
+
+    def slot(self, j):
+        if self.out is None:
+            return None
+        a, b = self.pieces[j]
+        return self.out[a:b]
+
+    def post(self, j, frames):
+        a, b = self.pieces[j]
+        if self.rank == self.dst:
+            if b > a and (frames.data_ptr() != self.out[a:b].data_ptr()):
+                self.out[a:b].copy_(frames)         # a decoder that did not take `into`
+            ops = []
+            for r in range(self.world):
+                if r == self.dst:
+                    continue
+                ra, rb = sub_ranges(*frame_range(self.n_total, r, self.world), self.k)[j]
+                if rb > ra:
+                    ops.append(dist.P2POp(dist.irecv, self.out[ra:rb], r))
+            if ops:
+                self.works += dist.batch_isend_irecv(ops)
+        elif b > a:
+            self.keep = getattr(self, "keep", []) + [frames]        # alive until the send has gone
+            self.works += dist.batch_isend_irecv([dist.P2POp(dist.isend, frames, self.dst)])
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works, self.keep = [], []
+        return self.out
+
+
+def gather_frames(local, n_total, dst=0, out=None):
+    """local: [n_local, ...] uint8 frames of this rank's range; rank `dst` gets [n_total, ...] (one buffer, every range
+    received in place; `out` reuses a buffer of that shape)"""
+    g = FrameGather(n_total, tuple(local.shape[1:]), local.dtype, local.device, dst, 1, out)
+    g.post(0, local)
+    return g.finish()
 
 
 def max_over_ranks(seconds, device):
@@ -115,17 +220,33 @@ def sum_over_ranks(value, device):
     return float(t.item())
 
 
-def strong_step(blob, offs, lens, n_total, device, decode, src=0, clock=None):
+def strong_step(blob, offs, lens, n_total, device, decode, src=0, clock=None, frame_shape=None, dtype=torch.uint8, k=1, out=None):
     """BASELINE.json configs[3] as stated: ONE stream of n_total frames held by rank `src` is frame-sharded over the
-    ranks -- scatter-v of the compressed chunks, decode(my_blob, my_offs, my_lens, first_frame) -> [n_local, ...]
-    uint8 frames on `device`, gather of the frames back to `src`.  Returns (frames on src | None, seconds per phase)
-    with clock() read after each phase (pass a function that synchronises the device first when timing a GPU)."""
+    ranks -- scatter-v of the compressed chunks, decode(my_blob, my_offs, my_lens, first_frame, into) -> [n_local, ...]
+    frames on `device` (`into`: on `src` the slice of the result the frames belong in -- write there and return it --
+    elsewhere None), the frames back to `src` in k sub-batches, each sent while the next one decodes.
+    Returns (frames on src | None, seconds per phase) with clock() read after each phase (pass a function that
+    synchronises the device first when timing a GPU; with k > 1 `decode` includes the sends it overlaps)."""
     clock = clock or (lambda: 0.0)
     t0 = clock()
     my_blob, my_offs, my_lens, first = scatter_stream(blob, offs, lens, device, src)
     t1 = clock()
-    local = decode(my_blob, my_offs, my_lens, first)
-    t2 = clock()
-    full = gather_frames(local, n_total, src)
+    g = None
+    for j in range(max(1, int(k))):
+        if g is None:
+            lo, hi = sub_ranges(first, first + int(my_lens.numel()), max(1, int(k)))[j]
+        else:
+            lo, hi = g.pieces[j]
+        a, b = lo - first, hi - first
+        if g is None and frame_shape is not None:
+            g = FrameGather(n_total, frame_shape, dtype, device, src, k, out)
+        into = g.slot(j) if g is not None else None
+        frames = decode(my_blob, my_offs[a:b], my_lens[a:b], lo, into)
+        if g is None:                               # frame shape learnt from the first decode
+            g = FrameGather(n_total, tuple(frames.shape[1:]), frames.dtype, device, src, k, out)
+        if j == max(1, int(k)) - 1:
+            t2 = clock()
+        g.post(j, frames)
+    full = g.finish()
     t3 = clock()
     return full, {"scatter": t1 - t0, "decode": t2 - t1, "gather": t3 - t2}

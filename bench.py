@@ -156,12 +156,38 @@ def profiled_path_traffic(tag, names, min_bytes=1e8):
     return total or None
 
 
-def cpu_cores():
-    """threads of the CPU leg = the cores this process may run on (its affinity mask, what `nproc` prints);
-    AMV_BENCH_CORES caps it from outside"""
+def cpu_share():
+    """what this process may use of the host: the CPUs of its affinity mask (what `nproc` prints) and the CPU quota of its
+    cgroup (cpu.max = "quota period": a one-GPU box of this pool sees all 256 host CPUs and is given 16 CPUs' worth of
+    time), read where they are -- nothing assumed"""
     avail = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            f = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if f[0] == "max" else float(f[0]) / float(f[1])
+            else:
+                q = float(f[0])
+                quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return avail, quota
+
+
+def cpu_cores():
+    """threads of the CPU leg: the affinity mask, capped by the cgroup's CPU quota when there is one (more threads than
+    that only take turns); AMV_BENCH_CORES overrides"""
+    avail, quota = cpu_share()
+    n = avail if quota is None else max(1, min(avail, int(math.ceil(quota))))
     cap = os.environ.get("AMV_BENCH_CORES")
-    return max(1, min(avail, int(cap))) if cap else max(1, avail)
+    return max(1, min(avail, int(cap))) if cap else n
+
+
+def cpu_note():
+    avail, quota = cpu_share()
+    return {"affinity_cpus": avail, "cgroup_cpu_quota": quota, "host_cpus_online": os.cpu_count()}
 
 
 def base_result(E, args, metric, unit, units_per_step_per_gpu, elapsed):
@@ -329,7 +355,7 @@ def run_decode(E, args):
         result["cpu_baseline"] = {"value": m * reps / tn, "unit": "frames/s", "cores": cores, "kind": "port",
                                   "sample": "first %d frames of the same stream, CPU oracle (amvlib algorithm restated in C), "
                                             "frame-sharded over %d OpenMP threads, %d passes" % (m, cores, reps),
-                                  "single_thread_value": m / t1, "host_cpus_online": os.cpu_count()}
+                                  "single_thread_value": m / t1, **cpu_note()}
     return result
 
 
@@ -343,22 +369,35 @@ def run_strong(E, args, w, h, n_total=10000):
     if E.rank == 0:
         d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, 0, n_total, w, h)
     maxf = max(hi - lo for lo, hi in (sh.frame_range(n_total, r, E.world) for r in range(E.world)))
-    d_out = torch.empty((maxf, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
+    shape = (h, ctx.stride(w))
+    # rank 0 decodes straight into its slice of the gathered buffer (`into`), the others into a buffer of their own that
+    # the send reads; the gathered buffer is allocated once and handed back in every step (out=)
+    d_out = torch.empty((maxf,) + shape, dtype=torch.uint8, device=dev) if E.rank != 0 else None
+    d_full = torch.empty((n_total,) + shape, dtype=torch.uint8, device=dev) if E.rank == 0 else None
     d_st = torch.empty(maxf, dtype=torch.int32, device=dev)
     bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    first_of = sh.frame_range(n_total, E.rank, E.world)[0]
+    # sub-batches: the send of one posted while the next decodes pays when the decode is bound by throughput; a rank's
+    # share of THIS stream (1 250 frames at 8 ranks) is one wave deep, and two launches of half the frames take twice as long
+    k = 2 if maxf >= 16384 else 1
 
-    def decode(my_blob, my_offs, my_lens, first):
-        k = int(my_lens.numel())
-        ctx.decode_batch_dev(my_blob, int(my_blob.numel()), my_offs, my_lens, k, w, h, 0, d_out, d_st, stream)
-        bad.add_((d_st[:k] != 0).sum())
-        return d_out[:k]
+    def decode(my_blob, my_offs, my_lens, first, into=None):
+        cnt = int(my_lens.numel())
+        dst = into if into is not None else d_out[first - first_of: first - first_of + cnt]
+        if cnt:
+            ctx.decode_batch_dev(my_blob, int(my_blob.numel()), my_offs, my_lens, cnt, w, h, 0, dst, d_st, stream)
+            bad.add_((d_st[:cnt] != 0).sum())
+        return dst
 
     def clock():
         torch.cuda.synchronize()
         return time.perf_counter()
 
+    def one_step(timed_clock=None):
+        return sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode, clock=timed_clock, frame_shape=shape, k=k, out=d_full)
+
     # gate: the gathered frames equal one GPU decoding the whole stream by itself, and the oracle on a sample
-    full, _ = sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode)
+    full, _ = one_step()
     torch.cuda.synchronize()
     ok = 1
     if E.rank == 0:
@@ -381,20 +420,22 @@ def run_strong(E, args, w, h, n_total=10000):
     steps = max(3, min(args.steps, 10))
     phases = {"scatter": 0.0, "decode": 0.0, "gather": 0.0}
     for _ in range(2):
-        sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode)
+        one_step()
     dist.barrier()
     t0 = clock()
     for _ in range(steps):
-        _, ph = sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode, clock=clock)
-        for k in phases:
-            phases[k] += ph[k]
+        _, ph = one_step(clock)
+        for name in phases:
+            phases[name] += ph[name]
     dist.barrier()
     elapsed = sh.max_over_ranks(clock() - t0, dev)
-    phases = {k: sh.max_over_ranks(v, dev) / steps * 1e3 for k, v in phases.items()}
+    phases = {name: sh.max_over_ranks(v, dev) / steps * 1e3 for name, v in phases.items()}
     return {"scaling": "strong", "workload": "one %d-frame %dx%d stream on rank 0 -> scatter-v of chunks (RCCL) -> per-rank decode "
                                             "-> gather of BGR frames to rank 0, end to end" % (n_total, w, h),
             "frames": n_total, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "frames_per_s": n_total * steps / elapsed,
-            "phase_ms_max_over_ranks": phases, "backend": dist.get_backend(), "n_gpus": E.world,
+            "phase_ms_max_over_ranks": phases, "backend": dist.get_backend(), "n_gpus": E.world, "sub_batches": k,
+            "exchange": "source sends slices of its blob (point to point, one grouped call), frames are received straight into "
+                        "slices of one buffer on rank 0, whose own range is decoded in place",
             "gathered_bytes_per_step": n_total * h * ctx.stride(w)}
 
 

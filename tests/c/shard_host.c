@@ -55,6 +55,7 @@ struct rank {
     uint64_t *d_offs;
     uint32_t *d_lens;
     int32_t *d_status;
+    const char *path;               /* how its frames reach device 0 */
 };
 
 int main(int argc, char **argv)
@@ -128,16 +129,24 @@ int main(int argc, char **argv)
     }
     HIP_OK(hipSetDevice(0));
     HIP_OK(hipMalloc((void **)&d_all, (size_t)fb * n));
-    for (r = 1; r < (uint32_t)nctx; ++r)
+    /* how each context's frames will reach device 0: in place (same device), over the peer link (xGMI: hipMemcpyPeerAsync
+     * moves device memory to device memory once peer access is on), or -- where the runtime refuses peer access -- by the
+     * runtime's own staging through host memory, which the same call falls back to; said per context in the output */
+    for (r = 0; r < (uint32_t)nctx; ++r) {
+        rk[r].path = "same device";
         if (rk[r].device != 0) {
             int can = 0;
+            hipError_t e;
             HIP_OK(hipDeviceCanAccessPeer(&can, rk[r].device, 0));
+            rk[r].path = "staged by the runtime (no peer access)";
             if (can) {
                 HIP_OK(hipSetDevice(rk[r].device));
-                (void)hipDeviceEnablePeerAccess(0, 0);                              /* (already enabled: not an error worth stopping for) */
+                e = hipDeviceEnablePeerAccess(0, 0);
                 (void)hipGetLastError();
+                if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) rk[r].path = "peer link (access enabled)";
             }
         }
+    }
 
     /* ---- 1. every range on its device, results gathered on device 0; nothing waits until the end */
     for (r = 0; r < (uint32_t)nctx; ++r) {
@@ -196,7 +205,8 @@ int main(int argc, char **argv)
     printf("frames: %u\n", n);
     printf("devices: %d\n", ndev);
     printf("contexts: %d\n", nctx);
-    for (r = 0; r < (uint32_t)nctx; ++r) printf("context %u: device %d frames %u..%u\n", r, rk[r].device, rk[r].first, rk[r].first + rk[r].count);
+    for (r = 0; r < (uint32_t)nctx; ++r)
+        printf("context %u: device %d frames %u..%u gather: %s\n", r, rk[r].device, rk[r].first, rk[r].first + rk[r].count, rk[r].path);
     printf("failed frames: %lu\n", bad);
     printf("gathered fnv1a64: %016llx\n", (unsigned long long)h_g);
     printf("single fnv1a64: %016llx\n", (unsigned long long)h_s);

@@ -1613,7 +1613,10 @@ def test_c_host_shards_a_stream_over_contexts(pkg, amv1, tmp_path):
         want = contexts if contexts else int(f["devices"])
         assert int(f["contexts"]) == want
         ranges = [f["context %d" % r] for r in range(want)]
-        assert ranges[0].endswith("frames 0..%d" % (252 // want)) and ranges[-1].endswith("..252")
+        assert ("frames 0..%d gather" % (252 // want)) in ranges[0] and "..252 gather" in ranges[-1]
+        # every context says how its frames reached device 0: in place, over the peer link, or staged by the runtime
+        assert ranges[0].endswith("gather: same device")
+        assert all(r.endswith(("same device", "peer link (access enabled)", "staged by the runtime (no peer access)")) for r in ranges)
 
 
 def test_amvlib_adpcm_stereo_decode(ctx, pkg, orc):

@@ -38,27 +38,56 @@ def _worker(rank, world, port, q):
             blob, offs, lens = orc.synth_stream(SEED, 0, N, W, H)
         lo, hi = sh.frame_range(N, rank, world)
 
-        def decode(my_blob, my_offs, my_lens, first):
-            assert first == lo and my_lens.numel() == hi - lo
+        calls = []
+
+        def decode(my_blob, my_offs, my_lens, first, into=None):
+            k = int(my_lens.numel())
+            assert lo <= first and first + k <= hi
+            calls.append((first, k, into is not None))
             b = my_blob.numpy()
-            frames = np.zeros((hi - lo, H, orc.stride(W)), np.uint8)
-            for i in range(hi - lo):
+            frames = np.zeros((k, H, orc.stride(W)), np.uint8)
+            for i in range(k):
                 o, ln = int(my_offs[i]), int(my_lens[i])
                 out, st, _ = orc.decode_frame(b[o:o + ln].tobytes(), W, H)
                 assert st == 0
                 frames[i] = out
+            if into is not None:                      # rank 0: the slice of the gathered buffer these frames belong in
+                assert tuple(into.shape) == frames.shape
+                into.copy_(torch.from_numpy(frames))
+                return into
             return torch.from_numpy(frames)
 
+        shape = (H, orc.stride(W))
         # the move bench.py times for BASELINE configs[3]: scatter-v -> per-rank decode -> gather; the stream is handed
         # over as numpy arrays the first time and as torch tensors (what bench.py holds) the second
-        full, phases = sh.strong_step(blob, offs, lens, N, dev, decode)
+        full, phases = sh.strong_step(blob, offs, lens, N, dev, decode, frame_shape=shape)
         assert set(phases) == {"scatter", "decode", "gather"}
+        assert calls == [(lo, hi - lo, rank == 0)]    # one call for the whole range; in place on the gathering rank only
         if rank == 0:
             tb, to, tl = torch.from_numpy(blob), torch.from_numpy(offs.view(np.int64)), torch.from_numpy(lens.view(np.int32))
-            full2, _ = sh.strong_step(tb, to, tl, N, dev, decode)
+            full2, _ = sh.strong_step(tb, to, tl, N, dev, decode, frame_shape=shape, out=torch.empty_like(full))
             assert torch.equal(full, full2)
+            # the frame shape learnt from the first decode, and the range sent in three sub-batches
+            full3, _ = sh.strong_step(tb, to, tl, N, dev, decode)
+            del calls[:]
+            full4, _ = sh.strong_step(tb, to, tl, N, dev, decode, frame_shape=shape, k=3)
+            assert torch.equal(full, full3) and torch.equal(full, full4)
         else:
+            sh.strong_step(None, None, None, N, dev, decode, frame_shape=shape)
             sh.strong_step(None, None, None, N, dev, decode)
+            del calls[:]
+            sh.strong_step(None, None, None, N, dev, decode, frame_shape=shape, k=3)
+        assert [c[:2] for c in calls] == [(a, b - a) for a, b in sh.sub_ranges(lo, hi, 3)]
+        # the scattered slices are exactly the rank's bytes: nothing padded
+        my_blob, my_offs, my_lens, first = sh.scatter_stream(blob, offs, lens, dev)
+        assert first == lo and my_lens.numel() == hi - lo and int(my_offs[0]) == 0
+        assert my_blob.numel() == int(my_offs[-1]) + int(my_lens[-1])
+        # gather_frames: the plain form (a decoder that knows nothing of `into`)
+        mine = decode(my_blob, my_offs, my_lens, first)
+        got = sh.gather_frames(mine, N)
+        assert (got is None) == (rank != 0)
+        if rank == 0:
+            assert torch.equal(got, full)
         slow = sh.max_over_ranks(float(rank + 1), dev)
         total = sh.sum_over_ranks(float(hi - lo), dev)
         assert slow == float(world) and total == float(N)
