@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <time.h>
 
 #include "../../include/amvhip.h"
 
@@ -237,11 +238,14 @@ AMVDecoder *AmvOpen(const char *amvname)
  * copies, five launches and a synchronisation for it.  So behind the same three calls the reader takes a WINDOW of
  * frames from the file at once, into page-locked buffers, and the first AmvVideoDecode (AmvAudioDecode) that falls
  * inside the window sends all of its video (audio) chunks through the batch ABI in one go; every decode call then
- * only copies its frame out of the window's result.  What the caller sees is unchanged: framebuf holds the
- * chunk's bytes in memory the decoder owns, videobuf / audiobuf are filled by the decode calls, positions advance
- * chunk by chunk, AmvRewindFrameStart and edited framebuf contents work (a decode call whose chunk is not byte for
- * byte the window's falls back to decoding that one chunk).  AMVHIP_READAHEAD=<frames> sets the window (default
- * 256, 1 = no read-ahead). */
+ * hands out its frame where it lies in the window's result (round 4; a copy into a fresh malloc before).  What the caller
+ * sees is unchanged: framebuf holds the chunk's bytes in memory the decoder owns, videobuf / audiobuf are set by the
+ * decode calls and stay valid until the next decode call of their kind (the reference frees and mallocs them there,
+ * AMVDec.c:277-283,326), positions advance chunk by chunk, AmvRewindFrameStart and edited framebuf contents work (a
+ * decode call whose chunk is not byte for byte the window's falls back to decoding that one chunk).
+ * AMVHIP_READAHEAD=<frames> sets the window (default 1 024 -- putting a window on the stream costs ~0.4 ms of API calls
+ * whatever its size --, never more than 64 MB of decoded frames; 1 = no read-ahead, one frame per GPU round trip, the
+ * copying path). */
 
 typedef struct ra_entry {
     long pos;                 /* file position of the frame's "00dc" */
@@ -249,17 +253,17 @@ typedef struct ra_entry {
     uint32_t aoff, alen;      /* audio chunk in ablob, alen = real length; the slot is zero-padded to 8 + round4(alen - 8) */
 } ra_entry;
 
-typedef struct readahead {
-    AMVDecoder *owner;
-    struct readahead *next;
-    FILE *fp;
-    long fsize;
-    uint32_t cap_frames;
-    uint32_t n, cur;          /* frames in the window, next one to hand out */
-    int last;                 /* window index of the frame in framebuf, -1 = none */
-    int vstate, astate;       /* 0 = not sent, 1 = result in vout / aout, -1 = the batch call failed */
-    uint32_t w, h;
-    uint64_t fb;              /* bytes of a decoded frame */
+/* One window of frames: the chunks as they lie in the file, and the decoded frames / PCM of all of them.  There are two,
+ * used in turn (round 4): the decode calls hand out POINTERS into the current window's results instead of copying
+ * them into a fresh malloc (the reference's per-frame malloc + memset, AMVDec.c:277-283,326-329, was 10 GB/s of
+ * single-thread memory traffic here), and what a caller holds stays untouched until its next decode call of the same
+ * kind because the window after is decoded into the OTHER set of buffers -- whose chunks are read, and whose decode is
+ * put on the context's stream, from inside that next decode call, so that it runs while the caller walks the frames of
+ * this window. */
+typedef struct ra_window {
+    long start, end;          /* file range of its frames: first frame's position, position behind the last one */
+    uint32_t n;               /* frames */
+    int vstate, astate;       /* 0 = not sent, 2 = on the stream, 1 = result in vout / aout, -1 = the batch call failed */
     ra_entry *e;
     /* page-locked */
     uint8_t *vblob, *ablob, *vout;
@@ -269,10 +273,46 @@ typedef struct readahead {
     uint64_t *voffs, *aoffs, *pcm_offs;
     uint32_t *vlens, *alens;
     int32_t *vstatus;
+} ra_window;
+
+typedef struct readahead {
+    AMVDecoder *owner;
+    struct readahead *next;
+    FILE *fp;
+    long fsize;
+    uint32_t cap_frames;
+    uint32_t w, h;
+    uint64_t fb;              /* bytes of a decoded frame */
     int pinned;               /* buffers came from amvhip_host_alloc (else malloc: no device in this process) */
+    ra_window win[2];
+    int c;                    /* the window frames are handed out of */
+    uint32_t cur;             /* next frame of it to hand out */
+    int last;                 /* index (in win[c]) of the frame in framebuf, -1 = none */
+    int ahead;                /* win[c ^ 1]: 0 = nothing, 1 = to be read when the next decode call comes, 2 = holds the frames behind win[c] */
+    /* what the caller holds of ours (never freed by anybody but the window's owner) */
+    unsigned char *lent_v;
+    short *lent_a;
+    /* framebuf's chunk buffers, kept from frame to frame */
+    unsigned char *fbv, *fba;
+    size_t fbv_cap, fba_cap;
+    size_t frame_bytes;       /* file bytes per frame of the last window read: what the next read is sized by */
 } readahead;
 
 static readahead *g_ra;
+
+/* AMVHIP_TRACE_WINDOWS=1: where the reader's time goes (seconds in the file reads, in putting windows on the stream, in
+ * waiting for the stream), printed to stderr by AmvClose */
+static double g_t_read, g_t_issue, g_t_wait;
+static unsigned long g_n_windows;
+static int g_trace = -1;
+static double ra_now(void)
+{
+    struct timespec ts;
+    if (g_trace < 0) g_trace = getenv("AMVHIP_TRACE_WINDOWS") != NULL;
+    if (!g_trace) return 0.0;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static readahead *ra_find(const AMVDecoder *amv)
 {
@@ -298,13 +338,17 @@ static void ra_release(readahead *r, void *p)
 
 static void ra_free(readahead *r)
 {
+    int k;
     if (r == NULL) return;
     if (ctx() != NULL) amvhip_sync(ctx());
     if (r->fp) fclose(r->fp);
-    ra_release(r, r->vblob); ra_release(r, r->ablob); ra_release(r, r->vout); ra_release(r, r->aout);
-    ra_release(r, r->voffs); ra_release(r, r->aoffs); ra_release(r, r->pcm_offs);
-    ra_release(r, r->vlens); ra_release(r, r->alens); ra_release(r, r->vstatus);
-    free(r->e);
+    for (k = 0; k < 2; k++) {
+        ra_window *w = &r->win[k];
+        ra_release(r, w->vblob); ra_release(r, w->ablob); ra_release(r, w->vout); ra_release(r, w->aout);
+        ra_release(r, w->voffs); ra_release(r, w->aoffs); ra_release(r, w->pcm_offs);
+        ra_release(r, w->vlens); ra_release(r, w->alens); ra_release(r, w->vstatus);
+        free(w->e);
+    }
     free(r);
 }
 
@@ -316,6 +360,7 @@ static readahead *ra_get(AMVDecoder *amv)
     readahead *r = ra_find(amv);
     const char *env;
     uint64_t cap;
+    int k, ok = 1;
     if (r != NULL) return r;
     r = (readahead *)calloc(1, sizeof *r);
     if (r == NULL) return NULL;
@@ -326,31 +371,36 @@ static readahead *ra_get(AMVDecoder *amv)
     r->fb = amvhip_frame_bytes(r->w, r->h);
     r->pinned = ctx() != NULL;
     env = getenv("AMVHIP_READAHEAD");
-    cap = env ? (uint64_t)strtoul(env, NULL, 10) : 256u;
+    cap = env ? (uint64_t)strtoul(env, NULL, 10) : 1024u;
     if (cap < 1) cap = 1;
     if (cap > 4096) cap = 4096;
     while (cap > 1 && cap * (r->fb ? r->fb : 1) > (64u << 20)) cap /= 2;   /* at most 64 MB of decoded frames per window */
     r->cap_frames = (uint32_t)cap;
     r->fp = fopen(amv->amvfilename, "rb");
     if (r->fp != NULL && fseek(r->fp, 0, SEEK_END) == 0) r->fsize = ftell(r->fp);
-    /* chunk space: AMV streams run at ~0.2 byte per pixel; a window that meets fatter chunks just ends early */
-    r->vblob_cap = (size_t)cap * ((size_t)r->w * r->h / 2 + 4096) + 64;
-    r->ablob_cap = (size_t)cap * 8192 + 64;
-    r->vout_cap = (size_t)cap * (size_t)r->fb + 64;
-    r->aout_cap = (size_t)cap * 4 * 8192;                       /* 4 bytes of PCM per chunk byte, chunks of at most 8 KB */
-    r->e = (ra_entry *)calloc(cap, sizeof(ra_entry));
-    r->vblob = (uint8_t *)ra_alloc(r, r->vblob_cap);
-    r->ablob = (uint8_t *)ra_alloc(r, r->ablob_cap);
-    r->vout = (uint8_t *)ra_alloc(r, r->vout_cap);
-    r->aout = (int16_t *)ra_alloc(r, r->aout_cap);
-    r->voffs = (uint64_t *)ra_alloc(r, cap * 8);
-    r->aoffs = (uint64_t *)ra_alloc(r, cap * 8);
-    r->pcm_offs = (uint64_t *)ra_alloc(r, cap * 8);
-    r->vlens = (uint32_t *)ra_alloc(r, cap * 4);
-    r->alens = (uint32_t *)ra_alloc(r, cap * 4);
-    r->vstatus = (int32_t *)ra_alloc(r, cap * 4);
-    if (!r->fp || r->fsize <= 0 || !r->e || !r->vblob || !r->ablob || !r->vout || !r->aout || !r->voffs || !r->aoffs ||
-        !r->pcm_offs || !r->vlens || !r->alens || !r->vstatus) {
+    for (k = 0; k < 2; k++) {
+        ra_window *w = &r->win[k];
+        /* chunk space: AMV streams run at ~0.2 byte per pixel; a window that meets fatter chunks just ends early */
+        w->vblob_cap = (size_t)cap * ((size_t)r->w * r->h / 2 + 4096) + 64;
+        w->ablob_cap = (size_t)cap * 8192 + 64;
+        w->vout_cap = (size_t)cap * (size_t)r->fb + 64;
+        w->aout_cap = (size_t)cap * 4 * 8192;                   /* 4 bytes of PCM per chunk byte, chunks of at most 8 KB */
+        w->e = (ra_entry *)calloc(cap, sizeof(ra_entry));
+        w->vblob = (uint8_t *)ra_alloc(r, w->vblob_cap);
+        w->ablob = (uint8_t *)ra_alloc(r, w->ablob_cap);
+        w->vout = (uint8_t *)ra_alloc(r, w->vout_cap);
+        w->aout = (int16_t *)ra_alloc(r, w->aout_cap);
+        w->voffs = (uint64_t *)ra_alloc(r, cap * 8);
+        w->aoffs = (uint64_t *)ra_alloc(r, cap * 8);
+        w->pcm_offs = (uint64_t *)ra_alloc(r, cap * 8);
+        w->vlens = (uint32_t *)ra_alloc(r, cap * 4);
+        w->alens = (uint32_t *)ra_alloc(r, cap * 4);
+        w->vstatus = (int32_t *)ra_alloc(r, cap * 4);
+        ok = ok && w->e && w->vblob && w->ablob && w->vout && w->aout && w->voffs && w->aoffs && w->pcm_offs && w->vlens &&
+             w->alens && w->vstatus;
+        if (cap == 1) break;                                    /* AMVHIP_READAHEAD=1: one frame per round trip, one window */
+    }
+    if (!r->fp || r->fsize <= 0 || !ok) {
         ra_free(r);
         return NULL;
     }
@@ -373,77 +423,160 @@ static int ra_grow(readahead *r, void **buf, size_t *cap, size_t need)
     return 0;
 }
 
-/* Fill the window with the frames that start at `pos`.  Returns the number of frames (0: none complete there),
- * -1 when `pos` holds the end marker.  The buffers are sized for the ~0.2 byte per pixel AMV streams run at; a window
- * that meets fatter chunks ends early, and a frame that does not fit an EMPTY window (a noisy picture with
- * AMVHIP_READAHEAD=1, an audio chunk of more than 8 KB) gets larger buffers: the reader has no size limit of its
- * own, as the reference's has none (AMVDec.c:196-231 mallocs what the chunk header says). */
-static int ra_refill(readahead *r, long pos)
+/* everything on the context's stream has finished: results that were on their way are there */
+static void ra_landed(readahead *r, int ok)
 {
-    unsigned char hd[8];
-    size_t vo = 0, ao = 0, pcm = 0;
-    if (ctx() != NULL && (r->vstate == 1 || r->astate == 1)) amvhip_sync(ctx());   /* nothing in flight into the buffers */
-    r->n = r->cur = 0;
-    r->last = -1;
-    r->vstate = r->astate = 0;
-    r->vbytes = r->abytes = 0;
-    if (fseek(r->fp, pos, SEEK_SET) != 0) return 0;
-    while (r->n < r->cap_frames) {
-        ra_entry *e = &r->e[r->n];
-        uint32_t vlen, alen, slot;
-        if (fread(hd, 1, 8, r->fp) != 8) break;
-        if (is4(hd, "AMV_") && is4(hd + 4, "END_")) return r->n ? (int)r->n : -1;       /* AMVDec.c:173-190 */
-        if (!is4(hd, "00dc")) break;                                                     /* :171,196-208 */
-        vlen = rd32(hd + 4);
-        if ((long)vlen > r->fsize - pos - 8) break;                                      /* truncated file */
-        if (vo + (size_t)round4(vlen) + 16 > r->vblob_cap &&                             /* window full -- or too small for any frame */
-            (r->n != 0 || ra_grow(r, (void **)&r->vblob, &r->vblob_cap, (size_t)round4(vlen) + 16) != 0)) break;
-        if (fread(r->vblob + vo, 1, vlen, r->fp) != vlen) break;
-        if (fread(hd, 1, 8, r->fp) != 8 || !is4(hd, "01wb")) break;                      /* :213-231 */
-        alen = rd32(hd + 4);
-        if ((long)alen > r->fsize - pos - 16 - (long)vlen) break;
-        slot = alen > 8 ? 8 + round4(alen - 8) : 8;
-        if ((ao + slot + 16 > r->ablob_cap || pcm + 4u * (size_t)(slot - 8) > r->aout_cap) &&
-            (r->n != 0 || ra_grow(r, (void **)&r->ablob, &r->ablob_cap, (size_t)slot + 16) != 0 ||
-             ra_grow(r, (void **)&r->aout, &r->aout_cap, 4u * (size_t)(slot - 8)) != 0)) break;
-        if (fread(r->ablob + ao, 1, alen, r->fp) != alen) break;
-        memset(r->ablob + ao + alen, 0, slot - alen);       /* the bytes the reference's 4-byte loop reads past the chunk */
-        e->pos = pos;
-        e->voff = (uint32_t)vo; e->vlen = vlen;
-        e->aoff = (uint32_t)ao; e->alen = alen;
-        vo += round4(vlen);
-        ao += slot;
-        pcm += 4u * (size_t)(slot - 8);
-        pos += 16 + (long)vlen + (long)alen;
-        r->n++;
-        r->vbytes = vo;
-        r->abytes = ao;
+    int k;
+    for (k = 0; k < 2; k++) {
+        if (r->win[k].vstate == 2) r->win[k].vstate = ok ? 1 : -1;
+        if (r->win[k].astate == 2) r->win[k].astate = ok ? 1 : -1;
     }
-    return (int)r->n;
+}
+
+/* Fill window `w` with the frames that start at `pos`.  Returns the number of frames (0: none complete there),
+ * -1 when `pos` holds the end marker.  The file is read a window at a time -- ONE fread of what the frames are expected
+ * to take (the last window's bytes per frame, with a margin) into the window's chunk buffer, the container walked in
+ * memory; the video chunks are used where they lie (the batch ABI takes chunks anywhere in its blob), the audio chunks
+ * are copied to slots of their own, zero-padded to what the reference's 4-byte loop reads.  (Four freads per frame were
+ * a third of the reader's time.)  The buffers are sized for the ~0.2 byte per pixel AMV streams run at; a window that
+ * meets fatter chunks ends early, and a frame that does not fit an EMPTY window (a noisy picture with
+ * AMVHIP_READAHEAD=1, an audio chunk of more than 8 KB) gets larger buffers: the reader has no size limit of its own,
+ * as the reference's has none (AMVDec.c:196-231 mallocs what the chunk header says).  Only the chunk buffers are written
+ * here; vout / aout -- what a caller may still hold a pointer into -- are written by the decode calls. */
+static int ra_refill(readahead *r, ra_window *w, long pos)
+{
+    const double t0 = ra_now();
+    const long start = pos;
+    size_t want, have = 0, p = 0, ao = 0, pcm = 0;
+    int attempt, result = 0;
+    if (ctx() != NULL && (w->vstate == 2 || w->astate == 2)) ra_landed(r, amvhip_sync(ctx()) == AMVHIP_OK);   /* nothing in flight out of the buffers */
+    w->n = 0;
+    w->vstate = w->astate = 0;
+    w->vbytes = w->abytes = 0;
+    w->start = w->end = pos;
+    want = (size_t)r->cap_frames * (r->frame_bytes ? r->frame_bytes + r->frame_bytes / 8 + 64 : (size_t)r->w * r->h / 4 + 2048) + 65536;
+    for (attempt = 0; attempt < 4 && w->n == 0; attempt++) {
+        if (want + 64 > w->vblob_cap) {
+            if (attempt == 0) want = w->vblob_cap - 64;                                   /* an ordinary window: what the buffer holds */
+            else if (ra_grow(r, (void **)&w->vblob, &w->vblob_cap, want + 64) != 0) break; /* a first frame that did not fit */
+        }
+        if ((long)want > r->fsize - start) want = (size_t)(r->fsize - start);
+        if (fseek(r->fp, start, SEEK_SET) != 0) break;
+        have = fread(w->vblob, 1, want, r->fp);
+        p = 0; ao = 0; pcm = 0; pos = start;
+        result = 0;
+        while (w->n < r->cap_frames) {
+            ra_entry *e = &w->e[w->n];
+            const unsigned char *hd = w->vblob + p;
+            uint32_t vlen, alen, slot;
+            if (p + 8 > have) break;
+            if (is4(hd, "AMV_") && is4(hd + 4, "END_")) { result = w->n ? (int)w->n : -1; break; }   /* AMVDec.c:173-190 */
+            if (!is4(hd, "00dc")) break;                                                 /* :171,196-208 */
+            vlen = rd32(hd + 4);
+            if ((long)vlen > r->fsize - pos - 8) break;                                  /* truncated file */
+            if (p + 8 + (size_t)vlen + 8 > have) {                                       /* the read ends inside this frame */
+                if (w->n == 0) want = 8 + (size_t)vlen + 8 + 8192;
+                break;
+            }
+            hd = w->vblob + p + 8 + vlen;
+            if (!is4(hd, "01wb")) { want = 0; break; }                                   /* :213-231 */
+            alen = rd32(hd + 4);
+            if ((long)alen > r->fsize - pos - 16 - (long)vlen) { want = 0; break; }
+            if (p + 16 + (size_t)vlen + alen > have) {
+                if (w->n == 0) want = 16 + (size_t)vlen + alen + 64;
+                break;
+            }
+            slot = alen > 8 ? 8 + round4(alen - 8) : 8;
+            if ((ao + slot + 16 > w->ablob_cap || pcm + 4u * (size_t)(slot - 8) > w->aout_cap) &&
+                (w->n != 0 || ra_grow(r, (void **)&w->ablob, &w->ablob_cap, (size_t)slot + 16) != 0 ||
+                 ra_grow(r, (void **)&w->aout, &w->aout_cap, 4u * (size_t)(slot - 8)) != 0)) break;
+            memcpy(w->ablob + ao, hd + 8, alen);
+            memset(w->ablob + ao + alen, 0, slot - alen);   /* the bytes the reference's 4-byte loop reads past the chunk */
+            e->pos = pos;
+            e->voff = (uint32_t)(p + 8); e->vlen = vlen;
+            e->aoff = (uint32_t)ao; e->alen = alen;
+            ao += slot;
+            pcm += 4u * (size_t)(slot - 8);
+            p += 16 + (size_t)vlen + alen;
+            pos += 16 + (long)vlen + (long)alen;
+            w->n++;
+            w->vbytes = e->voff + (size_t)round4(vlen);
+            w->abytes = ao;
+            w->end = pos;
+        }
+        if (result != 0 || want == 0 || (long)want <= 0 || have < 8) break;
+        if (w->n == 0 && want + 64 <= w->vblob_cap && want <= have) break;                /* nothing more a larger read would bring */
+    }
+    if (w->n) r->frame_bytes = (size_t)(w->end - w->start) / w->n;
+    g_t_read += ra_now() - t0;
+    g_n_windows++;
+    return result != 0 ? result : (int)w->n;
+}
+
+/* vb->fbmpdat / ab->audiodata are the caller's to read, ours to replace: free what malloc made, forget what was lent */
+static void drop_video(AMVDecoder *amv, readahead *r)
+{
+    if (r == NULL || amv->videobuf.fbmpdat != r->lent_v) free(amv->videobuf.fbmpdat);
+    amv->videobuf.fbmpdat = NULL;
+    if (r != NULL) r->lent_v = NULL;
+}
+
+static void drop_audio(AMVDecoder *amv, readahead *r)
+{
+    if (r == NULL || amv->audiobuf.audiodata != r->lent_a) free(amv->audiobuf.audiodata);
+    amv->audiobuf.audiodata = NULL;
+    if (r != NULL) r->lent_a = NULL;
+}
+
+static void drop_chunks(AMVDecoder *amv, readahead *r)
+{
+    FRAMEBUFF *fb = &amv->framebuf;
+    if (r == NULL || fb->videobuff != r->fbv) free(fb->videobuff);
+    if (r == NULL || fb->audiobuff != r->fba) free(fb->audiobuff);
+    fb->videobuff = fb->audiobuff = NULL;
+    fb->videobufflen = fb->audiobufflen = 0;
 }
 
 void AmvClose(AMVDecoder *amv)
 {
     readahead *r, **pp;
     if (amv == NULL) return;                                      /* AMVDec.c:131-148 */
+    r = ra_find(amv);
+    drop_video(amv, r);
+    drop_audio(amv, r);
+    drop_chunks(amv, r);
+    if (r != NULL) {
+        free(r->fbv);
+        free(r->fba);
+    }
     for (pp = &g_ra; (r = *pp) != NULL; pp = &r->next)
         if (r->owner == amv) { *pp = r->next; ra_free(r); break; }
     free(amv->amvfilename);
-    free(amv->framebuf.audiobuff);
-    free(amv->framebuf.videobuff);
-    free(amv->videobuf.fbmpdat);
-    free(amv->audiobuf.audiodata);
     free(amv);
+    if (g_trace > 0)
+        fprintf(stderr, "amvhip reader: %lu windows, %.3f ms reading the file, %.3f ms putting them on the stream, %.3f ms waiting for it\n",
+                g_n_windows, 1e3 * g_t_read, 1e3 * g_t_issue, 1e3 * g_t_wait);
 }
 
-/* the chunk's bytes into memory framebuf owns (the reference frees and mallocs per frame, AMVDec.c:196-231) */
-static int hand_out(unsigned char **buf, unsigned int *len, const unsigned char *src, uint32_t n)
+/* the chunk's bytes into memory framebuf owns (the reference frees and mallocs per frame, AMVDec.c:196-231; here the
+ * buffer is kept and grown).  A copy, not a pointer into the window: a caller may edit framebuf in place, and the
+ * decode calls tell an edited chunk from the window's by comparing the two. */
+static int hand_out(unsigned char **buf, unsigned int *len, unsigned char **mine, size_t *cap, const unsigned char *src, uint32_t n)
 {
-    unsigned char *p = (unsigned char *)malloc(n ? n : 1);
-    if (p == NULL) return -1;
-    memcpy(p, src, n);
-    free(*buf);
-    *buf = p;
+    if (*buf != *mine) {                                          /* somebody else's malloc: replaced as the reference would */
+        free(*buf);
+        *buf = NULL;
+    }
+    if (*mine == NULL || *cap < n) {
+        const size_t want = (size_t)n + (size_t)n / 2 + 64;
+        unsigned char *p = (unsigned char *)malloc(want);
+        if (p == NULL) { *buf = NULL; *len = 0; return -1; }
+        free(*mine);
+        *mine = p;
+        *cap = want;
+    }
+    *buf = *mine;
+    memcpy(*buf, src, n);
     *len = n;
     return 0;
 }
@@ -452,29 +585,42 @@ int AmvReadNextFrame(AMVDecoder *amv)
 {
     FRAMEBUFF *fb;
     readahead *r;
+    ra_window *w;
     const ra_entry *e;
 
     if (amv == NULL) return -1;                                   /* AMVDec.c:157-160 */
     if (!amv->opened || amv->amvfilename == NULL) return -1;
     fb = &amv->framebuf;
     if ((r = ra_get(amv)) == NULL) return -1;
-    if (!(r->cur < r->n && r->e[r->cur].pos == amv->fileseekpos)) {   /* window used up, or the position was moved */
-        const int got = ra_refill(r, amv->fileseekpos);
+    w = &r->win[r->c];
+    if (!(r->cur < w->n && w->e[r->cur].pos == amv->fileseekpos)) {   /* window used up, or the position was moved */
+        const int o = r->cap_frames > 1 ? r->c ^ 1 : r->c;
+        ra_window *nw = &r->win[o];
+        int got;
+        if (r->ahead == 2 && nw->n > 0 && nw->start == amv->fileseekpos) {
+            got = (int)nw->n;                                     /* read (and being decoded) since the first decode call of this window */
+        } else {
+            got = ra_refill(r, nw, amv->fileseekpos);
+        }
+        r->ahead = 0;
         if (got < 0) {                                            /* :173-190 end of stream */
-            free(fb->videobuff); fb->videobuff = NULL;
-            free(fb->audiobuff); fb->audiobuff = NULL;
-            fb->videobufflen = fb->audiobufflen = 0;
+            drop_chunks(amv, r);
             fb->framenum = -1;
             amv->fileseekpos += 8;
             return 0;
         }
         if (got == 0) return -1;                                  /* no complete frame here: nothing changes */
+        r->c = o;
+        r->cur = 0;
+        r->last = -1;
+        r->ahead = r->cap_frames > 1 ? 1 : 0;                     /* the window behind this one: at the next decode call */
+        w = nw;
     }
-    e = &r->e[r->cur];
+    e = &w->e[r->cur];
     /* both chunks or neither (a reader that took the video chunk and then failed on the audio chunk would be out of
      * step with the file) */
-    if (hand_out(&fb->videobuff, &fb->videobufflen, r->vblob + e->voff, e->vlen) != 0) return -1;
-    if (hand_out(&fb->audiobuff, &fb->audiobufflen, r->ablob + e->aoff, e->alen) != 0) {
+    if (hand_out(&fb->videobuff, &fb->videobufflen, &r->fbv, &r->fbv_cap, w->vblob + e->voff, e->vlen) != 0) return -1;
+    if (hand_out(&fb->audiobuff, &fb->audiobufflen, &r->fba, &r->fba_cap, w->ablob + e->aoff, e->alen) != 0) {
         fb->videobufflen = 0;
         return -1;
     }
@@ -497,44 +643,76 @@ int AmvRewindFrameStart(AMVDecoder *amv)
 static readahead *ra_current(AMVDecoder *amv, int video)
 {
     readahead *r = ra_find(amv);
+    const ra_window *w;
     const ra_entry *e;
     const FRAMEBUFF *fb = &amv->framebuf;
     if (r == NULL || r->last < 0 || ctx() == NULL) return NULL;
     if (r->w != amv->amvinfo.dwWidth || r->h != amv->amvinfo.dwHeight) return NULL;
-    e = &r->e[r->last];
-    if (video) return (fb->videobufflen == e->vlen && memcmp(fb->videobuff, r->vblob + e->voff, e->vlen) == 0) ? r : NULL;
-    return (fb->audiobufflen == e->alen && e->alen > 8 && memcmp(fb->audiobuff, r->ablob + e->aoff, e->alen) == 0) ? r : NULL;
+    w = &r->win[r->c];
+    e = &w->e[r->last];
+    if (video) return (fb->videobufflen == e->vlen && memcmp(fb->videobuff, w->vblob + e->voff, e->vlen) == 0) ? r : NULL;
+    return (fb->audiobufflen == e->alen && e->alen > 8 && memcmp(fb->audiobuff, w->ablob + e->aoff, e->alen) == 0) ? r : NULL;
 }
 
-/* send the window's video (audio) chunks through the batch ABI, once per window */
-static int ra_decode_window(readahead *r, int video)
+/* put the window's video (audio) chunks on the context's stream through the batch ABI, once per window */
+static void ra_issue(ra_window *w, int video, uint32_t width, uint32_t height)
 {
     uint32_t i;
-    int *state = video ? &r->vstate : &r->astate;
-    if (*state != 0) return *state;
+    int *state = video ? &w->vstate : &w->astate;
+    const double t0 = ra_now();
+    if (*state != 0 || w->n == 0) return;
     if (video) {
-        for (i = 0; i < r->n; i++) { r->voffs[i] = r->e[i].voff; r->vlens[i] = r->e[i].vlen; }
-        *state = amvhip_decode_batch_async(ctx(), r->vblob, r->vbytes + 16, r->voffs, r->vlens, r->n, r->w, r->h, 0, r->vout,
-                                           r->vstatus) == AMVHIP_OK ? 1 : -1;
+        for (i = 0; i < w->n; i++) { w->voffs[i] = w->e[i].voff; w->vlens[i] = w->e[i].vlen; }
+        *state = amvhip_decode_batch_async(ctx(), w->vblob, w->vbytes + 16, w->voffs, w->vlens, w->n, width, height, 0, w->vout,
+                                           w->vstatus) == AMVHIP_OK ? 2 : -1;
     } else {
         uint64_t po = 0;
-        for (i = 0; i < r->n; i++) {
-            const uint32_t slot = r->e[i].alen > 8 ? 8 + round4(r->e[i].alen - 8) : 8;
-            r->aoffs[i] = r->e[i].aoff; r->alens[i] = slot; r->pcm_offs[i] = po;
+        for (i = 0; i < w->n; i++) {
+            const uint32_t slot = w->e[i].alen > 8 ? 8 + round4(w->e[i].alen - 8) : 8;
+            w->aoffs[i] = w->e[i].aoff; w->alens[i] = slot; w->pcm_offs[i] = po;
             po += 2ull * (slot - 8);
         }
-        *state = amvhip_adpcm_decode_batch_async(ctx(), r->ablob, r->abytes + 16, r->aoffs, r->alens, r->n, r->aout, po, r->pcm_offs,
-                                                 NULL) == AMVHIP_OK ? 1 : -1;
+        *state = amvhip_adpcm_decode_batch_async(ctx(), w->ablob, w->abytes + 16, w->aoffs, w->alens, w->n, w->aout, po, w->pcm_offs,
+                                                 NULL) == AMVHIP_OK ? 2 : -1;
     }
-    if (*state == 1 && amvhip_sync(ctx()) != AMVHIP_OK) *state = -1;
+    g_t_issue += ra_now() - t0;
+}
+
+/* the current window's video (audio) result: 1 = there */
+static int ra_decode_window(readahead *r, int video)
+{
+    ra_window *w = &r->win[r->c];
+    int *state = video ? &w->vstate : &w->astate;
+    ra_issue(w, video, r->w, r->h);
+    if (*state == 2) {
+        const double t0 = ra_now();
+        ra_landed(r, amvhip_sync(ctx()) == AMVHIP_OK);
+        g_t_wait += ra_now() - t0;
+    }
     return *state;
+}
+
+/* From inside a decode call of kind `video`: whatever the caller held of that kind from the window before is dead by
+ * the call's contract, so the OTHER window's buffers of that kind may be written now -- read the frames behind this
+ * window into it (once) and put their decode of this kind on the stream; it runs while the caller walks this window. */
+static void ra_look_ahead(readahead *r, int video)
+{
+    ra_window *o;
+    if (r->ahead == 0 || r->cap_frames <= 1) return;
+    o = &r->win[r->c ^ 1];
+    if (r->ahead == 1) {
+        const int got = ra_refill(r, o, r->win[r->c].end);
+        if (got <= 0) { o->n = 0; r->ahead = 0; return; }         /* end of stream / nothing complete: the reader finds out itself */
+        r->ahead = 2;
+    }
+    ra_issue(o, video, r->w, r->h);
 }
 
 int AmvVideoDecode(AMVDecoder *amv)
 {
     FRAMEBUFF *fb;
     VIDEOBUFF *vb;
-    readahead *r;
+    readahead *r, *any;
     uint64_t full;
     size_t size;
 
@@ -543,17 +721,30 @@ int AmvVideoDecode(AMVDecoder *amv)
     fb = &amv->framebuf;
     if (fb->videobuff == NULL || fb->videobufflen == 0) return -1; /* :271-272 */
     vb = &amv->videobuf;
+    any = ra_find(amv);
     full = amvhip_frame_bytes(amv->amvinfo.dwWidth, amv->amvinfo.dwHeight);
     vb->len = amv->amvinfo.dwHeight * amv->amvinfo.dwWidth * 3;   /* :277 */
     size = full > vb->len ? (size_t)full : (vb->len ? vb->len : 1);
-    free(vb->fbmpdat);
-    vb->fbmpdat = (unsigned char *)malloc(size);
-    if (vb->fbmpdat == NULL) return -2;                           /* :281-282 */
     if ((r = ra_current(amv, 1)) != NULL && ra_decode_window(r, 1) == 1) {
         /* the whole frame, padding and undecoded remainder included, comes zeroed from the decoder (:283) */
-        memcpy(vb->fbmpdat, r->vout + (size_t)r->last * (size_t)r->fb, (size_t)full);
-        return r->vstatus[r->last] == 0 ? 0 : -1;                 /* AmvJpeg.c:1531-1538 */
+        const ra_window *w = &r->win[r->c];
+        unsigned char *frame = w->vout + (size_t)r->last * (size_t)r->fb;
+        const int rc = w->vstatus[r->last] == 0 ? 0 : -1;         /* AmvJpeg.c:1531-1538 */
+        if (r->cap_frames > 1) {                                  /* lend the window's frame: valid until the next AmvVideoDecode */
+            drop_video(amv, r);
+            vb->fbmpdat = r->lent_v = frame;
+            ra_look_ahead(r, 1);
+            return rc;
+        }
+        drop_video(amv, any);
+        vb->fbmpdat = (unsigned char *)malloc(size);
+        if (vb->fbmpdat == NULL) return -2;                       /* :281-282 */
+        memcpy(vb->fbmpdat, frame, (size_t)full);
+        return rc;
     }
+    drop_video(amv, any);
+    vb->fbmpdat = (unsigned char *)malloc(size);
+    if (vb->fbmpdat == NULL) return -2;                           /* :281-282 */
     memset(vb->fbmpdat, 0, size);                                 /* :283 */
     if (full > vb->len) {                                         /* room for the padded rows: decode in place */
         unsigned int keep = vb->len;
@@ -571,7 +762,7 @@ int AmvAudioDecode(AMVDecoder *amv)
     FRAMEBUFF *fb;
     AUDIOBUFF *ab;
     ADPCMContext audio;
-    readahead *r;
+    readahead *r, *any;
     int rtn, declen = 0;
 
     if (amv == NULL) return -1;                                   /* AMVDec.c:296-299 */
@@ -580,18 +771,32 @@ int AmvAudioDecode(AMVDecoder *amv)
     if (fb->audiobuff == NULL || fb->audiobufflen == 0) return -1; /* :302-303 */
     if (fb->audiobufflen <= 8) return -1;
     ab = &amv->audiobuf;
+    any = ra_find(amv);
     ab->len = rd32(fb->audiobuff + 4) * 2;                        /* :319-321 */
     if (ab->len < (fb->audiobufflen - 8) * 4) ab->len = (fb->audiobufflen - 8) * 4;  /* :322-323 */
-    free(ab->audiodata);
-    ab->audiodata = (short *)malloc((size_t)ab->len + 32);        /* :326 (+ what the 4 / 8-byte loop writes past it) */
-    if (ab->audiodata == NULL) return -2;
-    memset(ab->audiodata, 0, ab->len);                            /* :329 */
     if (amv->amvinfo.nChannels != 2 && (r = ra_current(amv, 0)) != NULL && ra_decode_window(r, 0) == 1) {
+        const ra_window *w = &r->win[r->c];
         const uint32_t n4 = round4(fb->audiobufflen - 8);         /* what AdpcmImaDecodeFrame consumes, AdpcmIma.c:225-241 */
-        memcpy(ab->audiodata, r->aout + r->pcm_offs[r->last], 4u * (size_t)n4);
+        short *pcm = w->aout + w->pcm_offs[r->last];
+        if (r->cap_frames > 1) {                                  /* lend the window's samples: valid until the next AmvAudioDecode */
+            drop_audio(amv, r);
+            ab->audiodata = r->lent_a = pcm;
+            ab->len = 4u * n4;                                    /* :333-337 */
+            ra_look_ahead(r, 0);
+            return 0;
+        }
+        drop_audio(amv, any);
+        ab->audiodata = (short *)malloc((size_t)ab->len + 32);    /* :326 */
+        if (ab->audiodata == NULL) return -2;
+        memset(ab->audiodata, 0, ab->len);                        /* :329 */
+        memcpy(ab->audiodata, pcm, 4u * (size_t)n4);
         ab->len = 4u * n4;                                        /* :333-337 */
         return 0;
     }
+    drop_audio(amv, any);
+    ab->audiodata = (short *)malloc((size_t)ab->len + 32);        /* :326 (+ what the 4 / 8-byte loop writes past it) */
+    if (ab->audiodata == NULL) return -2;
+    memset(ab->audiodata, 0, ab->len);                            /* :329 */
     memset(&audio, 0, sizeof audio);
     audio.channel = amv->amvinfo.nChannels;
     audio.status[0].predictor = (short)rd16(fb->audiobuff);       /* :312 */

@@ -1015,8 +1015,15 @@ def test_amvlib_readahead_semantics(ctx, pkg, orc, amv1, tmp_path):
         try:
             amv = lib.AmvOpen(amv1["path"].encode())
             d = amv.contents
+            held_v = held_a = None
             for k in range(252):
                 assert lib.AmvReadNextFrame(amv) == 0 and d.framebuf.framenum == k + 1
+                # what the decode calls handed out for the frame before (pointers into the read-ahead windows since round
+                # 4) is the caller's until its NEXT decode call of that kind: reading on -- window boundaries included --
+                # has not touched it
+                if held_v is not None:
+                    assert ctypes.string_at(held_v[0], len(held_v[1])) == held_v[1], (window, k)
+                    assert ctypes.string_at(held_a[0], len(held_a[1])) == held_a[1], (window, k)
                 assert ctypes.string_at(d.framebuf.videobuff, d.framebuf.videobufflen) == amv1["video"][k]
                 assert ctypes.string_at(d.framebuf.audiobuff, d.framebuf.audiobufflen) == amv1["audio"][k]
                 assert lib.AmvVideoDecode(amv) == 0 and (frame(d) == want_v[k]).all(), (window, k)
@@ -1036,6 +1043,8 @@ def test_amvlib_readahead_semantics(ctx, pkg, orc, amv1, tmp_path):
                     ref, st, _ = orc.decode_frame(other[: d.framebuf.videobufflen], 128, 96)
                     assert (rc == 0) == (st == 0) and (frame(d) == ref.ravel()).all()
                     d.framebuf.videobufflen = keep
+                held_v = (ctypes.cast(d.videobuf.fbmpdat, ctypes.c_void_p).value, ctypes.string_at(d.videobuf.fbmpdat, d.videobuf.len))
+                held_a = (ctypes.cast(d.audiobuf.audiodata, ctypes.c_void_p).value, ctypes.string_at(d.audiobuf.audiodata, d.audiobuf.len))
             assert lib.AmvReadNextFrame(amv) == 0 and d.framebuf.framenum == -1          # AMV_END_
             assert lib.AmvRewindFrameStart(amv) == 0
             for k in range(10):
