@@ -325,7 +325,7 @@ extern "C" uint32_t amvhip_encode_bound(uint32_t w, uint32_t h) {
 // video decode
 // =============================================================================================
 
-static int size_ok(uint32_t w, uint32_t h) { return w > 0 && h > 0 && w <= 16384 && h <= 16384; }
+static int size_ok(uint32_t w, uint32_t h) { return w > 0 && h > 0 && w <= AMVHIP_MAX_DIM && h <= AMVHIP_MAX_DIM; }
 
 // Frames the synchronising kernel does not decode go through amv_huffman_kernel, whose output is dense coefficient
 // lines: all of them in AMVHIP_ENTROPY_SERIAL mode (and for pictures of >= 16384 blocks), else the few it hands back

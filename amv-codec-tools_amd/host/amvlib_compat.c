@@ -364,6 +364,7 @@ static readahead *ra_get(AMVDecoder *amv)
     if (r != NULL) return r;
     r = (readahead *)calloc(1, sizeof *r);
     if (r == NULL) return NULL;
+    if (amv->amvinfo.dwWidth > AMVHIP_MAX_DIM || amv->amvinfo.dwHeight > AMVHIP_MAX_DIM) { free(r); return NULL; }   /* (sizes below are products of the two) */
     r->owner = amv;
     r->last = -1;
     r->w = amv->amvinfo.dwWidth;
@@ -722,6 +723,14 @@ int AmvVideoDecode(AMVDecoder *amv)
     if (fb->videobuff == NULL || fb->videobufflen == 0) return -1; /* :271-272 */
     vb = &amv->videobuf;
     any = ra_find(amv);
+    /* a header that claims a picture the decoder refuses (a damaged file: 8 million pixels wide) is refused HERE, before
+     * W*H*3 bytes are allocated and cleared for it frame after frame (what AMVDec.c:277-283 would do: gigabytes) */
+    if (amv->amvinfo.dwWidth == 0 || amv->amvinfo.dwHeight == 0 || amv->amvinfo.dwWidth > AMVHIP_MAX_DIM ||
+        amv->amvinfo.dwHeight > AMVHIP_MAX_DIM) {
+        drop_video(amv, any);
+        vb->len = 0;
+        return -1;
+    }
     full = amvhip_frame_bytes(amv->amvinfo.dwWidth, amv->amvinfo.dwHeight);
     vb->len = amv->amvinfo.dwHeight * amv->amvinfo.dwWidth * 3;   /* :277 */
     size = full > vb->len ? (size_t)full : (vb->len ? vb->len : 1);
@@ -866,7 +875,8 @@ int AmvConvertJpegFileToBmpFile(const char *jpgname, const char *bmpname)
         h = ((uint32_t)jpg[sof + 5] << 8) | jpg[sof + 6];
         w = ((uint32_t)jpg[sof + 7] << 8) | jpg[sof + 8];
         amvhip_jpeg_header((uint16_t)h, (uint16_t)w, want, sizeof want);
-        if (w && h && memcmp(jpg, want, hdr) == 0) {              /* amvlib's tables and 4:2:0, nothing else */
+        if (w && h && w <= AMVHIP_MAX_DIM && h <= AMVHIP_MAX_DIM &&  /* (stride * h below fits 32 bits; a larger picture is refused by the decoder anyway) */
+            memcmp(jpg, want, hdr) == 0) {                        /* amvlib's tables and 4:2:0, nothing else */
             stride = amvhip_stride(w);                            /* WIDTHBYTES, AmvJpeg.c:1343 */
             img = stride * h;
             bmp = (unsigned char *)calloc(1, 54 + (size_t)img);

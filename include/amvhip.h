@@ -152,6 +152,7 @@ int encode_amv_frame(const unsigned char *pixels, unsigned int stride, unsigned 
 
 typedef struct amvhip_ctx amvhip_ctx;
 
+#define AMVHIP_MAX_DIM 16384 /* widest / tallest picture the batch ABI takes (AMVHIP_ERR_ARG beyond; the amvlib surface: -1) */
 #define AMVHIP_OK 0
 #define AMVHIP_ERR_ARG -1     /* null pointer, zero/odd size, ... */
 #define AMVHIP_ERR_DEVICE -2  /* no usable HIP device / HIP call failed (see amvhip_last_error) */

@@ -234,6 +234,10 @@ static int encode_video_leg(const char *dir)
         free(cb);
         free(cr);
     }
+    free(planes[0]);
+    free(planes[1]);
+    free(planes[2]);
+    free(buf);
     return 0;
 }
 

@@ -275,3 +275,53 @@ def test_reconstruction_piece_map_arithmetic(tmp_path):
                     os.path.join(ROOT, "tests", "c", "piece_map_test.cc"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
+def test_host_c_under_sanitizers(amv1, tmp_path):
+    """SURVEY.md section 5 for the PRODUCT's host C: host/amvlib_compat.c (the reader parses untrusted AMV files -- chunk
+    lengths from the file size its reads and its buffers, AMVDec.c:150-238 is what it replaces) and host/amv_container.c,
+    built with -fsanitize=address,undefined -fno-sanitize-recover=all against tests/c/host_stub.c (the device half: every
+    call failing as on a machine without a GPU, or delivering zeros of the right size), walked by tests/c/host_fuzz.c over
+    ~2 000 mutations of the reference's clip per mode -- truncation at every header byte and around chunk headers, chunk
+    lengths of 0 / 2^31 / 2^32 - 1 / file size +- 1, missing AMV_END_, 00dc / 01wb swapped, every header byte forced, seeded
+    random damage -- and over what the muxer writes for ordinary, empty and odd-sized frames.  Every call returns a code
+    the reference's API has for it, and the sanitizers (leak check included) stay silent.  Where the reference tree is at
+    hand the AVCodec plugin (host/amvhip_lavc.c) and the C host that drives it run the same way."""
+    inc = os.path.join(ROOT, "include")
+    host = os.path.join(ROOT, "amv-codec-tools_amd", "host")
+    cdir = os.path.join(ROOT, "tests", "c")
+    san = ["-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-Wall", "-Wextra"]
+    exe = str(tmp_path / "host_fuzz")
+    subprocess.run(["gcc"] + san + ["-I", inc, os.path.join(cdir, "host_fuzz.c"), os.path.join(cdir, "host_stub.c"),
+                                    os.path.join(host, "amvlib_compat.c"), os.path.join(host, "amv_container.c"), "-lpthread", "-o", exe],
+                   check=True)
+    env = dict(os.environ, ASAN_OPTIONS="allocator_may_return_null=1:detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    runs = []
+    for k, (mode, window, iters) in enumerate((("fail", "32", 300), ("zero", "32", 300), ("zero", "1024", 60), ("zero", "1", 40))):
+        work = tmp_path / ("w%d" % k)
+        work.mkdir()
+        e = dict(env, HOST_STUB_MODE=mode, AMVHIP_READAHEAD=window)
+        runs.append((mode, window, subprocess.Popen([exe, amv1["path"], str(work), str(iters), str(k + 1)], env=e, stdout=subprocess.PIPE,
+                                                    stderr=subprocess.PIPE, text=True)))
+    for mode, window, p in runs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and out.strip().splitlines()[-1].startswith("ok mutations="), (mode, window, out[-2000:], err[-4000:])
+        assert "Sanitizer" not in err and "runtime error" not in err, (mode, window, err[-4000:])
+        fields = dict(kv.split("=") for kv in out.strip().splitlines()[-1].split()[1:])
+        assert int(fields["mutations"]) > 1500 and int(fields["violations"]) == 0
+        if mode == "zero":      # the stub decodes: the windows, the lent pointers and the decode calls really ran
+            assert int(fields["video_ok"]) > 10000 and int(fields["audio_ok"]) > 10000
+        else:                   # nothing decodes, the reader still walks every readable frame
+            assert int(fields["video_ok"]) == 0 and int(fields["frames"]) > 10000
+    ref = "/root/reference/AMVmuxer/ffmpeg"
+    if os.path.isdir(ref):      # the plugin is compiled against the reference's own avcodec.h (as build.py does); not on the GPU box
+        lavc = str(tmp_path / "lavc_host")
+        subprocess.run(["gcc"] + san + ["-Wno-unused-parameter", "-Wno-sign-compare", "-Wno-missing-field-initializers", "-Wno-deprecated-declarations",
+                                        "-I", inc, "-I", os.path.join(ref, "libavcodec"), "-I", os.path.join(ref, "libavutil"),
+                                        os.path.join(cdir, "lavc_host.c"), os.path.join(host, "amvhip_lavc.c"), os.path.join(cdir, "host_stub.c"),
+                                        os.path.join(host, "amvlib_compat.c"), os.path.join(host, "amv_container.c"), "-lpthread", "-o", lavc],
+                       check=True)
+        outdir = tmp_path / "lavc_out"
+        outdir.mkdir()
+        r = subprocess.run([lavc, amv1["path"], str(outdir)], env=dict(env, HOST_STUB_MODE="zero"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stdout[-2000:], r.stderr[-4000:])
