@@ -1053,14 +1053,13 @@ uint32_t amvo_encode_bound(uint32_t w, uint32_t h)
     return 4 + amvo_mcus_per_row(w) * amvo_mcu_rows(h) * 6 * 64 * 4 * 2;
 }
 
-int amvo_encode_frame(const uint8_t *src, uint32_t src_stride, uint32_t w, uint32_t h, int bgr,
-                      uint32_t qbias, uint8_t *out, int16_t *coef_out)
+/* planes (tight rows: Y w x h, Cb / Cr w/2 x h/2) -> chunk: what amv_encode_picture does with the picture it is given
+ * (mjpegenc.c:454-472 flip, :379-450 blocks), behind whatever produced the planes */
+static int encode_planes(const uint8_t *yp, const uint8_t *cb, const uint8_t *cr, uint32_t w, uint32_t h, uint32_t qbias, uint8_t *out,
+                         int16_t *coef_out)
 {
-    if (w == 0 || h == 0 || (w & 1) || (h & 1)) return -1;
     const uint32_t mcw = amvo_mcus_per_row(w), mch = amvo_mcu_rows(h);
     const uint32_t cw = w / 2, ch = h / 2;
-    uint8_t *yp = (uint8_t *)malloc((size_t)w * h + 2 * (size_t)cw * ch);
-    uint8_t *cb = yp + (size_t)w * h, *cr = cb + (size_t)cw * ch;
     uint8_t *raw = (uint8_t *)malloc(amvo_encode_bound(w, h));
     hufenc he[4];
     bitwr bw = { raw, 0, 0, 0 };
@@ -1068,8 +1067,6 @@ int amvo_encode_frame(const uint8_t *src, uint32_t src_stride, uint32_t w, uint3
     uint32_t mcu = 0;
 
     for (int t = 0; t < 4; t++) build_enc(&he[t], k_bits[t], k_vals[t]);
-    amvo_rgb24_to_yuvj420p(src, src_stride, w, h, bgr, yp, cb, cr);
-
     for (uint32_t my = 0; my < mch; my++)
         for (uint32_t mx = 0; mx < mcw; mx++, mcu++)
             for (int k = 0; k < 6; k++) {                     /* block order Y0..Y3,Cb,Cr mjpegenc.c:437-450 */
@@ -1102,8 +1099,67 @@ int amvo_encode_frame(const uint8_t *src, uint32_t src_stride, uint32_t w, uint3
     }
     out[o++] = 0xff; out[o++] = 0xd9;                          /* EOI :354 */
     free(raw);
-    free(yp);
     return (int)o;
+}
+
+int amvo_encode_frame(const uint8_t *src, uint32_t src_stride, uint32_t w, uint32_t h, int bgr,
+                      uint32_t qbias, uint8_t *out, int16_t *coef_out)
+{
+    if (w == 0 || h == 0 || (w & 1) || (h & 1)) return -1;
+    const uint32_t cw = w / 2, ch = h / 2;
+    uint8_t *yp = (uint8_t *)malloc((size_t)w * h + 2 * (size_t)cw * ch);
+    uint8_t *cb = yp + (size_t)w * h, *cr = cb + (size_t)cw * ch;
+    amvo_rgb24_to_yuvj420p(src, src_stride, w, h, bgr, yp, cb, cr);
+    const int n = encode_planes(yp, cb, cr, w, h, qbias, out, coef_out);
+    free(yp);
+    return n;
+}
+
+/* The picture amv_encoder is handed as PIX_FMT_YUVJ420P (mjpegenc.c:493 pix_fmts, get_pixels mpegvideo_enc.c:1539-1549):
+ * planes with the caller's line sizes, no colour conversion. */
+int amvo_encode_frame_yuv420(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, uint32_t y_stride, uint32_t c_stride,
+                             uint32_t w, uint32_t h, uint32_t qbias, uint8_t *out)
+{
+    if (w == 0 || h == 0 || (w & 1) || (h & 1)) return -1;
+    const uint32_t cw = w / 2, ch = h / 2;
+    uint8_t *yp = (uint8_t *)malloc((size_t)w * h + 2 * (size_t)cw * ch);
+    uint8_t *pb = yp + (size_t)w * h, *pr = pb + (size_t)cw * ch;
+    for (uint32_t r = 0; r < h; r++) memcpy(yp + (size_t)r * w, y + (size_t)r * y_stride, w);
+    for (uint32_t r = 0; r < ch; r++) {
+        memcpy(pb + (size_t)r * cw, cb + (size_t)r * c_stride, cw);
+        memcpy(pr + (size_t)r * cw, cr + (size_t)r * c_stride, cw);
+    }
+    const int n = encode_planes(yp, pb, pr, w, h, qbias, out, NULL);
+    free(yp);
+    return n;
+}
+
+/* PIX_FMT_YUVJ422P, the other format amv_encoder declares (mjpegenc.c:493; chroma planes w/2 x h, mpegvideo_enc.c:534-543).
+ * The reference itself would code it as MCUs of EIGHT blocks (ff_mjpeg_encode_mb, mjpegenc.c:437-450: blocks 6 and 7 when
+ * the CHROMA_420 test fails) -- a scan no AMV decoder reads: the container has no frame header and both amvlib
+ * (AmvJpeg.c:1406-1420) and the reference's own amv decoder (sp5xdec.c:51-91, a fixed 4:2:0 SOF) take six blocks per MCU.
+ * The product's rule, restated here: chroma row r of the 4:2:0 picture = ((row 2r + row 2r+1 + 1) >> 1) of the 4:2:2 plane,
+ * sample by sample, rounding up (h is even: every row has its pair); the picture is then coded as 4:2:0.  A DEFINITION,
+ * not reference behaviour -- there is none that an AMV player could show. */
+void amvo_yuv422_to_420(const uint8_t *c422, uint32_t stride422, uint32_t cw, uint32_t h, uint8_t *c420, uint32_t stride420)
+{
+    for (uint32_t r = 0; r < h / 2; r++)
+        for (uint32_t x = 0; x < cw; x++)
+            c420[(size_t)r * stride420 + x] =
+                (uint8_t)(((uint32_t)c422[(size_t)(2 * r) * stride422 + x] + c422[(size_t)(2 * r + 1) * stride422 + x] + 1u) >> 1);
+}
+
+int amvo_encode_frame_yuv422(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, uint32_t y_stride, uint32_t c_stride,
+                             uint32_t w, uint32_t h, uint32_t qbias, uint8_t *out)
+{
+    if (w == 0 || h == 0 || (w & 1) || (h & 1)) return -1;
+    const uint32_t cw = w / 2, ch = h / 2;
+    uint8_t *pb = (uint8_t *)malloc(2 * (size_t)cw * ch), *pr = pb + (size_t)cw * ch;
+    amvo_yuv422_to_420(cb, c_stride, cw, h, pb, cw);
+    amvo_yuv422_to_420(cr, c_stride, cw, h, pr, cw);
+    const int n = amvo_encode_frame_yuv420(y, pb, pr, y_stride, cw, w, h, qbias, out);
+    free(pb);
+    return n;
 }
 
 /* ------------------------------------------------------------------------------------

@@ -145,6 +145,14 @@ void amvo_quantize_block(const int16_t dct[64], int comp, uint32_t qbias, int16_
 int amvo_encode_frame(const uint8_t *src, uint32_t src_stride, uint32_t w, uint32_t h, int bgr,
                       uint32_t qbias, uint8_t *out, int16_t *coef_out);
 uint32_t amvo_encode_bound(uint32_t w, uint32_t h);
+/* the same from planes: YUVJ420P as amv_encoder takes it (mjpegenc.c:493), and YUVJ422P by the product's rule (the two chroma
+ * rows over a 4:2:0 sample averaged, rounding up -- amvo_yuv422_to_420; the reference's own 4:2:2 scan has eight blocks per
+ * MCU, mjpegenc.c:437-450, which no AMV decoder reads).  out: amvo_encode_bound(w,h) bytes; returns the chunk's length. */
+int amvo_encode_frame_yuv420(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, uint32_t y_stride, uint32_t c_stride,
+                             uint32_t w, uint32_t h, uint32_t qbias, uint8_t *out);
+void amvo_yuv422_to_420(const uint8_t *c422, uint32_t stride422, uint32_t cw, uint32_t h, uint8_t *c420, uint32_t stride420);
+int amvo_encode_frame_yuv422(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, uint32_t y_stride, uint32_t c_stride,
+                             uint32_t w, uint32_t h, uint32_t qbias, uint8_t *out);
 
 /* ---- synthetic sources, integer-only, seeded ---------------- */
 void amvo_synth_frame(uint32_t seed, uint32_t frame, uint32_t w, uint32_t h, uint8_t *rgb /* w*h*3, RGB24 */);

@@ -69,6 +69,9 @@ def lib():
             "amvo_quantize_block": (None, [_vp, _int, _u32, _vp]),
             "amvo_encode_frame": (_int, [_vp, _u32, _u32, _u32, _int, _u32, _vp, _vp]),
             "amvo_encode_bound": (_u32, [_u32, _u32]),
+            "amvo_encode_frame_yuv420": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp]),
+            "amvo_encode_frame_yuv422": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp]),
+            "amvo_yuv422_to_420": (None, [_vp, _u32, _u32, _u32, _vp, _u32]),
             "amvo_synth_frame": (None, [_u32, _u32, _u32, _u32, _vp]),
             "amvo_synth_audio": (None, [_u32, _u64, _u32, _vp]),
             "amvo_fnv1a64": (_u64, [_u64, _vp, ctypes.c_size_t]),
@@ -213,6 +216,21 @@ def encode_frame(pix, w, h, bgr=False, qbias=0, want_coef=False):
     if n < 0:
         raise ValueError("amvo_encode_frame rejected %dx%d" % (w, h))
     return (bytes(buf[:n]), coef) if want_coef else bytes(buf[:n])
+
+
+def encode_frame_yuv(y, cb, cr, w, h, qbias=0):
+    """planes as 2-D uint8 arrays (rows may be wider than the picture: the row pitch is the array's) -> chunk bytes.
+    cb / cr with h/2 rows: YUVJ420P (amvo_encode_frame_yuv420); with h rows: YUVJ422P by the product's averaging rule
+    (amvo_encode_frame_yuv422)"""
+    L = lib()
+    y, cb, cr = (np.ascontiguousarray(p, np.uint8) for p in (y, cb, cr))
+    assert cb.shape == cr.shape and y.shape[0] == h and cb.shape[0] in (h // 2, h)
+    buf = np.zeros(L.amvo_encode_bound(w, h), np.uint8)
+    fn = L.amvo_encode_frame_yuv420 if cb.shape[0] == h // 2 else L.amvo_encode_frame_yuv422
+    n = fn(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, y.shape[1], cb.shape[1], w, h, qbias, buf.ctypes.data)
+    if n < 0:
+        raise ValueError("encode_frame_yuv rejected %dx%d" % (w, h))
+    return bytes(buf[:n])
 
 
 def synth_frame(seed, t, w, h):

@@ -1672,34 +1672,47 @@ def test_amvlib_adpcm_stereo_decode(ctx, pkg, orc):
 
 
 def test_encode_yuv422_entry(ctx, orc):
-    """amvhip_encode_yuv422_batch(_dev): planar YUVJ422P in (chroma planes w/2 x h, padded strides) = the YUVJ420P entry
-    -- itself pinned to the oracle's encoder by test_encode_yuv420_entry_matches_rgb_path -- on the planes whose chroma
-    rows are the rounded-up averages of the 4:2:2 pairs; sizes with partial MCUs (rows below the picture repeat chroma
-    row 0 in both forms), device and host forms, and the frames the one-kernel encoder hands back (noise)"""
+    """amvhip_encode_yuv422_batch(_dev): planar YUVJ422P in (chroma planes w/2 x h, padded strides) against the ORACLE's
+    restatement of the rule -- amvo_yuv422_to_420 (chroma row r = (row 2r + row 2r+1 + 1) >> 1) followed by the oracle's
+    plane encoder, which test_oracle_pin.py ties to the oracle's RGB encoder -- byte for byte: the fixture geometries with
+    partial MCUs (rows below the picture repeat the edge row), device and host forms, the frames the one-kernel encoder
+    hands back (noise), 255 + 254 and 0 + 1 chroma pairs (the +1 of the rounding).  The YUVJ420P entry on the
+    oracle-averaged planes gives the same bytes (what the round-3 form of this test compared with)."""
     import torch
     rng = np.random.default_rng(422)
-    for w, h, n in ((160, 120, 4), (130, 98, 3), (16, 16, 2), (320, 240, 2)):
+    for w, h, n in ((160, 120, 4), (130, 98, 3), (16, 16, 2), (320, 240, 2), (176, 144, 2), (336, 32, 2)):
         cw = w // 2
         ys, cs = w + 8, cw + 24
         Y = rng.integers(0, 256, (n, h, ys), dtype=np.uint8)
         C2 = rng.integers(0, 256, (2, n, h, cs), dtype=np.uint8)
         smooth = (np.add.outer(np.arange(h) * 2, np.arange(cs) * 3) & 255).astype(np.uint8)
         C2[:, : n - 1] = smooth                                   # all but the last frame: codable content; the last: noise
+        C2[0, 0, 0::2, : cw // 2], C2[0, 0, 1::2, : cw // 2] = 255, 254   # pairs whose average needs the rounding: 255 + 254 -> 255
+        C2[1, 0, 0::2, : cw // 2], C2[1, 0, 1::2, : cw // 2] = 0, 1       # 0 + 1 -> 1
         Y[: n - 1] = (np.add.outer(np.arange(h) * 3, np.arange(ys)) & 255).astype(np.uint8)
-        C0 = ((C2[:, :, 0::2].astype(np.uint16) + C2[:, :, 1::2] + 1) >> 1).astype(np.uint8)
+        want = [orc.encode_frame_yuv(Y[t], C2[0, t], C2[1, t], w, h) for t in range(n)]
         cap = ctx.encode_bound(w, h) * n
-        want_blob, want_offs, want_lens = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
-        ctx.encode_yuv420_batch(Y, np.ascontiguousarray(C0[0]), np.ascontiguousarray(C0[1]), ys, cs, h * ys, (h // 2) * cs, n, w, h, 0,
-                                want_blob, cap, want_offs, want_lens)
         blob, offs, lens = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
         ctx.encode_yuv422_batch(Y, np.ascontiguousarray(C2[0]), np.ascontiguousarray(C2[1]), ys, cs, h * ys, h * cs, n, w, h, 0, blob, cap, offs, lens)
-        total = int(want_offs[-1] + want_lens[-1])
-        assert (lens == want_lens).all() and blob[:total].tobytes() == want_blob[:total].tobytes(), (w, h)
+        for t in range(n):
+            assert blob[int(offs[t]):int(offs[t]) + int(lens[t])].tobytes() == want[t], (w, h, t)
         d_blob = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
         d_offs = torch.zeros(n, dtype=torch.int64, device="cuda:0")
         d_lens = torch.zeros(n, dtype=torch.int32, device="cuda:0")
         ctx.encode_yuv422_batch_dev(_t(Y), _t(C2[0]), _t(C2[1]), ys, cs, h * ys, h * cs, n, w, h, 0, d_blob, cap, d_offs, d_lens)
         torch.cuda.synchronize()
-        assert (d_lens.cpu().numpy().astype(np.uint32) == want_lens).all() and d_blob.cpu().numpy()[:total].tobytes() == want_blob[:total].tobytes()
-        for i in range(n):                                          # and every chunk is a valid AMV frame
-            assert orc.decode_frame(want_blob[int(want_offs[i]):int(want_offs[i]) + int(want_lens[i])].tobytes(), w, h)[1] == 0
+        got, go, gl = d_blob.cpu().numpy(), d_offs.cpu().numpy(), d_lens.cpu().numpy()
+        for t in range(n):
+            assert got[int(go[t]):int(go[t]) + int(gl[t])].tobytes() == want[t], (w, h, t)
+        # the 4:2:0 entry on the oracle's averaged planes: the same chunks
+        C0 = np.zeros((2, n, h // 2, cs), np.uint8)
+        L = orc.lib()
+        for c in range(2):
+            for t in range(n):
+                src = np.ascontiguousarray(C2[c, t])
+                L.amvo_yuv422_to_420(src.ctypes.data, cs, cw, h, C0[c, t].ctypes.data, cs)
+        b0, o0, l0 = np.zeros(cap, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+        ctx.encode_yuv420_batch(Y, np.ascontiguousarray(C0[0]), np.ascontiguousarray(C0[1]), ys, cs, h * ys, (h // 2) * cs, n, w, h, 0, b0, cap, o0, l0)
+        for t in range(n):
+            assert b0[int(o0[t]):int(o0[t]) + int(l0[t])].tobytes() == want[t], (w, h, t)
+            assert orc.decode_frame(want[t], w, h)[1] == 0          # and every chunk is a valid AMV frame

@@ -446,3 +446,30 @@ def test_oracle_matches_reference_produced_outputs(orc, amv1):
             chunk, idx = orc.adpcm_encode_chunk(x, idx) if key == "plain" else orc.adpcm_encode_chunk_trellis(x, idx, a[key]["trellis"])
             hh = orc.fnv1a64(hh, np.frombuffer(chunk, np.uint8))
         assert ("%016x" % hh, idx) == (a[key]["fnv"], a[key]["end_index"]), key
+
+
+def test_plane_encoders_are_the_rgb_encoder_behind_its_conversion(orc):
+    """The oracle's plane-level encoders (round 4: what the YUVJ420P / YUVJ422P entries of the product are compared with):
+    amvo_encode_frame_yuv420 on the oracle's own rgb24_to_yuvj420p planes -- itself pinned to the reference's imgconvert.c --
+    gives amvo_encode_frame's chunk byte for byte, with padded plane rows; amvo_yuv422_to_420 is the stated rule
+    ((a + b + 1) >> 1 per sample over row pairs) on exhaustive pairs; the 4:2:2 encoder is that rule in front of the
+    4:2:0 one."""
+    L = orc.lib()
+    rng = np.random.default_rng(7)
+    for w, h in ((160, 120), (130, 98), (16, 16), (336, 32)):
+        cw, ch = w // 2, h // 2
+        src = orc.synth_frame(SEED, 9, w, h)
+        y, cb, cr = np.zeros((h, w + 8), np.uint8), np.zeros((ch, cw + 24), np.uint8), np.zeros((ch, cw + 24), np.uint8)
+        yt, bt, rt = np.zeros((h, w), np.uint8), np.zeros((ch, cw), np.uint8), np.zeros((ch, cw), np.uint8)
+        L.amvo_rgb24_to_yuvj420p(src.ctypes.data, w * 3, w, h, 0, yt.ctypes.data, bt.ctypes.data, rt.ctypes.data)
+        y[:, :w], cb[:, :cw], cr[:, :cw] = yt, bt, rt
+        y[:, w:], cb[:, cw:], cr[:, cw:] = 0xEE, 0xEE, 0xEE         # the padding is never read
+        assert orc.encode_frame_yuv(y, cb, cr, w, h) == orc.encode_frame(src, w, h), (w, h)
+        c2 = rng.integers(0, 256, (2, h, cw + 5), dtype=np.uint8)
+        avg = ((c2[:, 0::2].astype(np.uint16) + c2[:, 1::2] + 1) >> 1).astype(np.uint8)
+        assert orc.encode_frame_yuv(y, c2[0], c2[1], w, h) == orc.encode_frame_yuv(y, avg[0], avg[1], w, h), (w, h)
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
+    pairs = np.ascontiguousarray(np.stack([a.ravel(), b.ravel()]))      # two rows of 65 536 samples: every (a, b)
+    out = np.zeros((1, 65536), np.uint8)
+    L.amvo_yuv422_to_420(pairs.ctypes.data, 65536, 65536, 2, out.ctypes.data, 65536)
+    assert (out[0] == ((a.ravel().astype(np.uint16) + b.ravel() + 1) >> 1)).all()
