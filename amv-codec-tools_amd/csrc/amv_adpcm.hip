@@ -1030,7 +1030,7 @@ const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs,
     uint32_t* list[2] = {reinterpret_cast<uint32_t*>(state + n), reinterpret_cast<uint32_t*>(state + n) + n};
     uint32_t* count = list[1] + n;                   // [0 .. sweeps + 1]: one per list generation; [63]: the flag
     if (sweeps > 60u) sweeps = 60u;
-    (void)hipMemsetAsync(count, 0, 256, s);
+    if (hipMemsetAsync(count, 0, 256, s) != hipSuccess) return nullptr;   // (the caller reports it: nothing has been queued)
     hipLaunchKernelGGL(amv_adpcm_guess_kernel, dim3((n + kEncodeBlock - 1u) / kEncodeBlock), dim3(kEncodeBlock), 0, s, pcm, pcm_offs, nsamp, n,
                        blob, offs, state);
     if (n > 1u) {

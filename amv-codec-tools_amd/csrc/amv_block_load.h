@@ -71,7 +71,7 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
         // image is zeroed while they are on their way.
         struct __attribute__((packed, aligned(4))) Rec4 { uint32_t w[4]; };
         constexpr uint32_t kAhead = 3;                                   // 768 records per trip; a segment has ~500
-        const uint32_t* rec = in.rec + (uint64_t)f * in.cap_rec + r0;
+        const uint32_t* rec = in.rec + (uint64_t)in.rec_line[f] * 32u + r0;
         const uint32_t nrec = r1 - r0;
         Rec4 q[kAhead];
 #pragma unroll

@@ -129,7 +129,7 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
 // frames; the same with DPP and LDS words 0.34.)
 __global__ __launch_bounds__(256) void amv_unstuff_kernel(
     const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offs,
-    const uint32_t* __restrict__ lens, uint32_t n, uint32_t cap_words, uint32_t* __restrict__ ws,
+    const uint32_t* __restrict__ lens, uint32_t n, const uint32_t* __restrict__ ws_line, uint32_t* __restrict__ ws,
     uint32_t* __restrict__ ws_bytes, uint32_t* __restrict__ retry_list, uint32_t* __restrict__ retry_count) {
     constexpr uint32_t kRing = 512;                 // output words being put together, per wave (a tile adds <= 256)
     constexpr uint32_t kTile = kWave * 16u;         // bytes
@@ -152,13 +152,15 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
     uint32_t len = lens[frame];
     if (off > blob_bytes) { off = blob_bytes; len = 0; }
     if ((uint64_t)len > blob_bytes - off) len = (uint32_t)(blob_bytes - off);
-    uint32_t* const out = ws + (uint64_t)frame * cap_words;
+    const uint32_t line0 = ws_line[frame];                 // the frame's window: 16-byte pieces ws_line[frame] .. ws_line[frame + 1]
+    uint32_t* const out = ws + (uint64_t)line0 * 4u;
+    const uint32_t cap_bytes = (ws_line[frame + 1u] - line0) * 16u;
 
     const uint32_t mis = (uint32_t)(off & 3u);
     const uint8_t* base = blob + (off - mis);
     const uint64_t guard = blob_bytes - (off - mis);
     const uint32_t first = mis + 2u, end = mis + len;      // data bytes [first, end), relative to base
-    bool retry = len > 2u && (len - 2u) > cap_words * 4u;   // does not fit its window
+    bool retry = len > 2u && (len - 2u) > cap_bytes;        // does not fit its window (chunks that overlap in the blob: the layout ran out)
     uint32_t total = 0, flushed = 0;                        // bytes kept so far; whole words that have left
     if (!retry) {
         uint32_t carry = 0;   // FF flags of the 16 bytes in front of the tile (bit 15: the byte right in front)
@@ -534,7 +536,7 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
 
 }  // namespace
 
-// Outputs of the records form (SyncOut::rec != nullptr), all per frame: rec[cap_rec] records, seg_start[segs + 1][2]
+// Outputs of the records form (SyncOut::rec != nullptr), all per frame: its lines of rec (rec_line), seg_start[segs + 1][2]
 // {from, to} bounds of each MCU-row segment's records (SyncSinks; entries of segments the decoder never reached, and
 // the last one, hold the total twice), lane_tab[L] = {first block whose DC the lane decoded, DC base Y, Cb, Cr} (lanes right of the
 // one that met the frame's end or first error: first block ~0), rec_count = total, or ~0 when the frame was handed to
@@ -542,7 +544,7 @@ __device__ __forceinline__ WriteResult walk_write(Stream& w, const uint16_t* __r
 struct SyncOut {
     int16_t* coef;
     uint32_t* rec;
-    uint32_t cap_rec;
+    const uint32_t* rec_line;
     uint32_t* seg_start;
     uint32_t* lane_tab;
     SegGeom sg;
@@ -558,7 +560,7 @@ template <int L>
 __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    uint32_t blocks_per_frame, uint32_t cap_words,
+    uint32_t blocks_per_frame, const uint32_t* __restrict__ ws_line,
     const HuffDecodeImage* __restrict__ img, SyncOut out, int32_t* __restrict__ status,
     uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
     constexpr int kFrames = kWave / L;   // frames per wave
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
         uint4* z = reinterpret_cast<uint4*>(coef);
         for (uint32_t i = sub; i < blocks_per_frame * 8u; i += L) z[i] = make_uint4(0, 0, 0, 0);
     }
-    Stream win{ws + (uint64_t)fsafe * cap_words, live ? ((total + 15u) >> 4) * 4u : 0u, ring, 0u, make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    Stream win{ws + (uint64_t)ws_line[fsafe] * 4u, live ? ((total + 15u) >> 4) * 4u : 0u, ring, 0u, make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
 
     // ---- 1/2. speculative walks until every lane's start state equals its neighbour's arrival
     uint32_t S = ((valid_bits + L - 1) / L + 31u) & ~31u;   // bits per lane, a whole number of words
@@ -929,9 +931,12 @@ template <uint32_t kFlush>
 __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    uint32_t blocks_per_frame, uint32_t cap_words,
+    uint32_t blocks_per_frame, const uint32_t* __restrict__ ws_line,
     const HuffDecodeImage* __restrict__ img, SyncOut out, int32_t* __restrict__ status,
     uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
+    // the stride-aligned record output below is written for eight slots per stride: a 32-record line per four strides
+    // (rp8 = stride_no << 11, p[q * kWave] for q < 8, the half of the staging area by (stride_no & 1) * kFlush)
+    static_assert(kFlush == 8u, "amv_huffman_fast_kernel stages a stride's eight record slots");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
     {   // tables, shared by the waves of the workgroup
@@ -966,10 +971,12 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
         if (!lds_at_zero) continue;
         const bool live = total != kNever;
         const uint32_t fsafe = live ? frame : 0u;
-        uint32_t* const rec = out.rec + (uint64_t)fsafe * out.cap_rec;
+        const uint32_t line0 = out.rec_line[fsafe];
+        uint32_t* const rec = out.rec + (uint64_t)line0 * 32u;
+        const uint32_t cap_rec = (out.rec_line[fsafe + 1u] - line0) * 32u;   // this frame's record space, a multiple of 32
         uint2* const seg_out = reinterpret_cast<uint2*>(out.seg_start) + (uint64_t)fsafe * (sg.count + 1u);
         const uint32_t valid_bits = live ? total * 8u : 0u;
-        Stream win{ws + (uint64_t)fsafe * cap_words, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
+        Stream win{ws + (uint64_t)ws_line[fsafe] * 4u, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
                    make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         fast_open(win);
         for (uint32_t c = 0; c < 3u; ++c) lds_store(sumb + c * kSlot, 0u);
@@ -1045,7 +1052,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
             }
             if (line_live) {
                 const uint32_t at = (stride_no - 4u) * 8u;
-                if (at + 32u <= out.cap_rec) {   // never past the frame's record space (a multiple of 32); an overfull frame is redone densely
+                if (at + 32u <= cap_rec) {   // never past the frame's record space (a multiple of 32); an overfull frame is redone densely
                     uint4* d = reinterpret_cast<uint4*>(rec + at);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) d[q] = line[q];
@@ -1061,7 +1068,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
             // segments the decoder never started begin (and end) at the total; so does the end of the last one
             for (uint32_t m = seg_next; m <= sg.count; ++m) seg_out[m] = make_uint2(recpos, recpos);
             if (stats) atomicAdd(&stats[0], 1ull);
-            if (recpos > out.cap_rec) {   // more non-zero coefficients than the record space holds
+            if (recpos > cap_rec) {   // more non-zero coefficients than the record space holds
                 out.rec_count[frame] = kNever;
                 out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
             } else {
@@ -1084,7 +1091,7 @@ template <int L>
 __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
     const uint32_t* __restrict__ ws, const uint32_t* __restrict__ ws_bytes, uint32_t n,
     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-    uint32_t blocks_per_frame, uint32_t cap_words,
+    uint32_t blocks_per_frame, const uint32_t* __restrict__ ws_line,
     const HuffDecodeImage* __restrict__ img, SyncOut out, int32_t* __restrict__ status,
     uint32_t* __restrict__ nmcu_ok, uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
     constexpr int kFrames = kWave / L;   // frames per wave
@@ -1130,10 +1137,12 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
         if (!lds_at_zero) continue;
         const bool live = total != kNever;
         const uint32_t fsafe = live ? frame : 0u;
-        uint32_t* const rec = out.rec + (uint64_t)fsafe * out.cap_rec;
+        const uint32_t line0 = out.rec_line[fsafe];
+        uint32_t* const rec = out.rec + (uint64_t)line0 * 32u;
+        const uint32_t cap_rec = (out.rec_line[fsafe + 1u] - line0) * 32u;   // this frame's record space, a multiple of 32
         uint2* const seg_out = reinterpret_cast<uint2*>(out.seg_start) + (uint64_t)fsafe * (sg.count + 1u);
         const uint32_t valid_bits = live ? total * 8u : 0u;
-        Stream win{ws + (uint64_t)fsafe * cap_words, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
+        Stream win{ws + (uint64_t)ws_line[fsafe] * 4u, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
                    make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
 
         // ---- 1/2. speculative walks until every lane's start state equals its neighbour's arrival
@@ -1206,7 +1215,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
         do {   // (bottom-tested, as in amv_huffman_fast_kernel)
             fast_service_paced<kServicePace>(win, (s.t + 1u) >> 5, alive, have_words, stride_no++);
             if ((s.rp8 >> 8) - flushed >= kFlush) {
-                stage_flush<kFlush>(stage, rec, flushed, out.cap_rec);
+                stage_flush<kFlush>(stage, rec, flushed, cap_rec);
                 flushed += kFlush;
             }
             const bool running = alive;
@@ -1244,7 +1253,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
             const uint32_t end = (recpos + kFlush - 1u) & ~(kFlush - 1u);
             for (uint32_t q = recpos; q < end; ++q) stage_put<kFlush>(stage, q, kDummyRecord);
             while (flushed < end) {
-                stage_flush<kFlush>(stage, rec, flushed, out.cap_rec);
+                stage_flush<kFlush>(stage, rec, flushed, cap_rec);
                 flushed += kFlush;
             }
         }
@@ -1292,7 +1301,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
                 atomicAdd(&stats[1], (unsigned long long)rounds);
                 atomicMax(&stats[2], (unsigned long long)rounds);
             }
-            if (rec_total > out.cap_rec) {   // more non-zero coefficients than the record space holds
+            if (rec_total > cap_rec) {   // more non-zero coefficients than the record space holds
                 out.rec_count[frame] = kNever;
                 out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
             } else {
@@ -1308,7 +1317,7 @@ namespace {
 
 template <int L>
 void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
-                 const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
+                 const uint32_t* list_count, const FrameGeom& g, const uint32_t* ws_line,
                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
                  uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
     constexpr uint32_t kMaxWaves = 10u;
@@ -1333,12 +1342,12 @@ void launch_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
     uint32_t grid = (tasks + waves - 1u) / waves;
     if (grid > groups) grid = groups;
     hipLaunchKernelGGL((amv_huffman_sync_kernel<L>), dim3(grid), dim3(kWave * waves), kTableBytes + waves * kPerWave, s, ws,
-                       ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
+                       ws_bytes, n, list, list_count, g.blocks, ws_line, d_img, out, status, nmcu_ok, queue, stats);
 }
 
 template <uint32_t kFlush>
 void launch_fast(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
-                 const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
+                 const uint32_t* list_count, const FrameGeom& g, const uint32_t* ws_line,
                  const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
                  uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
     constexpr uint32_t kMaxWaves = fast_waves(kFlush);
@@ -1358,12 +1367,12 @@ void launch_fast(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
     uint32_t grid = (tasks + waves - 1u) / waves;
     if (grid > cus) grid = cus;
     hipLaunchKernelGGL((amv_huffman_fast_kernel<kFlush>), dim3(grid), dim3(kWave * waves), kFastTableBytes + waves * fast_per_wave(kFlush), s,
-                       ws, ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
+                       ws, ws_bytes, n, list, list_count, g.blocks, ws_line, d_img, out, status, nmcu_ok, queue, stats);
 }
 
 template <int L>
 void launch_sync2(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
-                  const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words,
+                  const uint32_t* list_count, const FrameGeom& g, const uint32_t* ws_line,
                   const HuffDecodeImage* d_img, const SyncOut& out, int32_t* status, uint32_t* nmcu_ok,
                   uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
     constexpr uint32_t kMaxWaves = fast_waves(8u);
@@ -1384,7 +1393,7 @@ void launch_sync2(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, cons
     uint32_t grid = (tasks + waves - 1u) / waves;
     if (grid > cus) grid = cus;
     hipLaunchKernelGGL((amv_huffman_sync2_kernel<L>), dim3(grid), dim3(kWave * waves), kFastTableBytes + waves * fast_per_wave(8u), s, ws,
-                       ws_bytes, n, list, list_count, g.blocks, cap_words, d_img, out, status, nmcu_ok, queue, stats);
+                       ws_bytes, n, list, list_count, g.blocks, ws_line, d_img, out, status, nmcu_ok, queue, stats);
 }
 
 }  // namespace
@@ -1420,22 +1429,22 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
 }
 
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
-                    uint32_t cap_words, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
+                    const uint32_t* ws_line, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
                     hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(amv_unstuff_kernel, dim3((n + 3u) / 4u), dim3(256), 0, s, blob, blob_bytes, offs, lens, n,
-                       cap_words, ws, ws_bytes, retry_list, retry_count);
+                       ws_line, ws, ws_bytes, retry_list, retry_count);
 }
 
 void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
-                         const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
+                         const uint32_t* list_count, const FrameGeom& g, const uint32_t* ws_line, int lanes_per_frame,
                          const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status, uint32_t* nmcu_ok,
                          uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s) {
     if (n == 0) return;
     const uint32_t per_row = (g.mcu_cols + kSegMcus - 1u) / kSegMcus;
-    SyncOut out{sinks.coef, sinks.rec, sinks.cap_rec, sinks.seg_start, sinks.lane_tab, SegGeom{g.mcu_cols, per_row, per_row * g.mcu_rows},
+    SyncOut out{sinks.coef, sinks.rec, sinks.rec_line, sinks.seg_start, sinks.lane_tab, SegGeom{g.mcu_cols, per_row, per_row * g.mcu_rows},
                 sinks.rec_count, sinks.retry_list, sinks.retry_count};
-#define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, cap_words, d_img, out, status, nmcu_ok, queue, stats, cus, s
+#define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, ws_line, d_img, out, status, nmcu_ok, queue, stats, cus, s
     if (sinks.rec) {
         switch (lanes_per_frame) {
             case 64: launch_sync2<64>(AMV_SYNC_ARGS); break;
@@ -1458,6 +1467,103 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
         }
     }
 #undef AMV_SYNC_ARGS
+}
+
+// Space per frame in the two workspaces between the decode stages (round 4; one stride for every frame before -- the
+// record space sized from the batch's MEAN chunk, the scan windows from the picture size: a heavy frame among light ones
+// went to the serial kernel): three small launches lay both out from the chunk lengths -- per-workgroup sums, a scan of
+// the sums in one workgroup, and the offsets.
+namespace {
+constexpr uint32_t kLayoutBlock = 256;
+
+__device__ __forceinline__ uint32_t layout_lines(uint32_t len, const LayoutSpec& sp) {
+    const uint64_t want = ((uint64_t)len * sp.per_byte_x2 >> 1) + sp.add;          // (a chunk length is whatever the caller wrote there)
+    return (uint32_t)((min(want, (uint64_t)sp.hi) + ((1u << sp.unit_shift) - 1u)) >> sp.unit_shift);
+}
+
+// exclusive scan of two values over the workgroup's 256 threads; returns the workgroup's totals in tot
+__device__ __forceinline__ uint2 block_scan2(uint2 v, uint2* s_wave, uint2& tot) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ax = (uint32_t)__shfl_up((int)inc.x, d), ay = (uint32_t)__shfl_up((int)inc.y, d);
+        if (lane >= (uint32_t)d) { inc.x += ax; inc.y += ay; }
+    }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    uint2 base = make_uint2(0u, 0u);
+    tot = make_uint2(0u, 0u);
+    for (uint32_t k = 0; k < kLayoutBlock / 64u; ++k) {
+        const uint2 w = s_wave[k];
+        if (k < wave) { base.x += w.x; base.y += w.y; }
+        tot.x += w.x; tot.y += w.y;
+    }
+    return make_uint2(base.x + inc.x - v.x, base.y + inc.y - v.y);
+}
+}  // namespace
+
+__global__ __launch_bounds__(kLayoutBlock) void amv_layout_sums_kernel(const uint32_t* __restrict__ lens, uint32_t n, LayoutSpec a, LayoutSpec b,
+                                                                      uint2* __restrict__ sums) {
+    __shared__ uint2 s_wave[kLayoutBlock / 64u];
+    const uint32_t i = blockIdx.x * kLayoutBlock + threadIdx.x;
+    const uint32_t len = i < n ? lens[i] : 0u;
+    uint2 tot;
+    (void)block_scan2(i < n ? make_uint2(layout_lines(len, a), b.line ? layout_lines(len, b) : 0u) : make_uint2(0u, 0u), s_wave, tot);
+    if (threadIdx.x == 0u) sums[blockIdx.x] = tot;
+}
+
+// sums[0 .. nb) -> exclusive prefix, saturating at the two capacities; sums[nb] = the totals
+__global__ __launch_bounds__(1024) void amv_layout_scan_kernel(uint2* __restrict__ sums, uint32_t nb, uint32_t cap_a, uint32_t cap_b) {
+    __shared__ uint64_t s_x[1024], s_y[1024];
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t lo = min(threadIdx.x * per, nb), up = min(lo + per, nb);
+    uint64_t mx = 0, my = 0;
+    for (uint32_t i = lo; i < up; ++i) { mx += sums[i].x; my += sums[i].y; }
+    s_x[threadIdx.x] = mx; s_y[threadIdx.x] = my;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint64_t lx = threadIdx.x >= d ? s_x[threadIdx.x - d] : 0u, ly = threadIdx.x >= d ? s_y[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_x[threadIdx.x] += lx; s_y[threadIdx.x] += ly;
+        __syncthreads();
+    }
+    uint64_t ax = threadIdx.x ? s_x[threadIdx.x - 1u] : 0u, ay = threadIdx.x ? s_y[threadIdx.x - 1u] : 0u;
+    for (uint32_t i = lo; i < up; ++i) {
+        const uint2 v = sums[i];
+        sums[i] = make_uint2((uint32_t)min(ax, (uint64_t)cap_a), (uint32_t)min(ay, (uint64_t)cap_b));
+        ax += v.x; ay += v.y;
+    }
+    if (threadIdx.x == 0u) sums[nb] = make_uint2((uint32_t)min(s_x[1023], (uint64_t)cap_a), (uint32_t)min(s_y[1023], (uint64_t)cap_b));
+}
+
+__global__ __launch_bounds__(kLayoutBlock) void amv_layout_write_kernel(const uint32_t* __restrict__ lens, uint32_t n, LayoutSpec a, LayoutSpec b,
+                                                                       const uint2* __restrict__ sums, uint32_t nb) {
+    __shared__ uint2 s_wave[kLayoutBlock / 64u];
+    const uint32_t i = blockIdx.x * kLayoutBlock + threadIdx.x;
+    const uint32_t len = i < n ? lens[i] : 0u;
+    uint2 tot;
+    const uint2 at = block_scan2(i < n ? make_uint2(layout_lines(len, a), b.line ? layout_lines(len, b) : 0u) : make_uint2(0u, 0u), s_wave, tot);
+    const uint2 base = sums[blockIdx.x];
+    if (i < n) {
+        a.line[i] = (uint32_t)min((uint64_t)base.x + at.x, (uint64_t)a.cap_lines);
+        if (b.line) b.line[i] = (uint32_t)min((uint64_t)base.y + at.y, (uint64_t)b.cap_lines);
+    }
+    if (i == 0u) {                                             // the end of the last frame's space
+        a.line[n] = sums[nb].x;
+        if (b.line) b.line[n] = sums[nb].y;
+    }
+}
+
+uint64_t layout_workspace(uint32_t n) { return ((uint64_t)(n + kLayoutBlock - 1u) / kLayoutBlock + 1u) * sizeof(uint2); }
+
+void launch_layout(const uint32_t* lens, uint32_t n, const LayoutSpec& a, const LayoutSpec& b, void* work, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t nb = (n + kLayoutBlock - 1u) / kLayoutBlock;
+    uint2* sums = static_cast<uint2*>(work);
+    hipLaunchKernelGGL(amv_layout_sums_kernel, dim3(nb), dim3(kLayoutBlock), 0, s, lens, n, a, b, sums);
+    hipLaunchKernelGGL(amv_layout_scan_kernel, dim3(1), dim3(1024), 0, s, sums, nb, a.cap_lines, b.line ? b.cap_lines : 0u);
+    hipLaunchKernelGGL(amv_layout_write_kernel, dim3(nb), dim3(kLayoutBlock), 0, s, lens, n, a, b, (const uint2*)sums, nb);
 }
 
 }  // namespace amv

@@ -21,15 +21,15 @@ void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
                     uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, uint32_t base, uint32_t items,
                     bool by_slot, hipStream_t s);
 // entropy stage with parallelism inside a frame (amv_decode_sync.hip): unstuff into a workspace
-// (cap_words words per frame, ws_bytes[i] = unstuffed length or ~0 when the frame is handed to
+// (frame i in the 16-byte pieces ws_line[i] .. ws_line[i + 1] of ws, ws_bytes[i] = unstuffed length or ~0 when the frame is handed to
 // launch_huffman through retry_list / *retry_count), then L lanes per frame synchronise and decode.
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
-                    uint32_t cap_words, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
+                    const uint32_t* ws_line, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
                     hipStream_t s);
 // lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units (amv_decode_sync.hip)
 int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels);
 // Where the entropy stage puts its result.  rec == nullptr: dense coefficient lines in coef
-// ([n][blocks][64] int16).  Otherwise the records form, per frame: rec[cap_rec] (one word per DC coefficient and
+// ([n][blocks][64] int16).  Otherwise the records form, per frame: its lines of rec (one word per DC coefficient and
 // per non-zero AC coefficient, stream order: bits 0-5 index in block (0 = DC), 6-11 (block - blocks per frame) modulo 64, bit 15 filler,
 // 16-31 value; a DC value counts from the decoding lane's first block), seg_start[segs + 1][2] = {from, to} for each
 // MCU-row segment of kSegMcus MCUs (what one wave of the reconstruction takes): the segment's first record is at or
@@ -41,7 +41,7 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels);
 struct SyncSinks {
     int16_t* coef;
     uint32_t* rec;
-    uint32_t cap_rec;
+    const uint32_t* rec_line;   // [n + 1]: frame i's records live in 128-byte lines rec_line[i] .. rec_line[i + 1] of rec (launch_layout)
     uint32_t* seg_start;
     uint32_t* lane_tab;
     uint32_t lanes;
@@ -49,9 +49,19 @@ struct SyncSinks {
     uint32_t* retry_list;
     uint32_t* retry_count;
 };
+// Space per frame from the frame's own chunk length, for the unstuffed scans (a) and, when b.line != nullptr, for the record
+// hand-over (b) alike: min(hi, per_byte_x2 / 2 * lens[i] + add) units, rounded up to whole lines of 1 << unit_shift units;
+// line[0 .. n] = where each frame's lines begin (an exclusive scan), never past cap_lines (a frame that gets less than it
+// needs is decoded by the serial kernel).  work: layout_workspace(n) bytes.
+struct LayoutSpec {
+    uint32_t per_byte_x2, add, hi, unit_shift, cap_lines;
+    uint32_t* line;
+};
+uint64_t layout_workspace(uint32_t n);
+void launch_layout(const uint32_t* lens, uint32_t n, const LayoutSpec& a, const LayoutSpec& b, void* work, hipStream_t s);
 // list/list_count: optional frame list; *queue: a zeroed task counter per launch
 void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
-                         const uint32_t* list_count, const FrameGeom& g, uint32_t cap_words, int lanes_per_frame,
+                         const uint32_t* list_count, const FrameGeom& g, const uint32_t* ws_line, int lanes_per_frame,
                          const HuffDecodeImage* d_img, const SyncSinks& sinks, int32_t* status, uint32_t* nmcu_ok,
                          uint32_t* queue, unsigned long long* stats, uint32_t cus, hipStream_t s);
 // Which frames a reconstruction launch takes.  Default: frame = blockIdx.x for all n frames, dense lines (if any) at

@@ -40,13 +40,14 @@ struct amvhip_ctx {
     HuffDecodeImage* d_dec = nullptr;
     HuffEncodeImage* d_enc = nullptr;
     // workspace
-    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, stats, ws, ws_bytes, rec, seg_start, lane_tab, rec_count, scaled, trellis_ws, chain;
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, enc_retry, stats, ws, ws_line, layout, ws_bytes, rec, rec_line, seg_start, lane_tab, rec_count, scaled, trellis_ws, chain;
     // amvhip_decode_submit_dev / _collect_dev: what the entropy stage hands to the reconstruction exists twice, so that
     // the entropy stage of one batch can run (stream `front`) beside the reconstruction of the batch before (`back`)
-    struct DecodeSet { DevBuf nmcu, retry, rec, seg_start, lane_tab, rec_count; } second;
+    struct DecodeSet { DevBuf nmcu, retry, rec, rec_line, seg_start, lane_tab, rec_count; } second;
     hipStream_t front = nullptr, back = nullptr;
     hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done[2] = {nullptr, nullptr};
     uint64_t submitted = 0, collected = 0;
+    DevBuf* last_decode_retry = nullptr;   // whose first word counts the frames the LAST decode call handed to the serial kernel
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
     uint32_t cus = 256;   // compute units of the device
     bool want_stats = false;
@@ -300,8 +301,8 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     for (hipEvent_t e : {c->ev_in, c->ev_front, c->ev_done[0], c->ev_done[1]})
         if (e) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->stats, &c->ws, &c->ws_bytes, &c->rec, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->chain, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out,
-                      &c->second.nmcu, &c->second.retry, &c->second.rec, &c->second.seg_start, &c->second.lane_tab, &c->second.rec_count})
+                      &c->start, &c->retry, &c->enc_retry, &c->stats, &c->ws, &c->ws_line, &c->layout, &c->ws_bytes, &c->rec, &c->rec_line, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->chain, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out,
+                      &c->second.nmcu, &c->second.retry, &c->second.rec, &c->second.rec_line, &c->second.seg_start, &c->second.lane_tab, &c->second.rec_count})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
     if (c->d_enc) (void)hipFree(c->d_enc);
@@ -341,20 +342,27 @@ struct Fallback {
 // what is left for the serial kernel
 static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offs,
                          const uint32_t* d_lens, uint32_t n, const FrameGeom& g, SyncSinks sinks, int32_t* d_status,
-                         uint32_t* d_nmcu_ok, DevBuf& retry, hipStream_t st, Fallback& fb) {
-    // window per frame for the unstuffed scan in the global workspace: ~1.6x the 0.2 B/pixel AMV streams
-    // run at; larger chunks take the serial kernel
-    uint32_t cap_bytes = ((g.width * g.height * 5u / 16u) + 1023u) & ~1023u;
-    if (cap_bytes < 2048u) cap_bytes = 2048u;
-    const uint32_t cap_words = cap_bytes / 4u;
+                         uint32_t* d_nmcu_ok, DevBuf& retry, hipStream_t st, Fallback& fb,
+                         const LayoutSpec& rec_layout = LayoutSpec{0u, 0u, 0u, 0u, 0u, nullptr}) {
+    // Window per frame for the unstuffed scan in the global workspace: the frame's own chunk length + the zeroed tail of its
+    // last 16-byte piece + a piece of slack, in 16-byte pieces laid out on the device (round 4; 5/16 byte per pixel for every
+    // frame before: a chunk over 1.6x the usual size went to the serial kernel, the others used 60 % of their window).  The
+    // total is bounded by what the chunks occupy; chunks that overlap in the blob make the layout run out, and the frames
+    // past its end take the serial kernel.
+    uint64_t ws_lines = (blob_bytes + (uint64_t)n * 48u) / 16u + 4u;
+    if (ws_lines > 0xffffffffull) ws_lines = 0xffffffffull;
     if (c->entropy_mode == AMVHIP_ENTROPY_SERIAL || g.blocks >= 16384u) {
         if (sinks.rec) HIP_TRY(c, hipMemsetAsync(sinks.rec_count, 0xff, (size_t)n * 4, st));   // every frame dense
         fb = Fallback{nullptr, nullptr, n};
         return AMVHIP_OK;
     }
     if (int r = ensure(c, retry, ((size_t)n + 8) * 4)) return r;   // [retry count, task counter, 6 spare | retry list n]
-    if (int r = ensure(c, c->ws, (size_t)n * cap_bytes)) return r;
+    if (int r = ensure(c, c->ws, (size_t)ws_lines * 16 + 64)) return r;
+    if (int r = ensure(c, c->ws_line, ((size_t)n + 1) * 4)) return r;
     if (int r = ensure(c, c->ws_bytes, (size_t)n * 4)) return r;
+    if (int r = ensure(c, c->layout, layout_workspace(n))) return r;
+    launch_layout(d_lens, n, LayoutSpec{2u, 32u, 0xffffffe0u, 4u, (uint32_t)ws_lines, (uint32_t*)c->ws_line.p}, rec_layout, c->layout.p, st);
+    if (int r = check_launch(c, "layout")) return r;
     uint32_t* retry_count = (uint32_t*)retry.p;
     uint32_t* retry_list = retry_count + 8;
     sinks.retry_list = retry_list;
@@ -362,14 +370,14 @@ static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
     HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, st));
     {
         Timed t(c, AMVHIP_K_UNSTUFF, st);
-        launch_unstuff(d_blob, blob_bytes, d_offs, d_lens, n, cap_words, (uint32_t*)c->ws.p, (uint32_t*)c->ws_bytes.p,
+        launch_unstuff(d_blob, blob_bytes, d_offs, d_lens, n, (const uint32_t*)c->ws_line.p, (uint32_t*)c->ws.p, (uint32_t*)c->ws_bytes.p,
                        retry_list, retry_count, st);
     }
     if (int r = check_launch(c, "unstuff")) return r;
     {
         Timed t(c, AMVHIP_K_HUFFMAN, st);
         unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
-        launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, cap_words,
+        launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, (const uint32_t*)c->ws_line.p,
                             sinks.rec ? (int)sinks.lanes : huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height),
                             c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1, stats, c->cus, st);
     }
@@ -443,7 +451,7 @@ static uint32_t dense_round(uint32_t n) { return n <= 16384u ? n : (n / 4u > 163
 
 // What one decode call hands from the entropy stage to the reconstruction (the context has two such sets).
 struct DecodeBufs {
-    DevBuf &nmcu, &retry, &rec, &seg_start, &lane_tab, &rec_count;
+    DevBuf &nmcu, &retry, &rec, &rec_line, &seg_start, &lane_tab, &rec_count;
 };
 
 static int decode_args_ok(amvhip_ctx* c, const uint8_t* d_blob, const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n, uint32_t w,
@@ -461,30 +469,47 @@ static int decode_core(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes
                        uint32_t n, uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out, int32_t* d_status, DecodeBufs b,
                        hipStream_t front, hipStream_t back) {
     const FrameGeom g = make_geom(w, h);
-    // Between the two stages coefficients travel as records (one word per DC and per non-zero AC coefficient).
-    // Record space per frame: 20 per block is the most the synchronising kernel is given (a frame that needs more
-    // goes to the serial kernel); a stream whose chunks are small gets proportionally less -- a record costs at
-    // least 3 bits of scan, in practice ~6 -- but never under 8 per block.  Always a multiple of 32 (whole 128-byte lines).
-    uint32_t cap_rec = (g.blocks * 20u + 31u) & ~31u;
+    // Between the two stages coefficients travel as records (one word per DC and per non-zero AC coefficient), every frame
+    // in space of its own, sized from ITS chunk (round 4; one stride for all, from the batch's mean chunk, before: a heavy
+    // frame in a light stream was silently decoded by the one-lane serial kernel).  A record costs at least 3 bits of scan,
+    // in practice ~6, and every block has a DC symbol and (nearly always) an end-of-block symbol, which take a slot each in
+    // the one-lane kernel's stride-aligned form: 2 words per byte of chunk + 2 per block + a stride's slack (never more than a
+    // frame with every coefficient non-zero could fill; a frame denser than 2 records per byte goes to the serial kernel), in
+    // whole 128-byte lines.  The space is laid out on
+    // the device (the lengths are there); its total is bounded here by what the chunks occupy (chunks that overlap make the
+    // sum larger than that: the layout saturates and the frames past the end are handed to the serial kernel).
+    const uint32_t hi_rec = (g.blocks * 66u + 95u) & ~31u;   // every coefficient of every block non-zero, an end-of-block slot each
+    const uint32_t add_rec = g.blocks * 2u + 64u;
+    uint64_t cap_lines = (uint64_t)n * (hi_rec / 32u);
     {
-        const uint64_t by_stream = (blob_bytes / n) * 2u;                // records, at 4 bits of scan each
-        const uint64_t floor_rec = (uint64_t)g.blocks * 8u;
-        if (by_stream < cap_rec) cap_rec = (uint32_t)((by_stream > floor_rec ? by_stream : floor_rec) + 31u) & ~31u;
+        const uint64_t by_stream = (2u * blob_bytes + (uint64_t)n * (add_rec + 31u)) / 32u + 1u;
+        if (by_stream < cap_lines) cap_lines = by_stream;
+        if (cap_lines > 0xffffffffull) cap_lines = 0xffffffffull;
     }
     const uint32_t lanes = (uint32_t)huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height);
     const uint32_t segs = ((g.mcu_cols + 9u) / 10u) * g.mcu_rows;
-    const uint32_t round = dense_round(n);
+    // dense lines for a round of fall-back frames: by count (above), and never more than 2 GB of them -- at 640x480 a
+    // block line is 128 bytes x 7 200 blocks, and 16 384 frames of that would be 15 GB kept for rounds that usually find nothing
+    uint32_t round = dense_round(n);
+    {
+        const uint64_t by_bytes = (2ull << 30) / ((uint64_t)g.blocks * 128u);
+        if (round > by_bytes) round = by_bytes > 64u ? (uint32_t)by_bytes : 64u;
+        if (round > n) round = n;
+    }
     if (int r = ensure(c, c->coef, (size_t)round * g.blocks * 128)) return r;
     if (int r = ensure(c, b.nmcu, (size_t)n * 4)) return r;
-    if (int r = ensure(c, b.rec, (size_t)n * cap_rec * 4 + 16)) return r;   // + what a 16-byte read of a frame's last records may overshoot
+    if (int r = ensure(c, b.rec, (size_t)cap_lines * 128 + 16)) return r;   // + what a 16-byte read of a frame's last records may overshoot
+    if (int r = ensure(c, b.rec_line, ((size_t)n + 1) * 4)) return r;
+    const LayoutSpec rec_layout{4u, add_rec, hi_rec, 5u, (uint32_t)cap_lines, (uint32_t*)b.rec_line.p};   // laid out by entropy_front's launch
     if (int r = ensure(c, b.seg_start, (size_t)n * (segs + 1) * 8)) return r;
     if (int r = ensure(c, b.lane_tab, (size_t)n * lanes * 16)) return r;
     if (int r = ensure(c, b.rec_count, (size_t)n * 4)) return r;
-    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)b.rec.p, cap_rec, (uint32_t*)b.seg_start.p, (uint32_t*)b.lane_tab.p, lanes,
+    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)b.rec.p, (const uint32_t*)b.rec_line.p, (uint32_t*)b.seg_start.p, (uint32_t*)b.lane_tab.p, lanes,
                     (uint32_t*)b.rec_count.p, nullptr, nullptr};
     uint32_t* d_nmcu = (uint32_t*)b.nmcu.p;
+    c->last_decode_retry = &b.retry;
     Fallback fb;
-    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu, b.retry, front, fb)) return r;
+    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu, b.retry, front, fb, rec_layout)) return r;
     if (back != front) {
         HIP_TRY(c, hipEventRecord(c->ev_front, front));
         HIP_TRY(c, hipStreamWaitEvent(back, c->ev_front, 0));
@@ -505,7 +530,7 @@ static int decode_core(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes
         if (int r = check_launch(c, "huffman")) return r;
         if (int r = reconstruct_launch(c, sinks, d_nmcu, n, FrameSel{fb.list, fb.count, base, items}, items, g, flags, d_out, st)) return r;
     }
-    c->ws_bytes_per_frame = (double)(c->ws.cap + c->coef.cap + c->ws_bytes.cap + c->rec.cap + c->seg_start.cap + c->lane_tab.cap +
+    c->ws_bytes_per_frame = (double)(c->ws.cap + c->coef.cap + c->ws_bytes.cap + c->ws_line.cap + c->rec.cap + c->rec_line.cap + c->second.rec_line.cap + c->seg_start.cap + c->lane_tab.cap +
                                      c->rec_count.cap + c->nmcu.cap + c->retry.cap + c->second.rec.cap + c->second.seg_start.cap +
                                      c->second.lane_tab.cap + c->second.rec_count.cap + c->second.nmcu.cap + c->second.retry.cap) / n;
     return AMVHIP_OK;
@@ -521,7 +546,7 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
     if (int r = use_device(c)) return r;
     std::lock_guard<std::mutex> lk(c->mu);
     return decode_core(c, d_blob, blob_bytes, d_offs, d_lens, n, w, h, flags, d_out, d_status,
-                       DecodeBufs{c->nmcu, c->retry, c->rec, c->seg_start, c->lane_tab, c->rec_count}, (hipStream_t)stream,
+                       DecodeBufs{c->nmcu, c->retry, c->rec, c->rec_line, c->seg_start, c->lane_tab, c->rec_count}, (hipStream_t)stream,
                        (hipStream_t)stream);
 }
 
@@ -557,8 +582,8 @@ extern "C" int amvhip_decode_submit_dev(amvhip_ctx* c, const uint8_t* d_blob, ui
     // ahead of the batch before this one -- whose entropy stage `front` has already gone through -- but not of `front`)
     if (c->submitted >= 2) HIP_TRY(c, hipStreamWaitEvent(c->front, c->ev_done[which], 0));
     if (n != 0) {
-        DecodeBufs first{c->nmcu, c->retry, c->rec, c->seg_start, c->lane_tab, c->rec_count};
-        DecodeBufs second{c->second.nmcu, c->second.retry, c->second.rec, c->second.seg_start, c->second.lane_tab, c->second.rec_count};
+        DecodeBufs first{c->nmcu, c->retry, c->rec, c->rec_line, c->seg_start, c->lane_tab, c->rec_count};
+        DecodeBufs second{c->second.nmcu, c->second.retry, c->second.rec, c->second.rec_line, c->second.seg_start, c->second.lane_tab, c->second.rec_count};
         if (int r = decode_core(c, d_blob, blob_bytes, d_offs, d_lens, n, w, h, flags, d_out, d_status, which ? second : first, c->front,
                                 c->back))
             return r;
@@ -674,12 +699,17 @@ static int encode_core(amvhip_ctx* c, const uint8_t* d_pix, uint32_t pix_stride,
                        const FrameGeom& g, uint32_t qbias, uint8_t* d_blob, uint64_t blob_cap, uint64_t* d_offs, uint32_t* d_lens,
                        hipStream_t stream) {
     const uint32_t bound = amvhip_encode_bound(g.width, g.height);
-    const uint32_t round = encode_round(n);
+    uint32_t round = encode_round(n);
+    {   // (never more than 2 GB of dense coefficient lines, as in decode_core)
+        const uint64_t by_bytes = (2ull << 30) / ((uint64_t)g.blocks * 128u);
+        if (round > by_bytes) round = by_bytes > 64u ? (uint32_t)by_bytes : 64u;
+        if (round > n) round = n;
+    }
     if (int r = ensure(c, c->coef, (size_t)round * g.blocks * 128)) return r;
     if (int r = ensure(c, c->tmp, (size_t)n * bound)) return r;
     if (int r = ensure(c, c->flag, 16)) return r;
-    if (int r = ensure(c, c->retry, ((size_t)n + 4) * 8)) return r;
-    uint32_t* retry_count = (uint32_t*)c->retry.p;
+    if (int r = ensure(c, c->enc_retry, ((size_t)n + 4) * 8)) return r;   // (the encoder's own: the decode path's counter is read by amvhip_entropy_stats)
+    uint32_t* retry_count = (uint32_t*)c->enc_retry.p;
     uint32_t* retry_list = retry_count + 8;
     HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, stream));
     const bool fused = c->entropy_mode != AMVHIP_ENTROPY_SERIAL;
@@ -956,7 +986,10 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
                 sweeps = n > 64u ? sweeps + 2u : 0u;
             }
             c->chain_n = n;
+            // (state, lists, counters and the flag live in the context's `chain` buffer: chained encodes of ONE context
+            // must be ordered on the device -- one stream at a time, as for every _dev entry point; see amvhip.h)
             need = launch_adpcm_chain(d_pcm, d_pcm_offs, d_nsamp, n, d_blob, d_offs, c->chain.p, sweeps, (hipStream_t)stream);
+            if (!need) return fail(c, AMVHIP_ERR_DEVICE, "adpcm_encode: clearing the chain counters failed");
         }
         launch_adpcm_map(d_pcm, d_pcm_offs, d_nsamp, n, (uint8_t*)c->map.p, (int32_t*)c->start.p, need, (hipStream_t)stream);
         d_step_in = (const int32_t*)c->start.p;
@@ -1223,6 +1256,7 @@ extern "C" int amvhip_set_entropy_mode(amvhip_ctx* c, int mode) {
 extern "C" int amvhip_entropy_stats(amvhip_ctx* c, int enable, uint64_t out[10]) {
     if (!c) return AMVHIP_ERR_ARG;
     if (int r = use_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
     if (int r = ensure(c, c->stats, 128)) return r;
     HIP_TRY(c, hipDeviceSynchronize());
     if (out) {
@@ -1231,7 +1265,7 @@ extern "C" int amvhip_entropy_stats(amvhip_ctx* c, int enable, uint64_t out[10])
         // frames of the LAST decode call that the synchronising kernel handed to the one-lane-per-frame kernel (chunk
         // over the workspace window, long FF run, more records than the record space holds: see blob_bytes in amvhip.h)
         uint32_t handed = 0;
-        if (c->retry.p) HIP_TRY(c, hipMemcpy(&handed, c->retry.p, 4, hipMemcpyDeviceToHost));
+        if (c->last_decode_retry && c->last_decode_retry->p) HIP_TRY(c, hipMemcpy(&handed, c->last_decode_retry->p, 4, hipMemcpyDeviceToHost));
         out[3] = handed;
     }
     HIP_TRY(c, hipMemset(c->stats.p, 0, 128));

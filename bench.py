@@ -58,10 +58,14 @@ class Env:
     pass
 
 
-def make_video_stream(E, first, n, w, h):
-    """frames [first, first+n) of the seeded source, encoded on the device -> blob, cap, offs, lens, bytes"""
+def make_video_stream(E, first, n, w, h, noise_every=0):
+    """frames [first, first+n) of the seeded source, encoded on the device -> blob, cap, offs, lens, bytes.
+    noise_every = k: every k-th frame (frame number % k == k - 1) is white noise instead -- every coefficient of every block
+    non-zero, a chunk 2.7 times the stream's mean (the "mixed" stream: what per-frame workspace is for)"""
     ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
-    cap = max(1 << 20, n * w * h)             # ~0.2 B/pixel in practice; checked below
+    cap = max(1 << 20, n * w * h * (2 if noise_every else 1))             # ~0.2 B/pixel in practice; checked below
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED)
     d_blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
     d_offs = torch.zeros(n, dtype=torch.int64, device=dev)
     d_lens = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -72,6 +76,14 @@ def make_video_stream(E, first, n, w, h):
     for lo in range(0, n, chunk):
         cnt = min(chunk, n - lo)
         ctx.synth_frames_dev(SEED, first + lo, cnt, w, h, d_rgb, stream)
+        if noise_every:
+            torch.cuda.synchronize()
+            idx = torch.arange(first + lo, first + lo + cnt, device=dev)
+            pick = (idx % noise_every) == noise_every - 1
+            k = int(pick.sum().item())
+            if k:
+                d_rgb[:cnt][pick] = torch.randint(0, 256, (k, h, w, 3), dtype=torch.uint8, device=dev, generator=gen)
+            torch.cuda.synchronize()
         ctx.encode_batch_dev(d_rgb, w * 3, 0, cnt, w, h, pkg.QBIAS_AMV, d_blob[pos:], cap - pos, t_offs, d_lens[lo:], stream)
         torch.cuda.synchronize()
         d_offs[lo:lo + cnt] = t_offs[:cnt] + pos
@@ -221,7 +233,24 @@ def run_decode(E, args):
     ctx, pkg, dev, stream = E.ctx, E.pkg, E.dev, E.stream
     w, h, n = args.width or 160, args.height or 120, args.frames or DECODE_FRAMES
     first = E.rank * n
-    d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, first, n, w, h)
+    kind = getattr(args, "stream", "synthetic") or "synthetic"
+    orc = entry.load_oracle()
+    if kind == "amv1":
+        # the reference's own clip (C-AMVDecoder/bin/AMV1.amv, 128x96, 252 frames, chunks of 1 410 - 2 924 bytes), its chunks
+        # laid out back to back over and over until there are n of them: a real clip's spread of chunk sizes, device-resident
+        info, amv_chunks, _ = orc.parse_amv(open(os.path.join(ROOT, "tests", "golden", "AMV1.amv"), "rb").read())
+        w, h = info["width"], info["height"]
+        once = np.frombuffer(b"".join(c + b"\0" * (-len(c) % 4) for c in amv_chunks), np.uint8)
+        lens1 = np.array([len(c) for c in amv_chunks], np.int64)
+        offs1 = np.concatenate([[0], np.cumsum((lens1 + 3) & ~3)[:-1]])
+        reps = (n + len(lens1) - 1) // len(lens1)
+        d_blob = torch.from_numpy(once.copy()).to(dev).repeat(reps)
+        cap = int(d_blob.numel())
+        d_offs = (torch.from_numpy(offs1).to(dev)[None, :] + torch.arange(reps, device=dev)[:, None] * once.size).reshape(-1)[:n].contiguous()
+        d_lens = torch.from_numpy(lens1.astype(np.int32)).to(dev).repeat(reps)[:n].contiguous()
+        stream_bytes = int(d_lens.sum().item())
+    else:
+        d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, first, n, w, h, 16 if kind == "mixed" else 0)
     d_out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
     d_st = torch.empty(n, dtype=torch.int32, device=dev)
 
@@ -233,14 +262,16 @@ def run_decode(E, args):
     torch.cuda.synchronize()
     if int((d_st != 0).sum().item()) != 0:
         raise SystemExit("decode reported errors on the synthetic stream")
-    orc = entry.load_oracle()
     offs_h, lens_h = d_offs.cpu().numpy(), d_lens.cpu().numpy()
-    for i in sorted({0, 1, n // 2, n - 1}):
+    for i in sorted({0, 1, 15, n // 2, n - 1} & set(range(n))):
         ch = d_blob[int(offs_h[i]):int(offs_h[i]) + int(lens_h[i])].cpu().numpy().tobytes()
         want, st, _ = orc.decode_frame(ch, w, h)
         if st != 0 or not (d_out[i].cpu().numpy() == want).all():
             raise SystemExit("HIP decode differs from the oracle at frame %d" % (first + i))
-        if ch != orc.encode_frame(orc.synth_frame(SEED, first + i, w, h), w, h):
+        if kind == "amv1":
+            if ch != amv_chunks[i % len(amv_chunks)]:
+                raise SystemExit("looped clip: frame %d is not the clip's chunk" % i)
+        elif not (kind == "mixed" and (first + i) % 16 == 15) and ch != orc.encode_frame(orc.synth_frame(SEED, first + i, w, h), w, h):
             raise SystemExit("device-made stream differs from the oracle's encoder at frame %d" % (first + i))
 
     # ... and EVERY frame of the batch against a second decode of it with the other entropy kernel (the serial one-lane
@@ -309,12 +340,19 @@ def run_decode(E, args):
     sync = ctx.entropy_stats(False)
 
     result = base_result(E, args, "AMV frames/sec/GPU (%dx%d decode, bit-exact)" % (w, h), "frames/s", n, elapsed)
-    result["config"] = {"workload": "%dx%d AMV decode, %d-frame synthetic stream per GPU, chunks resident in HBM" % (w, h, n),
+    result["config"] = {"workload": "%dx%d AMV decode, %d-frame %s stream per GPU, chunks resident in HBM"
+                                    % (w, h, n, {"synthetic": "synthetic", "mixed": "mixed (synthetic + noise)", "amv1": "AMV1.amv looped"}[kind]),
                         "frames_per_gpu": n, "mean_chunk_bytes": stream_bytes / n, "parallelism": "frame-range x%d" % E.world,
                         "per_gpu_frames_per_s": result["value"] / E.world,
                         "gate": "every frame == a second decode through the serial entropy kernel (device compare); frames 0, 1, "
                                 "n/2, n-1 == the CPU oracle; their chunks == the oracle's encoder"}
     result["config"]["decode_workspace_bytes_per_frame"] = workspace
+    result["config"]["handed_to_serial"] = int(sync["handed_to_serial"])   # frames of the batch the parallel entropy kernels gave up on
+    result["config"]["stream"] = {"synthetic": "seeded synthetic source (BASELINE.md section 4), every frame",
+                                  "mixed": "the synthetic source with every 16th frame replaced by white noise: chunk sizes from %d to %d bytes"
+                                           % (int(d_lens.min().item()), int(d_lens.max().item())),
+                                  "amv1": "the reference's clip AMV1.amv (128x96, 252 frames, chunks of %d - %d bytes) repeated"
+                                          % (int(d_lens.min().item()), int(d_lens.max().item()))}[kind]
     if one_call:
         result["config"]["calls"] = ("amvhip_decode_submit_dev / _collect_dev, batch k+1 submitted before batch k is collected "
                                      "(entropy stage of one batch beside the reconstruction of the one before), two sets of output buffers")
@@ -748,6 +786,8 @@ def run_secondary(E, args):
     # 10 000-frame line is there to show the other regime
     plan = (("decode_320x240", run_decode, {"width": 320, "height": 240, "frames": 128000}),
             ("decode_160x120_10k_stream", run_decode, {"frames": 10000}),
+            ("decode_160x120_mixed", run_decode, {"stream": "mixed"}),
+            ("decode_amv1_looped", run_decode, {"stream": "amv1", "frames": 200000}),
             ("encode_320x240", run_encode, {}),
             ("coresident_320x240_adpcm", lambda e, a: run_adpcm(e, a, with_video=True), {"frames": 64000}),
             ("adpcm", lambda e, a: run_adpcm(e, a, with_video=False), {}))
@@ -836,6 +876,9 @@ def main():
                          "back) and report it under config.config4_strong_10k; always on when WORLD_SIZE > 1")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="frames of the stream the CPU baseline decodes")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="bound on the all-core part of the CPU baseline")
+    ap.add_argument("--stream", choices=("synthetic", "mixed", "amv1"), default="synthetic",
+                    help="decode: the seeded synthetic source; the same with every 16th frame noise (chunk sizes spread over 20x); "
+                         "the reference's clip AMV1.amv (128x96) repeated")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default line only: skip the other BASELINE configs (config.secondary)")
     args = ap.parse_args()
@@ -866,7 +909,7 @@ def main():
 
     if args.workload == "decode":
         result = run_decode(E, args)
-        plain = not (args.frames or args.width or args.height or args.pipelined or args.strong)
+        plain = not (args.frames or args.width or args.height or args.pipelined or args.strong or args.stream != "synthetic")
         if plain and E.world == 1 and not args.no_secondary:
             sec = run_secondary(E, args)
             result["config"].update(flat_secondary(sec))

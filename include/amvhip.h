@@ -199,10 +199,13 @@ uint32_t amvhip_jpeg_header(uint16_t height, uint16_t width, uint8_t *out, uint3
  *   d_blob     : all chunks back to back (each "FF D8" scan "FF D9"); the pointer must be 4-byte aligned (AMVHIP_ERR_ARG
  *                otherwise; chunks themselves may start at any byte)
  *   blob_bytes : the bytes of d_blob the chunks OCCUPY (the end of the last chunk), not the capacity of a larger
- *                buffer: chunks are bounds-checked against it, and the hand-over space between the two decode stages is
- *                sized from blob_bytes / n (two records per byte of chunk, never under 8 per block) -- with a figure far
- *                above the real mean, memory is wasted; with one below it (a few heavy frames among light ones), frames
- *                that need more records than that are decoded by the one-lane-per-frame kernel: same bytes, slower
+ *                buffer: chunks are bounds-checked against it, and the two workspaces between the decode stages -- the
+ *                unstuffed scans, the coefficient records -- are laid out per frame from d_lens[i] (on the device) inside a
+ *                total sized from blob_bytes here: 1x + 48 bytes per frame for the scans, 8x + (8 per block + 380) bytes per
+ *                frame for the records.  Chunks that OVERLAP in the blob (their lengths add up to more than blob_bytes) are
+ *                legal and decode correctly, but the layout runs out and the frames behind that point are decoded by the
+ *                one-lane-per-frame kernel: same bytes, slower; so is a frame with more than two records per chunk byte
+ *                (amvhip_entropy_stats reports how many frames of the last call took that route)
  *   d_offs[i]  : byte offset of chunk i in d_blob;  d_lens[i]: its length
  *   d_out      : n * amvhip_frame_bytes(w,h), 4-byte aligned; frame i is BGR24, row 0 = top, rows padded to
  *                amvhip_stride(w); pixels of MCUs after a failing one are zero (AMVDec.c:283)
