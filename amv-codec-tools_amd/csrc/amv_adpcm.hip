@@ -153,12 +153,16 @@ template <bool kWrite, int kSlot>
 __device__ __forceinline__ void compress(EncodeState& s, float sample, const EncodeLds& l, uint32_t& qb, uint32_t& sb, uint32_t& tick) {
     const float d = sample - s.prev;
     const float q8 = fminf(truncf(__builtin_fmaf(__builtin_fabsf(d), s.rcp, 8.0f)), 15.0f);
-    const float mag = truncf(__builtin_fmaf(q8, s.s4, s.s8m));                      // step * yamaha_difflookup[nibble] / 8
-    s.prev = __builtin_amdgcn_fmed3f(s.prev + __builtin_copysignf(mag, d), -32768.0f, 32767.0f);
+    // the next cell is asked for the moment its address exists -- the factor loop (cell -> quotient -> address -> cell) is
+    // the longer of the two, and the scheduler would put four independent instructions in front of the read
     uint32_t addr;
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"
         : "=v"(addr) : "v"(s.row), "v"(q8));
+    const float s4 = s.s4, s8m = s.s8m;
     take_cell(s, *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(l.cell) + addr));
+    __builtin_amdgcn_sched_barrier(0);
+    const float mag = truncf(__builtin_fmaf(q8, s4, s8m));                          // step * yamaha_difflookup[nibble] / 8
+    s.prev = __builtin_amdgcn_fmed3f(s.prev + __builtin_copysignf(mag, d), -32768.0f, 32767.0f);
     tick = __float_as_uint(q8);     // known before the cell is asked for: what the next sample's conversion is tied behind
     if (kWrite) {
         const uint32_t c80 = 0x80u;

@@ -980,10 +980,13 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
         if (c->adpcm_sweeps >= 0) {   // guessed starts + sweeps; the exhaustive route behind it runs only if they do not settle
             if (int r = ensure(c, c->chain, adpcm_chain_workspace(n))) return r;
             uint32_t sweeps = (uint32_t)c->adpcm_sweeps;
-            if (!c->adpcm_sweeps_set) {   // the lists shrink ~3.7x per sweep on ordinary audio; a few to spare
+            if (!c->adpcm_sweeps_set) {
+                // launched sweeps: until the list is expected to be a few hundred entries (it starts at ~0.41 n and shrinks
+                // ~3.7x per sweep on ordinary audio; counted here as n shrinking 3.3x), one to spare; the one-workgroup
+                // settle kernel takes the rest, round after round, without a launch and a table load per round
                 sweeps = 0;
-                for (uint64_t left = n; left > 64u; left = left * 3u / 10u) ++sweeps;
-                sweeps = n > 64u ? sweeps + 2u : 0u;
+                for (uint64_t left = n; left > 512u; left = left * 3u / 10u) ++sweeps;
+                sweeps = n > 64u ? sweeps + 1u : 0u;
             }
             c->chain_n = n;
             // (state, lists, counters and the flag live in the context's `chain` buffer: chained encodes of ONE context
