@@ -5,7 +5,7 @@
 # usage: tools/profile_round.sh <tag>      (outputs under gpurun_out/<tag>_*; tools/collect_profiles.py copies the
 #                                           summaries to profiles/)
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd $root
@@ -17,6 +17,8 @@ python3 bench.py --workload amvlib > $out/${tag}_bench_amvlib.json 2>> $out/${ta
 python3 bench.py --width 320 --height 240 --frames 32000 --no-cpu-baseline > $out/${tag}_bench_decode320.json 2>> $out/${tag}_bench.err
 python3 bench.py --frames 10000 --no-cpu-baseline > $out/${tag}_bench_decode10k.json 2>> $out/${tag}_bench.err
 python3 bench.py --strong --frames 20000 --no-cpu-baseline > $out/${tag}_bench_strong_world1.json 2>> $out/${tag}_bench.err
+python3 bench.py --stream mixed --no-secondary > $out/${tag}_bench_mixed.json 2>> $out/${tag}_bench.err
+python3 bench.py --stream amv1 --frames 200000 --no-secondary > $out/${tag}_bench_amv1.json 2>> $out/${tag}_bench.err
 echo "benches done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o run --output-format csv -- python3 $root/bench.py --no-cpu-baseline --no-secondary > $out/${tag}_stats.log 2>&1
@@ -30,7 +32,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch_encode -o run
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write_encode -o run --output-format csv -- python3 $root/bench.py --workload encode --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write_encode.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch_decode320 -o run --output-format csv -- python3 $root/bench.py --width 320 --height 240 --frames 128000 --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch_decode320.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write_decode320 -o run --output-format csv -- python3 $root/bench.py --width 320 --height 240 --frames 128000 --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write_decode320.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch_adpcm -o run --output-format csv -- python3 $root/bench.py --workload adpcm --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch_adpcm.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write_adpcm -o run --output-format csv -- python3 $root/bench.py --workload adpcm --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write_adpcm.log 2>&1
 echo "pmc done"
 bash $root/tools/pmc_sq.sh ${tag}sq 160000
 bash $root/tools/pmc_sq_bench.sh ${tag}sqenc --workload encode
+bash $root/tools/pmc_sq_bench.sh ${tag}sqadpcm --workload adpcm
 echo done
