@@ -576,11 +576,8 @@ __device__ __forceinline__ int encode_chunk(const int16_t* __restrict__ x, uint3
     const int prev = pairs ? x[0] : 0;              // adpcm.c:464
     const uint32_t cnt = pairs << 1;                // :479 le32 sample count
     if (live) {
-        d[0] = (uint8_t)(prev & 0xff);              // :465 le16 first sample
-        d[1] = (uint8_t)((prev >> 8) & 0xff);
-        d[2] = (uint8_t)start;                      // :466 le16 step index
-        d[3] = 0;
-        d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
+        // :465 le16 first sample, :466 le16 step index, :479 le32 sample count -- the eight bytes as one store
+        *reinterpret_cast<Bytes8*>(d) = Bytes8{{((uint32_t)prev & 0xffffu) | ((uint32_t)start & 0xffu) << 16, cnt}};
     }
     EncodeState s = encode_state(prev, start, l);
     encode_rows<true>(x, cnt, s, d + 8, l, st);
@@ -594,11 +591,7 @@ __device__ __forceinline__ int encode_chunk_alone(const int16_t* __restrict__ x,
     const uint32_t pairs = nsamp >> 1;
     const int prev = pairs ? x[0] : 0;
     const uint32_t cnt = pairs << 1;
-    d[0] = (uint8_t)(prev & 0xff);
-    d[1] = (uint8_t)((prev >> 8) & 0xff);
-    d[2] = (uint8_t)start;
-    d[3] = 0;
-    d[4] = (uint8_t)cnt; d[5] = (uint8_t)(cnt >> 8); d[6] = (uint8_t)(cnt >> 16); d[7] = (uint8_t)(cnt >> 24);
+    *reinterpret_cast<Bytes8*>(d) = Bytes8{{((uint32_t)prev & 0xffffu) | ((uint32_t)start & 0xffu) << 16, cnt}};
     EncodeState s = encode_state(prev, start, l);
     encode_run<true>(x, cnt, s, d + 8, l);
     return state_index(s);
