@@ -159,7 +159,15 @@ __device__ __forceinline__ void compress(EncodeState& s, float sample, const Enc
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"
         : "=v"(addr) : "v"(s.row), "v"(q8));
     const float s4 = s.s4, s8m = s.s8m;
-    take_cell(s, *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(l.cell) + addr));
+    // ... as TWO 8-byte reads: a ds_read_b128 with a row of its own per lane occupies the CU's LDS for 27 cycles, a
+    // ds_read_b64 for 6 - 7 (tools/microbench_lds_lookup.hip, profiles/r04_lds_lookup.txt), and with three waves per SIMD
+    // asking once per sample that was what the guess pass was bound by.  The half the factor loop waits for goes first;
+    // the address is hidden from the compiler in between, or it makes the two reads one again.
+    const uint8_t* cells = reinterpret_cast<const uint8_t*>(l.cell);
+    const uint2 hi = *reinterpret_cast<const uint2*>(cells + addr + 8u);
+    asm("" : "+v"(addr));
+    const uint2 lo = *reinterpret_cast<const uint2*>(cells + addr);
+    take_cell(s, make_uint4(lo.x, lo.y, hi.x, hi.y));
     __builtin_amdgcn_sched_barrier(0);
     const float mag = truncf(__builtin_fmaf(q8, s4, s8m));                          // step * yamaha_difflookup[nibble] / 8
     s.prev = __builtin_amdgcn_fmed3f(s.prev + __builtin_copysignf(mag, d), -32768.0f, 32767.0f);
@@ -569,6 +577,19 @@ __global__ void amv_adpcm_wav_encode_kernel(const int16_t* __restrict__ x, int g
 __device__ __forceinline__ uint32_t peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void poke(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// state[i] = {start the chunk's bytes were coded from, end reached from it}, replaced as ONE 64-bit word so that no reader
+// and no second writer ever sees one chunk's start beside another coding's end; returns the end that was there.  Whoever
+// changes a chunk's end lists its successor: that rule, and a listed chunk being coded again whenever its start is not its
+// predecessor's end, is all the sweeps rest on.  kPredicted in the start: the end is where the chunk WILL end from that
+// start (the front sweep's look-ahead), its bytes are not coded yet -- no real start equals it, so the chunk is coded
+// when its turn comes.
+constexpr uint32_t kPredicted = 0x100u;
+__device__ __forceinline__ uint32_t swap_state(uint2* p, uint32_t start, uint32_t end) {
+    const uint64_t old = __hip_atomic_exchange(reinterpret_cast<uint64_t*>(p), (uint64_t)start | (uint64_t)end << 32, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+    return (uint32_t)(old >> 32);
+}
+
 // the chunks of a wave's 64 lanes (live: this lane has one), each from its start index; returns the end index
 __device__ __forceinline__ int encode_chunk(const int16_t* __restrict__ x, uint32_t nsamp, int start, uint8_t* __restrict__ d,
                                             bool live, const EncodeLds& l, StageLds& st) {
@@ -649,8 +670,9 @@ __device__ __forceinline__ void sweep_one(const int16_t* __restrict__ pcm, const
                                           const uint32_t* __restrict__ nsamp, uint32_t n, uint8_t* __restrict__ blob,
                                           const uint64_t* __restrict__ offs, uint2* __restrict__ state, uint32_t i, bool listed,
                                           uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out, const EncodeLds& s_tab,
-                                          StageLds& st) {
-    // (kStaged: all 64 lanes of the wave come here together; `listed`: this lane has an entry i of the list)
+                                          StageLds* st) {
+    // (kStaged: all 64 lanes of the wave come here together, st = the wave's staging tile; `listed`: this lane has an entry i
+    // of the list)
     uint32_t* sw = reinterpret_cast<uint32_t*>(state);
     uint32_t start = 0u;
     bool todo = false;
@@ -661,16 +683,13 @@ __device__ __forceinline__ void sweep_one(const int16_t* __restrict__ pcm, const
     uint32_t end;
     if (kStaged) {
         end = (uint32_t)encode_chunk(todo ? pcm + pcm_offs[i] : pcm, todo ? nsamp[i] : 0u, (int)start, todo ? blob + offs[i] : blob, todo,
-                                     s_tab, st);
+                                     s_tab, *st);
         if (!todo) return;
     } else {
         if (!todo) return;
         end = (uint32_t)encode_chunk_alone(pcm + pcm_offs[i], nsamp[i], (int)start, blob + offs[i], s_tab);
     }
-    poke(sw + 2u * i, start);
-    if (end == peek(sw + 2u * i + 1u)) return;
-    poke(sw + 2u * i + 1u, end);
-    if (i + 1u < n) list_out[atomicAdd(count_out, 1u)] = i + 1u;
+    if (swap_state(state + i, start, end) != end && i + 1u < n) list_out[atomicAdd(count_out, 1u)] = i + 1u;
 }
 
 constexpr uint32_t kStagedAbove = 32768;   // list entries from which a sweep is bound by its memory accesses, not by one chunk's chain
@@ -692,8 +711,108 @@ __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_sweep_kernel(
     for (uint32_t base = blockIdx.x * kEncodeBlock + (threadIdx.x & ~63u); base < count; base += gridDim.x * kEncodeBlock) {
         const bool listed = base + lane < count;
         const uint32_t i = listed ? list_in[base + lane] : 1u;
-        if (count > kStagedAbove) sweep_one<true>(pcm, pcm_offs, nsamp, n, blob, offs, state, i, listed, list_out, count_out, s_tab, st);
-        else sweep_one<false>(pcm, pcm_offs, nsamp, n, blob, offs, state, i, listed, list_out, count_out, s_tab, st);
+        if (count > kStagedAbove) sweep_one<true>(pcm, pcm_offs, nsamp, n, blob, offs, state, i, listed, list_out, count_out, s_tab, &st);
+        else sweep_one<false>(pcm, pcm_offs, nsamp, n, blob, offs, state, i, listed, list_out, count_out, s_tab, nullptr);
+    }
+}
+
+// A sweep that looks ahead (round 4).  A listed chunk is the head of a FRONT: if its end moves, its successor must be coded
+// again, and so on -- one chunk per sweep, each sweep one chunk's serial chain long.  Once the list is short there are
+// lanes to spare: a workgroup per head codes the head again (one lane) and, beside it, runs the next kFrontAhead chunks
+// from ALL 89 start indices (state only, a lane per (chunk, start)): when the head's new end is known, the maps say at once
+// where each of those chunks ends.  Their predicted ends are written to `state` with the start they follow from, marked
+// kPredicted (the chunks' bytes are stale until the next round codes them again -- from starts that are now all known, in
+// ONE round), and every chunk whose predecessor's end moved is listed, as the plain sweep does: once, whichever of two
+// fronts reaches it.  The sweeps' rule that a listed chunk is coded whenever its start is not its predecessor's end makes
+// whatever two fronts write about the same chunk converge.  With more than kFrontMost heads the kernel is a plain sweep.
+constexpr uint32_t kFrontAhead = 4;
+constexpr uint32_t kFrontMost = 320;        // heads: seven waves each, so about two waves per SIMD at most
+constexpr uint32_t kFrontHead = 384;        // waves 0-5: 4 x 89 map lanes; wave 6, lane 0: the head
+constexpr uint32_t kFrontThreads = 448;
+static_assert(kFrontAhead * 89u <= kFrontHead && kFrontHead + 64u == kFrontThreads, "map lanes, then the head's wave");
+
+__global__ __launch_bounds__(kFrontThreads) void amv_adpcm_front_kernel(
+    const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
+    uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state, const uint32_t* __restrict__ list_in,
+    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out,
+    uint32_t* __restrict__ listed, uint32_t* __restrict__ need_map) {
+    __shared__ EncodeLds s_tab;
+    __shared__ uint8_t s_map[kFrontAhead][96];
+    __shared__ uint32_t s_head[4];               // todo, start, end of the head
+    const uint32_t count = *count_in;
+    if (blockIdx.x >= count) return;
+    __builtin_amdgcn_s_setprio(3);
+    load_encode_tables(s_tab);
+    const bool ahead = count <= kFrontMost && (kFrontAhead + 1u) * count + 8u <= n;     // (a list holds n entries: room for every append)
+    uint32_t* sw = reinterpret_cast<uint32_t*>(state);
+    if (!ahead) {                                    // the list is still long (or the stream tiny): a plain sweep, a lane per entry
+        for (uint32_t k = blockIdx.x * kFrontThreads + threadIdx.x; k < count; k += gridDim.x * kFrontThreads)
+            sweep_one<false>(pcm, pcm_offs, nsamp, n, blob, offs, state, list_in[k], true, list_out, count_out, s_tab, nullptr);
+        return;
+    }
+    auto append = [&](uint32_t x) {
+        // once per chunk (`listed`: a bit per chunk, zero when the chain starts): a chunk two lanes of the next round code at
+        // the same time, from two different readings of its predecessor's end, would be left with bytes of both
+        if (atomicOr(listed + (x >> 5), 1u << (x & 31u)) >> (x & 31u) & 1u) return;
+        const uint32_t slot = atomicAdd(count_out, 1u);
+        if (slot < n) list_out[slot] = x;
+        else *need_map = 1u;                         // (cannot happen with the room checked above; the exhaustive route is always right)
+    };
+    for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+        const uint32_t i = list_in[h];
+        if (threadIdx.x == kFrontHead) {
+            const uint32_t start = peek(sw + 2u * (i - 1u) + 1u);
+            uint32_t what = start != peek(sw + 2u * i) ? 1u : 0u;
+            if (what) {
+                // a run of chunks whose starts are all about to move has ONE head, the first; the kFrontAhead chunks behind
+                // it are in its look-ahead, and coding them here from an end that is about to move would only write ends
+                // (and predictions) for the next rounds to take back.  Chunk j's end is about to move when the start its
+                // end belongs to is not its predecessor's end.
+                bool moving[kFrontAhead + 1u];
+#pragma unroll
+                for (uint32_t d = 1; d <= kFrontAhead + 1u; ++d)
+                    moving[d - 1u] = i > d && (peek(sw + 2u * (i - d)) & 0xffu) != peek(sw + 2u * (i - d - 1u) + 1u);
+                uint32_t d = 0;
+                while (d <= kFrontAhead && moving[d]) ++d;                 // chunk i-1-d is the nearest one that stays
+                if (d >= 1u && d <= kFrontAhead) what = 2u;               // the head is i-d, and i is in its look-ahead
+            }
+            s_head[0] = what;
+            s_head[1] = start;
+        }
+        __syncthreads();
+        const uint32_t what = s_head[0];
+        if (what == 1u) {
+            if (threadIdx.x == kFrontHead) {
+                s_head[2] = (uint32_t)encode_chunk_alone(pcm + pcm_offs[i], nsamp[i], (int)s_head[1], blob + offs[i], s_tab);
+            } else if (threadIdx.x < kFrontAhead * 89u) {
+                const uint32_t k = threadIdx.x / 89u, st = threadIdx.x - k * 89u, x = i + 1u + k;
+                if (x < n) {
+                    const int16_t* p = pcm + pcm_offs[x];
+                    const uint32_t m = nsamp[x] & ~1u;
+                    EncodeState e = encode_state(m ? p[0] : 0, (int)st, s_tab);
+                    encode_run<false>(p, m, e, nullptr, s_tab);
+                    s_map[k][st] = (uint8_t)state_index(e);
+                }
+            }
+        }
+        __syncthreads();
+        if (what == 2u && threadIdx.x == 0u) append(i);     // coded when its start is known: next round, from the head's prediction
+        if (what == 1u && threadIdx.x == 0u) {
+            uint32_t at = s_head[2];
+            if (swap_state(state + i, s_head[1], at) != at) {
+                for (uint32_t x = i + 1u, k = 0; x < n; ++x, ++k) {
+                    // its predecessor's end moved: validated next round, whatever its state says now -- x may be a head
+                    // itself, about to replace what is read here by what it coded from the end that has just moved
+                    append(x);
+                    if ((peek(sw + 2u * x) & 0xffu) == at) break;    // x's end is the end from `at` already
+                    if (k == kFrontAhead) break;     // ... and past the maps, that round finds where it ends
+                    const uint32_t pred = s_map[k][at];
+                    if (swap_state(state + x, at | kPredicted, pred) == pred) break;   // it ends where it ended: nothing behind it moves
+                    at = pred;
+                }
+            }
+        }
+        __syncthreads();                             // s_head / s_map are free again
     }
 }
 
@@ -704,10 +823,8 @@ __global__ __launch_bounds__(256) void amv_adpcm_settle_kernel(
     uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state, uint32_t* __restrict__ list_a,
     uint32_t* __restrict__ count_a, uint32_t* __restrict__ list_b, uint32_t* __restrict__ count_b, uint32_t* __restrict__ need_map) {
     __shared__ EncodeLds s_tab;
-    __shared__ StageLds s_stage[4];
     __builtin_amdgcn_s_setprio(3);
     load_encode_tables(s_tab);
-    StageLds& st = s_stage[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t round = 0;; ++round) {
         const uint32_t count = peek(count_a);
@@ -718,7 +835,7 @@ __global__ __launch_bounds__(256) void amv_adpcm_settle_kernel(
         }
         for (uint32_t base = threadIdx.x & ~63u; base < count; base += 256u) {
             const bool listed = base + lane < count;
-            sweep_one<false>(pcm, pcm_offs, nsamp, n, blob, offs, state, listed ? peek(list_a + base + lane) : 1u, listed, list_b, count_b, s_tab, st);
+            sweep_one<false>(pcm, pcm_offs, nsamp, n, blob, offs, state, listed ? peek(list_a + base + lane) : 1u, listed, list_b, count_b, s_tab, nullptr);
         }
         __threadfence();
         __syncthreads();                            // everyone has read count_a and finished its appends
@@ -1018,16 +1135,18 @@ void launch_adpcm_encode(const int16_t* pcm, const uint64_t* pcm_offs, const uin
 }
 
 // The guessed-start route.  work: adpcm_chain_workspace(n) bytes = state[n] (uint2), two lists of n words, 64 words of
-// counters (zeroed here; word 63 is the flag launch_adpcm_map / launch_adpcm_encode are given as `need`).
-uint64_t adpcm_chain_workspace(uint32_t n) { return (uint64_t)n * 16u + 256u; }
+// counters (word 63 is the flag launch_adpcm_map / launch_adpcm_encode are given as `need`) and a bit per chunk for the
+// front sweep; counters and bits are zeroed here.
+static uint64_t chain_zeroed_bytes(uint32_t n) { return 256u + (((uint64_t)n + 31u) / 32u) * 4u; }
+uint64_t adpcm_chain_workspace(uint32_t n) { return (uint64_t)n * 16u + chain_zeroed_bytes(n); }
 
 const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, uint8_t* blob,
                                    const uint64_t* offs, void* work, uint32_t sweeps, hipStream_t s) {
     uint2* state = static_cast<uint2*>(work);
     uint32_t* list[2] = {reinterpret_cast<uint32_t*>(state + n), reinterpret_cast<uint32_t*>(state + n) + n};
     uint32_t* count = list[1] + n;                   // [0 .. sweeps + 1]: one per list generation; [63]: the flag
-    if (sweeps > 60u) sweeps = 60u;
-    if (hipMemsetAsync(count, 0, 256, s) != hipSuccess) return nullptr;   // (the caller reports it: nothing has been queued)
+    if (sweeps > 59u) sweeps = 59u;
+    if (hipMemsetAsync(count, 0, chain_zeroed_bytes(n), s) != hipSuccess) return nullptr;   // (the caller reports it: nothing has been queued)
     hipLaunchKernelGGL(amv_adpcm_guess_kernel, dim3((n + kEncodeBlock - 1u) / kEncodeBlock), dim3(kEncodeBlock), 0, s, pcm, pcm_offs, nsamp, n,
                        blob, offs, state);
     if (n > 1u) {
@@ -1039,8 +1158,11 @@ const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs,
                                list[k & 1u], count + k, list[(k + 1u) & 1u], count + k + 1u);
             grid = grid > 256u ? (grid + 1u) / 2u : grid;
         }
+        // one sweep that looks four chunks ahead of every head (a plain sweep while the list is still long), then the rest
+        hipLaunchKernelGGL(amv_adpcm_front_kernel, dim3(kFrontMost), dim3(kFrontThreads), 0, s, pcm, pcm_offs, nsamp, n, blob, offs, state,
+                           list[sweeps & 1u], count + sweeps, list[(sweeps + 1u) & 1u], count + sweeps + 1u, count + 64, count + 63);
         hipLaunchKernelGGL(amv_adpcm_settle_kernel, dim3(1), dim3(256), 0, s, pcm, pcm_offs, nsamp, n, blob, offs, state,
-                           list[sweeps & 1u], count + sweeps, list[(sweeps + 1u) & 1u], count + sweeps + 1u, count + 63);
+                           list[(sweeps + 1u) & 1u], count + sweeps + 1u, list[sweeps & 1u], count + sweeps + 2u, count + 63);
     }
     return count + 63;
 }

@@ -981,12 +981,12 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
             if (int r = ensure(c, c->chain, adpcm_chain_workspace(n))) return r;
             uint32_t sweeps = (uint32_t)c->adpcm_sweeps;
             if (!c->adpcm_sweeps_set) {
-                // launched sweeps: until the list is expected to be a few hundred entries (it starts at ~0.41 n and shrinks
-                // ~3.7x per sweep on ordinary audio; counted here as n shrinking 3.3x), one to spare; the one-workgroup
-                // settle kernel takes the rest, round after round, without a launch and a table load per round
+                // launched sweeps: until the list is expected to be a couple of hundred entries (it starts at ~0.41 n and
+                // shrinks ~3.7x per sweep on ordinary audio; counted here as n shrinking 3.3x).  The front sweep behind them
+                // (a workgroup per entry, four chunks looked ahead) and the one-workgroup settle kernel take the rest
                 sweeps = 0;
                 for (uint64_t left = n; left > 512u; left = left * 3u / 10u) ++sweeps;
-                sweeps = n > 64u ? sweeps + 1u : 0u;
+                if (n <= 64u) sweeps = 0u;
             }
             c->chain_n = n;
             // (state, lists, counters and the flag live in the context's `chain` buffer: chained encodes of ONE context

@@ -1505,6 +1505,33 @@ def test_adpcm_index_chain_routes(pkg, orc):
     assert seen_exhaustive == 3 and seen_settled == 1
 
 
+def test_adpcm_index_chain_many_streams(ctx, orc):
+    """The sweeps' hand-offs are between workgroups that run at the same time (the front sweep writes predictions about
+    chunks other workgroups are coding): a dozen ragged streams of a few hundred to a few thousand chunks, each coded
+    three times, every byte against the oracle's sequential encode.  (Stream lengths chosen so that the front sweep gets
+    its look-ahead lists of one to three hundred heads.)"""
+    rng = np.random.default_rng(20260404)
+    for it in range(12):
+        n = int(rng.integers(300, 5000))
+        sizes = [1378 if rng.integers(0, 10) else 2 * int(rng.integers(0, 700)) for _ in range(n)]
+        pcm_offs = np.cumsum([0] + sizes).astype(np.uint64)
+        pcm = orc.synth_audio(SEED + it, 4242, int(pcm_offs[-1]) + 2)
+        offs = np.cumsum([0] + [8 + s // 2 for s in sizes]).astype(np.uint64)
+        want, idx = [], 0
+        for i in range(n):
+            seg = pcm[int(pcm_offs[i]):int(pcm_offs[i + 1])]
+            if seg.size:
+                chunk, idx = orc.adpcm_encode_chunk(seg, idx)
+            else:
+                chunk = bytes([0, 0, idx, 0, 0, 0, 0, 0])
+            want.append(chunk)
+        want = b"".join(want)
+        for rep in range(3):
+            blob = np.full(int(offs[-1]), 0xEE, np.uint8)
+            ctx.adpcm_encode_batch(pcm, pcm.size, pcm_offs[:-1].copy(), np.array(sizes, np.uint32), n, None, blob, blob.size, offs[:-1].copy())
+            assert blob.tobytes() == want, (it, rep, n, ctx.adpcm_chain_stats())
+
+
 def test_encode_frame_kernel_paths(ctx, pkg, orc):
     """amv_encode_frame_kernel's less travelled paths, every chunk against the oracle's encoder: runs of symbols that
     overflow a lane's scratch and are coded a second time straight into the round's bit string (a few noisy blocks in a

@@ -174,5 +174,15 @@ int main() {
     printf("four waves of one workgroup (one per SIMD), same chains:\n");
     run("dep_add x4 waves", dep_add, 256, d_out);
     run("ds_read_b128 chase x4 waves", lds_chase<16>, 256, d_out);
+    printf("two, three and four waves per SIMD (workgroups of 512, 768, 1024), the same dependent chains -- per instruction of ONE wave:\n");
+    for (int t = 512; t <= 1024; t += 256) {
+        char name[96];
+        snprintf(name, sizeof name, "dep_add x%d waves", t / 64); run(name, dep_add, t, d_out);
+        snprintf(name, sizeof name, "dep_fma_f32 x%d waves", t / 64); run(name, dep_fma_f32, t, d_out);
+        snprintf(name, sizeof name, "dep_sdwa_add x%d waves", t / 64); run(name, dep_sdwa_add, t, d_out);
+        snprintf(name, sizeof name, "dep_med3_f x%d waves", t / 64); run(name, dep_med3_f, t, d_out);
+        snprintf(name, sizeof name, "ds_read_b64 chase x%d waves", t / 64); run(name, lds_chase<8>, t, d_out);
+        snprintf(name, sizeof name, "ds_read_b128 chase x%d waves", t / 64); run(name, lds_chase<16>, t, d_out);
+    }
     return 0;
 }
