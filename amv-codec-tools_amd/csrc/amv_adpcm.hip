@@ -625,9 +625,11 @@ constexpr uint32_t kSettleRounds = 48;
 // every chunk from a guessed start; state[i] = {start used, end reached}
 __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_guess_kernel(
     const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
-    uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state) {
+    uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint2* __restrict__ state, uint32_t* __restrict__ list,
+    uint32_t* __restrict__ count) {
     __shared__ EncodeLds s_tab;
     __shared__ StageLds s_stage[kEncodeBlock / 64u];
+    __shared__ uint32_t s_end[kEncodeBlock / 64u];
     load_encode_tables(s_tab);
     StageLds& st = s_stage[threadIdx.x >> 6];
     const uint32_t i = blockIdx.x * kEncodeBlock + threadIdx.x;
@@ -643,22 +645,22 @@ __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_guess_kernel(
     }
     const int end = encode_chunk(live ? pcm + pcm_offs[i] : pcm, live ? nsamp[i] : 0u, start, live ? blob + offs[i] : blob, live, s_tab, st);
     if (live) state[i] = make_uint2((uint32_t)start, (uint32_t)end);
-}
-
-// the chunks whose predecessor ended elsewhere than they assumed
-__global__ __launch_bounds__(256) void amv_adpcm_mismatch_kernel(const uint2* __restrict__ state, uint32_t n, uint32_t* __restrict__ list,
-                                                                 uint32_t* __restrict__ count) {
-    __shared__ uint32_t s_count, s_base;
-    if (threadIdx.x == 0) s_count = 0u;
+    // The first list: the chunks whose predecessor ended elsewhere than they assumed.  The predecessor is the lane before
+    // (the wave before, through LDS); a workgroup's first chunk cannot know yet and is listed whatever it assumed -- the
+    // first sweep looks before it codes.  (A kernel of its own for this was 11 us between the guess pass and the sweeps.)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 63u) s_end[wave] = (uint32_t)end;
     __syncthreads();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x + 1u;
-    const bool wrong = i < n && state[i].x != state[i - 1u].y;
-    uint32_t slot = 0;
-    if (wrong) slot = atomicAdd(&s_count, 1u);                  // one update of the global counter per workgroup
-    __syncthreads();
-    if (threadIdx.x == 0 && s_count) s_base = atomicAdd(count, s_count);
-    __syncthreads();
-    if (wrong) list[s_base + slot] = i;
+    const uint32_t left = (uint32_t)__shfl_up(end, 1);          // (by every lane: lane 1 reads lane 0's)
+    const uint32_t before = lane ? left : (wave ? s_end[wave - 1u] : ~0u);
+    const bool wrong = live && i > 0u && (uint32_t)start != before;
+    const uint64_t mask = __ballot(wrong);
+    if (mask) {
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(count, (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (wrong) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+    }
 }
 
 // One sweep over a list: a listed chunk whose predecessor's end is not the start it used is coded again from there; if
@@ -867,33 +869,40 @@ __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_map_kernel(
     }
 }
 
-// composition of the maps of kChainBlock consecutive chunks: bmap[b][s] = where start s ends up
-__global__ __launch_bounds__(128) void amv_adpcm_chain_block_kernel(const uint8_t* __restrict__ map, uint32_t n,
-                                                                    uint8_t* __restrict__ bmap, const uint32_t* __restrict__ need) {
+// Composition of the maps of kChainBlock consecutive chunks (bmap[b][s] = where start s ends up) and -- by the workgroup
+// that finishes last -- the serial walk over those (n / 256 steps through LDS): the start index of every block.
+// *done counts the workgroups that have written their map (zero when the kernel starts).
+__global__ __launch_bounds__(128) void amv_adpcm_chain_kernel(const uint8_t* __restrict__ map, uint32_t n, uint8_t* __restrict__ bmap,
+                                                              int32_t* __restrict__ bstart, uint32_t* __restrict__ done,
+                                                              const uint32_t* __restrict__ need) {
     __shared__ uint32_t s_map[kChainBlock * 24u];
+    __shared__ uint32_t s_last;
     if (need && *need == 0u) return;
-    const uint32_t c0 = blockIdx.x * kChainBlock, cnt = min(kChainBlock, n - c0);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(map + (uint64_t)c0 * 96u);
-    for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
+    const uint32_t nb = gridDim.x;
+    {
+        const uint32_t c0 = blockIdx.x * kChainBlock, cnt = min(kChainBlock, n - c0);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(map + (uint64_t)c0 * 96u);
+        for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
+        __syncthreads();
+        if (threadIdx.x < 89u) {
+            const uint8_t* m8 = reinterpret_cast<const uint8_t*>(s_map);
+            uint32_t v = threadIdx.x;
+            for (uint32_t c = 0; c < cnt; ++c) v = m8[c * 96u + v];
+            bmap[(uint64_t)blockIdx.x * 96u + threadIdx.x] = (uint8_t)v;
+        }
+    }
+    __threadfence();                                // this workgroup's map is out before it counts itself
     __syncthreads();
-    if (threadIdx.x >= 89u) return;
-    const uint8_t* m8 = reinterpret_cast<const uint8_t*>(s_map);
-    uint32_t v = threadIdx.x;
-    for (uint32_t c = 0; c < cnt; ++c) v = m8[c * 96u + v];
-    bmap[(uint64_t)blockIdx.x * 96u + threadIdx.x] = (uint8_t)v;
-}
-
-// the serial walk over the workgroup maps (n / 256 steps through LDS): start index of every block
-__global__ __launch_bounds__(128) void amv_adpcm_chain_top_kernel(const uint8_t* __restrict__ bmap, uint32_t nb,
-                                                                  int32_t* __restrict__ bstart, const uint32_t* __restrict__ need) {
-    __shared__ uint32_t s_map[kChainBlock * 24u];
-    if (need && *need == 0u) return;
+    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) + 1u == nb ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
     uint32_t v = 0;   // the encoder context starts zeroed
     for (uint32_t t0 = 0; t0 < nb; t0 += kChainBlock) {
         const uint32_t cnt = min(kChainBlock, nb - t0);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(bmap + (uint64_t)t0 * 96u);
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = peek(src + i);   // (other workgroups' stores: past this CU's L1)
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint8_t* m8 = reinterpret_cast<const uint8_t*>(s_map);
@@ -905,27 +914,43 @@ __global__ __launch_bounds__(128) void amv_adpcm_chain_top_kernel(const uint8_t*
     }
 }
 
-// back down: start index of every chunk of a block from the block's start
-__global__ __launch_bounds__(128) void amv_adpcm_chain_fill_kernel(const uint8_t* __restrict__ map, uint32_t n,
-                                                                   const int32_t* __restrict__ bstart,
-                                                                   int32_t* __restrict__ start, const uint32_t* __restrict__ need) {
-    __shared__ uint32_t s_map[kChainBlock * 24u];
-    __shared__ int32_t s_start[kChainBlock];
+// Every chunk from the start index the maps give it: a workgroup walks from its block's start through the maps of the
+// chunks before its own (one lane, <= 256 steps through LDS -- the space the cells and the staging tiles take afterwards).
+__global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_encode_mapped_kernel(
+    const int16_t* __restrict__ pcm, const uint64_t* __restrict__ pcm_offs, const uint32_t* __restrict__ nsamp, uint32_t n,
+    const uint8_t* __restrict__ map, const int32_t* __restrict__ bstart, uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs,
+    const uint32_t* __restrict__ need) {
+    constexpr uint32_t kRaw = (uint32_t)(sizeof(EncodeLds) + sizeof(StageLds) * (kEncodeBlock / 64u));
+    static_assert(kRaw >= kEncodeBlock * 96u && kChainBlock % kEncodeBlock == 0u, "a workgroup's worth of maps fits where the cells go");
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[kRaw];
+    __shared__ uint8_t s_start[kEncodeBlock];
     if (need && *need == 0u) return;
-    const uint32_t c0 = blockIdx.x * kChainBlock, cnt = min(kChainBlock, n - c0);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(map + (uint64_t)c0 * 96u);
-    for (uint32_t i = threadIdx.x; i < cnt * 24u; i += 128u) s_map[i] = src[i];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint8_t* m8 = reinterpret_cast<const uint8_t*>(s_map);
-        uint32_t v = (uint32_t)bstart[blockIdx.x];
-        for (uint32_t c = 0; c < cnt; ++c) {
-            s_start[c] = (int32_t)v;
-            v = m8[c * 96u + v];
+    const uint32_t c0 = blockIdx.x * kEncodeBlock, block = c0 / kChainBlock;
+    uint32_t v = (uint32_t)bstart[block];            // (thread 0's copy is the one that walks)
+    for (uint32_t t0 = block * kChainBlock; t0 <= c0; t0 += kEncodeBlock) {
+        const uint32_t cnt = min(kEncodeBlock, n - t0);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(map + (uint64_t)t0 * 96u);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_raw);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt * 24u; i += kEncodeBlock) dst[i] = src[i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint32_t c = 0; c < cnt; ++c) {
+                if (t0 == c0) s_start[c] = (uint8_t)v;
+                v = s_raw[c * 96u + v];
+            }
         }
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < cnt; c += 128u) start[c0 + c] = s_start[c];
+    const uint32_t i = c0 + threadIdx.x;
+    const bool live = i < n;
+    const int start = live ? (int)s_start[threadIdx.x] : 0;
+    __syncthreads();                                 // the maps have been read: their space becomes cells and staging tiles
+    EncodeLds& s_tab = *reinterpret_cast<EncodeLds*>(s_raw);
+    StageLds* s_stage = reinterpret_cast<StageLds*>(s_raw + sizeof(EncodeLds));
+    load_encode_tables(s_tab);
+    encode_chunk(live ? pcm + pcm_offs[i] : pcm, live ? nsamp[i] : 0u, start, live ? blob + offs[i] : blob, live, s_tab,
+                 s_stage[threadIdx.x >> 6]);
 }
 
 __global__ __launch_bounds__(kEncodeBlock) void amv_adpcm_encode_kernel(
@@ -1106,18 +1131,22 @@ void launch_adpcm_wav_encode(const int16_t* samples, int groups, int32_t* state,
 }
 
 void launch_adpcm_map(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,
-                      uint8_t* map, int32_t* start, const uint32_t* need, hipStream_t s) {
-    // map: (n + nb) * 96 bytes, start: n + nb words, nb = adpcm_chain_blocks(n)
+                      uint8_t* map, int32_t* bstart, uint32_t* done, const uint32_t* need, hipStream_t s) {
+    // map: (n + nb) * 96 bytes, bstart: nb words, nb = adpcm_chain_blocks(n); *done == 0
     if (n == 0) return;
     const uint32_t nb = adpcm_chain_blocks(n);
     uint8_t* bmap = map + (uint64_t)n * 96u;
-    int32_t* bstart = start + n;
     const uint64_t groups = ((uint64_t)n * 89u + kEncodeBlock - 1u) / kEncodeBlock;
     hipLaunchKernelGGL(amv_adpcm_map_kernel, dim3((uint32_t)(groups < 4096u ? groups : 4096u)), dim3(kEncodeBlock), 0, s, pcm, pcm_offs,
                        nsamp, n, map, need);
-    hipLaunchKernelGGL(amv_adpcm_chain_block_kernel, dim3(nb), dim3(128), 0, s, map, n, bmap, need);
-    hipLaunchKernelGGL(amv_adpcm_chain_top_kernel, dim3(1), dim3(128), 0, s, bmap, nb, bstart, need);
-    hipLaunchKernelGGL(amv_adpcm_chain_fill_kernel, dim3(nb), dim3(128), 0, s, map, n, bstart, start, need);
+    hipLaunchKernelGGL(amv_adpcm_chain_kernel, dim3(nb), dim3(128), 0, s, map, n, bmap, bstart, done, need);
+}
+
+void launch_adpcm_encode_mapped(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, const uint8_t* map,
+                                const int32_t* bstart, uint8_t* blob, const uint64_t* offs, const uint32_t* need, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(amv_adpcm_encode_mapped_kernel, dim3((n + kEncodeBlock - 1u) / kEncodeBlock), dim3(kEncodeBlock), 0, s, pcm,
+                       pcm_offs, nsamp, n, map, bstart, blob, offs, need);
 }
 
 uint32_t adpcm_chain_blocks(uint32_t n) { return (n + kChainBlock - 1u) / kChainBlock; }
@@ -1144,13 +1173,12 @@ const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs,
                                    const uint64_t* offs, void* work, uint32_t sweeps, hipStream_t s) {
     uint2* state = static_cast<uint2*>(work);
     uint32_t* list[2] = {reinterpret_cast<uint32_t*>(state + n), reinterpret_cast<uint32_t*>(state + n) + n};
-    uint32_t* count = list[1] + n;                   // [0 .. sweeps + 1]: one per list generation; [63]: the flag
+    uint32_t* count = list[1] + n;                   // [0 .. sweeps + 2]: one per list generation; [62]: launch_adpcm_map's `done`; [63]: the flag
     if (sweeps > 59u) sweeps = 59u;
     if (hipMemsetAsync(count, 0, chain_zeroed_bytes(n), s) != hipSuccess) return nullptr;   // (the caller reports it: nothing has been queued)
     hipLaunchKernelGGL(amv_adpcm_guess_kernel, dim3((n + kEncodeBlock - 1u) / kEncodeBlock), dim3(kEncodeBlock), 0, s, pcm, pcm_offs, nsamp, n,
-                       blob, offs, state);
+                       blob, offs, state, list[0], count);
     if (n > 1u) {
-        hipLaunchKernelGGL(amv_adpcm_mismatch_kernel, dim3((n + 254u) / 256u), dim3(256), 0, s, state, n, list[0], count);
         // sweep k's list is a fraction of the one before; the grid is sized for the first and strides if it must
         uint32_t grid = (n + kEncodeBlock - 1u) / kEncodeBlock;
         for (uint32_t k = 0; k < sweeps; ++k) {

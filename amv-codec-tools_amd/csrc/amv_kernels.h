@@ -141,15 +141,19 @@ void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_
                          int32_t* final_state, hipStream_t s);
 // The reference's step_index carry (adpcm.c:461-498) without a serial pass over the stream.  launch_adpcm_chain: every
 // chunk coded from a guessed start, then `sweeps` launches + one settling workgroup that code again what started wrong;
-// returns the device word that is 1 when the stream did not settle.  launch_adpcm_map (89-way state map of every chunk +
-// composition of the maps -> start[i]) and launch_adpcm_encode leave at once when *need == 0 (need == nullptr: run).
+// returns the device word that is 1 when the stream did not settle (the word before it is a zeroed counter for
+// launch_adpcm_map's `done`).  launch_adpcm_map (89-way state map of every chunk + composition of the maps -> the start of
+// every block of 256 chunks) and launch_adpcm_encode_mapped (every chunk coded from the start the maps give it) leave at once
+// when *need == 0 (need == nullptr: run).
 uint64_t adpcm_chain_workspace(uint32_t n);
 const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, uint8_t* blob,
                                    const uint64_t* offs, void* work, uint32_t sweeps, hipStream_t s);
 void adpcm_quotient_table(float out[89]);   // the encoder's quotient factors (see amv_adpcm.hip: compress)
-uint32_t adpcm_chain_blocks(uint32_t n);   // launch_adpcm_map needs map[(n + blocks) * 96] and start[n + blocks]
+uint32_t adpcm_chain_blocks(uint32_t n);   // launch_adpcm_map needs map[(n + blocks) * 96] and bstart[blocks]
 void launch_adpcm_map(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,
-                      uint8_t* map, int32_t* start, const uint32_t* need, hipStream_t s);
+                      uint8_t* map, int32_t* bstart, uint32_t* done, const uint32_t* need, hipStream_t s);
+void launch_adpcm_encode_mapped(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, const uint8_t* map,
+                                const int32_t* bstart, uint8_t* blob, const uint64_t* offs, const uint32_t* need, hipStream_t s);
 // amvlib's IMA-WAV-layout frame encoder (AdpcmIma.c:43-160), one lane
 void launch_adpcm_wav_encode(const int16_t* samples, int groups, int32_t* state, uint8_t* frame, hipStream_t s);
 void launch_adpcm_encode(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp,

@@ -974,9 +974,10 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
     Timed t(c, AMVHIP_K_ADPCM_ENC, (hipStream_t)stream);
     const uint32_t* need = nullptr;
     if (!d_step_in) {  // the reference's behaviour: step_index runs through the whole stream
-        const size_t slots = (size_t)n + adpcm_chain_blocks(n);
-        if (int r = ensure(c, c->map, slots * 96)) return r;
-        if (int r = ensure(c, c->start, slots * 4)) return r;
+        const size_t nb = adpcm_chain_blocks(n);
+        if (int r = ensure(c, c->map, ((size_t)n + nb) * 96)) return r;
+        if (int r = ensure(c, c->start, (nb + 1) * 4)) return r;    // the blocks' starts + a counter for the exhaustive route alone
+        uint32_t* done = (uint32_t*)c->start.p + nb;
         if (c->adpcm_sweeps >= 0) {   // guessed starts + sweeps; the exhaustive route behind it runs only if they do not settle
             if (int r = ensure(c, c->chain, adpcm_chain_workspace(n))) return r;
             uint32_t sweeps = (uint32_t)c->adpcm_sweeps;
@@ -993,11 +994,16 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
             // must be ordered on the device -- one stream at a time, as for every _dev entry point; see amvhip.h)
             need = launch_adpcm_chain(d_pcm, d_pcm_offs, d_nsamp, n, d_blob, d_offs, c->chain.p, sweeps, (hipStream_t)stream);
             if (!need) return fail(c, AMVHIP_ERR_DEVICE, "adpcm_encode: clearing the chain counters failed");
+            done = const_cast<uint32_t*>(need) - 1;   // zeroed with the flag
+        } else {
+            HIP_TRY(c, hipMemsetAsync(done, 0, 4, (hipStream_t)stream));
         }
-        launch_adpcm_map(d_pcm, d_pcm_offs, d_nsamp, n, (uint8_t*)c->map.p, (int32_t*)c->start.p, need, (hipStream_t)stream);
-        d_step_in = (const int32_t*)c->start.p;
+        launch_adpcm_map(d_pcm, d_pcm_offs, d_nsamp, n, (uint8_t*)c->map.p, (int32_t*)c->start.p, done, need, (hipStream_t)stream);
+        launch_adpcm_encode_mapped(d_pcm, d_pcm_offs, d_nsamp, n, (const uint8_t*)c->map.p, (const int32_t*)c->start.p, d_blob, d_offs, need,
+                                   (hipStream_t)stream);
+        return check_launch(c, "adpcm_encode");
     }
-    launch_adpcm_encode(d_pcm, d_pcm_offs, d_nsamp, n, d_step_in, d_blob, d_offs, need, (hipStream_t)stream);
+    launch_adpcm_encode(d_pcm, d_pcm_offs, d_nsamp, n, d_step_in, d_blob, d_offs, nullptr, (hipStream_t)stream);
     return check_launch(c, "adpcm_encode");
 }
 
