@@ -570,10 +570,29 @@ def make_audio(E, first_chunk, n):
 
 
 def audio_gate(E, A, n):
-    """encode on the device == oracle's encoder (index carried), decode on the device == oracle's decoder"""
+    """encode on the device == oracle's encoder (index carried) on the first chunks, and EVERY chunk == a second encode through
+    the exhaustive 89-start route (other kernels, nothing guessed; device compare); decode on the device == oracle's decoder"""
     d_pcm, d_pcm_offs, d_nsamp, d_chunks, d_offs, d_lens, clen = A
     orc = entry.load_oracle()
     spf = SAMPLES_PER_FRAME
+    old = os.environ.get("AMVHIP_ADPCM_SWEEPS")
+    os.environ["AMVHIP_ADPCM_SWEEPS"] = "map"          # (read when a context is made)
+    try:
+        ref = E.pkg.Context(E.dev.index)
+    finally:
+        if old is None:
+            os.environ.pop("AMVHIP_ADPCM_SWEEPS", None)
+        else:
+            os.environ["AMVHIP_ADPCM_SWEEPS"] = old
+    try:
+        d_want = torch.zeros_like(d_chunks)
+        ref.adpcm_encode_batch_dev(d_pcm, d_pcm_offs, d_nsamp, n, None, d_want, d_offs, E.stream)
+        torch.cuda.synchronize()
+        if not torch.equal(d_want[: n * clen], d_chunks[: n * clen]):
+            raise SystemExit("HIP ADPCM encode: the chained route and the exhaustive route differ")
+        del d_want
+    finally:
+        ref.close()
     m = min(n, 64)
     pcm = d_pcm[: m * spf].cpu().numpy()
     got = d_chunks[: m * clen].cpu().numpy()

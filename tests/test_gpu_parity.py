@@ -1533,6 +1533,54 @@ def test_adpcm_index_chain_many_streams(ctx, orc):
             assert blob.tobytes() == want, (it, rep, n, ctx.adpcm_chain_stats())
 
 
+def test_adpcm_full_size_chain_against_exhaustive_route(pkg, orc):
+    """bench.py's ADPCM workload at full size (200 000 chunks of 1 378 samples, index carried through all of them): the chain
+    of guessed starts, sweeps, front sweep and settling rounds writes the bytes the exhaustive 89-start route writes (other
+    kernels, no guessing), every start index in the headers continues its predecessor's decode-side end index, the first 300
+    chunks are the oracle's sequential encode, and decoding returns PCM of the right length for every chunk."""
+    import torch
+    dev = "cuda:0"
+    n, spf = 200000, 1378
+    clen = 8 + spf // 2
+    s = torch.cuda.current_stream().cuda_stream
+    ctx = pkg.Context(0)
+    ref = _with_env(pkg, "AMVHIP_ADPCM_SWEEPS", "map")
+    try:
+        pcm = torch.empty(n * spf, dtype=torch.int16, device=dev)
+        ctx.synth_audio_dev(SEED, 0, n * spf, pcm, s)
+        pcm_offs = torch.arange(n, dtype=torch.int64, device=dev) * spf
+        nsamp = torch.full((n,), spf, dtype=torch.int32, device=dev)
+        offs = torch.arange(n, dtype=torch.int64, device=dev) * clen
+        got = torch.full((n * clen + 16,), 0xEE, dtype=torch.uint8, device=dev)
+        want = torch.full((n * clen + 16,), 0xDD, dtype=torch.uint8, device=dev)
+        for rep in range(3):
+            got[: n * clen] = 0xEE
+            ctx.adpcm_encode_batch_dev(pcm, pcm_offs, nsamp, n, None, got, offs, s)
+            if rep == 0:
+                ref.adpcm_encode_batch_dev(pcm, pcm_offs, nsamp, n, None, want, offs, s)
+            torch.cuda.synchronize()
+            assert torch.equal(got[: n * clen], want[: n * clen]), rep
+        st = ctx.adpcm_chain_stats()
+        assert not st["exhaustive"] and len(st["recoded"]) >= 4, st
+        # the chain as the headers state it: chunk i + 1 starts where decoding chunk i leaves the step index
+        lens = torch.full((n,), clen, dtype=torch.int32, device=dev)
+        back = torch.zeros(n * spf + 8, dtype=torch.int16, device=dev)
+        fin = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        ctx.adpcm_decode_batch_dev(got, n * clen, offs, lens, n, back, pcm_offs, fin, s)
+        torch.cuda.synchronize()
+        heads = got[: n * clen].view(n, clen)
+        assert int(heads[0, 2]) == 0 and torch.equal(heads[1:, 2].to(torch.int32), fin[:-1, 1])
+        assert len(torch.unique(heads[:, 2])) > 20
+        h_pcm, h_got = pcm[: 300 * spf].cpu().numpy(), got[: 300 * clen].cpu().numpy()
+        idx = 0
+        for i in range(300):
+            chunk, idx = orc.adpcm_encode_chunk(h_pcm[i * spf:(i + 1) * spf], idx)
+            assert h_got[i * clen:(i + 1) * clen].tobytes() == chunk, i
+    finally:
+        ctx.close()
+        ref.close()
+
+
 def test_encode_frame_kernel_paths(ctx, pkg, orc):
     """amv_encode_frame_kernel's less travelled paths, every chunk against the oracle's encoder: runs of symbols that
     overflow a lane's scratch and are coded a second time straight into the round's bit string (a few noisy blocks in a
