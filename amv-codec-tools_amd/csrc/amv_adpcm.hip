@@ -849,6 +849,15 @@ __global__ __launch_bounds__(256) void amv_adpcm_settle_kernel(
     }
 }
 
+// The chain's own check, behind the last round: every chunk's bytes were coded from the start its state names (states are
+// replaced whole), so the stream is the sequential encoder's if and only if every chunk's start is its predecessor's end.
+// A chunk for which that does not hold -- none, unless the list handling above has a hole -- sends the stream down the
+// exhaustive route instead of out of the door.
+__global__ __launch_bounds__(256) void amv_adpcm_check_kernel(const uint2* __restrict__ state, uint32_t n, uint32_t* __restrict__ need_map) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x + 1u;
+    if (i < n && state[i].x != state[i - 1u].y) *need_map = 1u;
+}
+
 // ---- the exhaustive route (queued behind the other; every kernel of it leaves at once unless *need says otherwise) ---
 // state-only run of chunk i from start index s: where does step_index end up?  One lane per
 // (chunk, start) pair, pairs packed densely into waves.
@@ -1170,7 +1179,7 @@ static uint64_t chain_zeroed_bytes(uint32_t n) { return 256u + (((uint64_t)n + 3
 uint64_t adpcm_chain_workspace(uint32_t n) { return (uint64_t)n * 16u + chain_zeroed_bytes(n); }
 
 const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, uint8_t* blob,
-                                   const uint64_t* offs, void* work, uint32_t sweeps, hipStream_t s) {
+                                   const uint64_t* offs, void* work, uint32_t sweeps, bool settle, hipStream_t s) {
     uint2* state = static_cast<uint2*>(work);
     uint32_t* list[2] = {reinterpret_cast<uint32_t*>(state + n), reinterpret_cast<uint32_t*>(state + n) + n};
     uint32_t* count = list[1] + n;                   // [0 .. sweeps + 2]: one per list generation; [62]: launch_adpcm_map's `done`; [63]: the flag
@@ -1187,10 +1196,15 @@ const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs,
             grid = grid > 256u ? (grid + 1u) / 2u : grid;
         }
         // one sweep that looks four chunks ahead of every head (a plain sweep while the list is still long), then the rest
-        hipLaunchKernelGGL(amv_adpcm_front_kernel, dim3(kFrontMost), dim3(kFrontThreads), 0, s, pcm, pcm_offs, nsamp, n, blob, offs, state,
-                           list[sweeps & 1u], count + sweeps, list[(sweeps + 1u) & 1u], count + sweeps + 1u, count + 64, count + 63);
-        hipLaunchKernelGGL(amv_adpcm_settle_kernel, dim3(1), dim3(256), 0, s, pcm, pcm_offs, nsamp, n, blob, offs, state,
-                           list[(sweeps + 1u) & 1u], count + sweeps + 1u, list[sweeps & 1u], count + sweeps + 2u, count + 63);
+        if (settle) {
+            hipLaunchKernelGGL(amv_adpcm_front_kernel, dim3(kFrontMost), dim3(kFrontThreads), 0, s, pcm, pcm_offs, nsamp, n, blob, offs,
+                               state, list[sweeps & 1u], count + sweeps, list[(sweeps + 1u) & 1u], count + sweeps + 1u, count + 64,
+                               count + 63);
+            hipLaunchKernelGGL(amv_adpcm_settle_kernel, dim3(1), dim3(256), 0, s, pcm, pcm_offs, nsamp, n, blob, offs, state,
+                               list[(sweeps + 1u) & 1u], count + sweeps + 1u, list[sweeps & 1u], count + sweeps + 2u, count + 63);
+        }
+        // (settle == false: a test knob -- the chain is left where its launched sweeps got it, and the check has to notice)
+        hipLaunchKernelGGL(amv_adpcm_check_kernel, dim3((n + 254u) / 256u), dim3(256), 0, s, state, n, count + 63);
     }
     return count + 63;
 }

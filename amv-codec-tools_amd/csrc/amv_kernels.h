@@ -147,7 +147,7 @@ void launch_adpcm_decode(const uint8_t* blob, uint64_t blob_bytes, const uint64_
 // when *need == 0 (need == nullptr: run).
 uint64_t adpcm_chain_workspace(uint32_t n);
 const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n, uint8_t* blob,
-                                   const uint64_t* offs, void* work, uint32_t sweeps, hipStream_t s);
+                                   const uint64_t* offs, void* work, uint32_t sweeps, bool settle, hipStream_t s);
 void adpcm_quotient_table(float out[89]);   // the encoder's quotient factors (see amv_adpcm.hip: compress)
 uint32_t adpcm_chain_blocks(uint32_t n);   // launch_adpcm_map needs map[(n + blocks) * 96] and bstart[blocks]
 void launch_adpcm_map(const int16_t* pcm, const uint64_t* pcm_offs, const uint32_t* nsamp, uint32_t n,

@@ -55,6 +55,7 @@ struct amvhip_ctx {
     int entropy_mode = AMVHIP_ENTROPY_AUTO;
     int adpcm_sweeps = 0;            // AMVHIP_ADPCM_SWEEPS: sweeps of the guessed-start route (-1: exhaustive route only)
     bool adpcm_sweeps_set = false;   // false: by stream length
+    bool adpcm_settle = true;        // "nosettle": the chain stops after its launched sweeps (test knob: its check must notice)
     uint32_t chain_n = 0;            // chunks of the last chained ADPCM encode (where its counters are in `chain`)
     // host-pointer staging (one in-order stream of the context's own carries every host-buffer entry point)
     DevBuf h_in, h_offs, h_lens, h_out, h_status, h_aux, a_in, a_tab, a_out;
@@ -279,8 +280,12 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->sync_lanes = v;
     }
     if (const char* e = getenv("AMVHIP_ADPCM_SWEEPS")) {   // tuning / test knob: "map" = exhaustive route only, or a sweep count
-        c->adpcm_sweeps_set = true;
-        c->adpcm_sweeps = strcmp(e, "map") == 0 ? -1 : (atoi(e) < 0 ? 0 : (atoi(e) > 60 ? 60 : atoi(e)));
+        if (strcmp(e, "nosettle") == 0) {
+            c->adpcm_settle = false;   // sweeps by stream length, then nothing: the chain's check sends the stream down the exhaustive route
+        } else {
+            c->adpcm_sweeps_set = true;
+            c->adpcm_sweeps = strcmp(e, "map") == 0 ? -1 : (atoi(e) < 0 ? 0 : (atoi(e) > 60 ? 60 : atoi(e)));
+        }
     }
     if (hipMalloc((void**)&c->d_dec, sizeof dec) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
     if (hipMalloc((void**)&c->d_enc, sizeof enc) != hipSuccess) return die(AMVHIP_ERR_NOMEM);
@@ -992,7 +997,7 @@ extern "C" int amvhip_adpcm_encode_batch_dev(amvhip_ctx* c, const int16_t* d_pcm
             c->chain_n = n;
             // (state, lists, counters and the flag live in the context's `chain` buffer: chained encodes of ONE context
             // must be ordered on the device -- one stream at a time, as for every _dev entry point; see amvhip.h)
-            need = launch_adpcm_chain(d_pcm, d_pcm_offs, d_nsamp, n, d_blob, d_offs, c->chain.p, sweeps, (hipStream_t)stream);
+            need = launch_adpcm_chain(d_pcm, d_pcm_offs, d_nsamp, n, d_blob, d_offs, c->chain.p, sweeps, c->adpcm_settle, (hipStream_t)stream);
             if (!need) return fail(c, AMVHIP_ERR_DEVICE, "adpcm_encode: clearing the chain counters failed");
             done = const_cast<uint32_t*>(need) - 1;   // zeroed with the flag
         } else {

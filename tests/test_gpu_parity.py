@@ -1479,8 +1479,8 @@ def test_adpcm_index_chain_routes(pkg, orc):
         if kind == "walk":
             assert 15 <= min(starts[8:]) and max(starts) <= 70 and len(set(starts)) > 20, (min(starts[8:]), max(starts))
         cases.append((sizes, pcm, pcm_offs, offs, b"".join(want), len(set(starts))))
-    seen_exhaustive = seen_settled = 0
-    for knob in (None, "0", "3", "map"):
+    seen_exhaustive = seen_settled = seen_unsettled = 0
+    for knob in (None, "0", "3", "map", "nosettle"):
         ctx = pkg.Context(0) if knob is None else _with_env(pkg, "AMVHIP_ADPCM_SWEEPS", knob)
         try:
             for k, (sizes, pcm, pcm_offs, offs, want, _) in enumerate(cases):
@@ -1489,7 +1489,14 @@ def test_adpcm_index_chain_routes(pkg, orc):
                 ctx.adpcm_encode_batch(pcm, pcm.size, pcm_offs[:-1].copy(), np.array(sizes, np.uint32), n, None, blob, blob.size,
                                        offs[:-1].copy())
                 assert blob.tobytes() == want, (knob, k)
-                if knob != "map":
+                if knob == "nosettle":
+                    # the chain stopped after its launched sweeps: its own check (every chunk's start == its predecessor's
+                    # end) must have noticed wherever something was left, and the exhaustive route have written the bytes
+                    st = ctx.adpcm_chain_stats()
+                    if k in (0, 1):
+                        assert st["exhaustive"], (knob, k, st)
+                        seen_unsettled += 1
+                elif knob != "map":
                     st = ctx.adpcm_chain_stats()
                     if k == 1:
                         assert st["exhaustive"], (knob, st)                  # 1 500 dependent chunks: no sweep count settles them
@@ -1502,7 +1509,7 @@ def test_adpcm_index_chain_routes(pkg, orc):
                         assert not st["exhaustive"], (knob, k, st)
         finally:
             ctx.close()
-    assert seen_exhaustive == 3 and seen_settled == 1
+    assert seen_exhaustive == 3 and seen_settled == 1 and seen_unsettled == 2
 
 
 def test_adpcm_index_chain_many_streams(ctx, orc):
