@@ -619,7 +619,7 @@ __device__ __forceinline__ int encode_chunk_alone(const int16_t* __restrict__ x,
 }
 
 constexpr uint32_t kGuessTail = 128;    // samples of the chunk before that the guess is run over
-constexpr uint32_t kSettleMost = 1024;  // entries the one-workgroup kernel takes on
+constexpr uint32_t kSettleMost = 2048;  // entries the one-workgroup kernel takes on (the front sweep may leave five per head)
 constexpr uint32_t kSettleRounds = 48;
 
 // every chunk from a guessed start; state[i] = {start used, end reached}
