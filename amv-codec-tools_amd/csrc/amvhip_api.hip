@@ -1346,7 +1346,7 @@ extern "C" const char* amvhip_kernel_name(int kernel) {
         case AMVHIP_K_PACK_SERIAL: return "amv_pack_kernel";
         case AMVHIP_K_COMPACT: return "amv_scan_kernel+amv_gather_kernel";
         case AMVHIP_K_ADPCM_DEC: return "amv_adpcm_decode_kernel";
-        case AMVHIP_K_ADPCM_ENC: return "amv_adpcm_guess_kernel+amv_adpcm_sweep_kernel*+settle (+map, chain_*, encode when the chain does not settle)";
+        case AMVHIP_K_ADPCM_ENC: return "amv_adpcm_guess_kernel+amv_adpcm_sweep_kernel*+front+settle+check (+map, chain, encode_mapped when the chain does not settle)";
         case AMVHIP_K_SYNTH: return "amv_synth_frames_kernel";
         default: return "";
     }
