@@ -52,10 +52,12 @@ SAMPLES_PER_FRAME = 1378  # 22050 Hz mono at 16 fps: the audio chunk that travel
 # 10 000 frames of 160x120 are 2 500 waves of the entropy kernel (10 per CU) and the step then lasts as long
 # as one wave's serial chain; DESIGN.md section 9 has the sweep (`--frames 10000` gives the 10 000-frame figure).
 DECODE_FRAMES = 160000
+# what the strong-scaling leg (a few seconds of work) gets before the line leaves without it
+STRONG_LEG_SECONDS = float(os.environ.get("AMV_BENCH_STRONG_SECONDS", "240"))
 
 
 class Env:
-    pass
+    json_fd = None
 
 
 def make_video_stream(E, first, n, w, h, noise_every=0):
@@ -372,7 +374,26 @@ def run_decode(E, args):
     if E.dist:          # config 4 as BASELINE.json states it, beside the weak-scaling line above
         result["config"]["scaling_modes"] = {"weak": "value / ms_per_step of this line: every GPU decodes its own %d frames" % n,
                                              "strong": "config4_strong_10k"}
-        strong = run_strong(E, args, w, h)
+        # The exchange has never met more than one GPU (§10): the weak line above must not be lost to it.  An error it raises
+        # on its own (not the gate's verdict, which stops the run) is recorded in its place; if it hangs -- a send nobody
+        # receives -- every rank's watchdog writes the line as it stands and leaves.
+        import threading
+        done = threading.Event()
+
+        def bail():
+            if done.wait(STRONG_LEG_SECONDS):
+                return
+            result["config"]["config4_strong_10k"] = {"skipped": "no end after %g s: left alone" % STRONG_LEG_SECONDS}
+            if E.rank == 0 and E.json_fd is not None:
+                os.write(E.json_fd, (json.dumps(result) + "\n").encode())
+            os._exit(0)
+
+        threading.Thread(target=bail, daemon=True).start()
+        try:
+            strong = run_strong(E, args, w, h)
+        except Exception as e:                       # (SystemExit -- the gate -- is not an Exception)
+            strong = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:400])}
+        done.set()
         result["config"]["config4_strong_10k"] = strong
 
     if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
@@ -910,6 +931,7 @@ def main():
     # descriptor 1 points at stderr for the length of the run and the line goes out through the saved descriptor
     sys.stdout.flush()
     json_fd = os.dup(1)
+    E.json_fd = json_fd
     os.dup2(2, 1)
     E.dist = E.world > 1 or args.strong
     if not torch.cuda.is_available():
