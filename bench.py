@@ -170,6 +170,24 @@ def profiled_path_traffic(tag, names, min_bytes=1e8):
     return total or None
 
 
+def profiled_adpcm_traffic(dom):
+    """the ADPCM workload's kernels in the same kind of passes (profiles/<round>_traffic_adpcm.json): the decode kernel's
+    bytes per launch, or -- the chained encode is a dozen launches -- the sum over the chain's kernels, every launch of a step"""
+    path = os.path.join(ROOT, "profiles", "%s_traffic_adpcm.json" % TRAFFIC_ROUND)
+    try:
+        prof = json.load(open(path))
+        rows = {k: v for k, v in prof["kernels"].items() if "adpcm" in k}
+        if dom.startswith("amv_adpcm_decode"):
+            total = max(v["hbm_corrected"] for k, v in rows.items() if "adpcm_decode" in k)
+        else:
+            total = sum(v["hbm_corrected"] * v.get("launches_per_step", 1) for k, v in rows.items() if "adpcm_decode" not in k)
+        return total, {"file": os.path.relpath(path, ROOT), "head": prof.get("head", ""),
+                       "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + WRITE_SIZE, separate passes; "
+                                 "one row per kernel and grid size, summed over the chain's kernels"}
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def cpu_share():
     """what this process may use of the host: the CPUs of its affinity mask (what `nproc` prints) and the CPU quota of its
     cgroup (cpu.max = "quota period": a one-GPU box of this pool sees all 256 host CPUs and is given 16 CPUs' worth of
@@ -696,7 +714,7 @@ def run_adpcm(E, args, with_video=False):
         result["config"] = {"workload": "%d AMV audio chunks of %d samples per GPU: PCM -> ADPCM (step index carried through "
                                         "the stream, as the reference encoder does) -> PCM" % (na, spf),
                             "chunks_per_gpu": na, "parallelism": "chunk-range x%d" % E.world}
-        result["roofline"] = roofline(kern, audio_bytes, elapsed / args.steps, None)
+        result["roofline"] = roofline(kern, audio_bytes, elapsed / args.steps, profiled_adpcm_traffic if na == 200000 else None)
 
     if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline and not with_video:
         m = min(na, 4096)
