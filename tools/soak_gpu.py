@@ -24,7 +24,7 @@ from conftest import SEED  # noqa: E402
 
 def soak_adpcm(pkg, orc, lo, hi):
     ctx = pkg.Context(0)
-    bad = 0
+    bad = repaired = 0
     for seed in range(lo, hi):
         rng = np.random.default_rng(seed)
         n = int(rng.integers(200, 6000))
@@ -44,12 +44,16 @@ def soak_adpcm(pkg, orc, lo, hi):
         for rep in range(3):
             blob = np.full(int(offs[-1]), 0xEE, np.uint8)
             ctx.adpcm_encode_batch(pcm, pcm.size, pcm_offs[:-1].copy(), np.array(sizes, np.uint32), n, None, blob, blob.size, offs[:-1].copy())
+            if ctx.adpcm_chain_stats()["exhaustive"]:      # the chain's check (or its settle kernel) sent the stream down the slow route
+                repaired += 1
+                print("exhaustive route taken: adpcm seed", seed, "rep", rep, "chunks", n, ctx.adpcm_chain_stats(), flush=True)
             if blob.tobytes() != want:
                 bad += 1
                 d = np.nonzero(blob != np.frombuffer(want, np.uint8))[0]
                 ch = int(np.searchsorted(offs, d[0], side="right") - 1)
                 print("MISMATCH adpcm seed", seed, "rep", rep, "chunks", n, "bytes", d.size, "first in chunk", ch, "at", int(d[0] - offs[ch]),
                       ctx.adpcm_chain_stats(), flush=True)
+    print("adpcm: streams that took the exhaustive route (none expected on ordinary audio):", repaired)
     return bad
 
 
