@@ -24,15 +24,27 @@ SURVEY_FNV_SEED = 1469598103934665603
 _vp, _u32, _u64, _int = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
 
 
+def _stale(target, sources):
+    return not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(os.path.join(HERE, f)) for f in sources)
+
+
 def build(force=False):
-    """make -C oracle (the restatement always; _ref only where /root/reference exists)"""
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(
-            os.path.getmtime(os.path.join(HERE, f)) for f in ("amv_oracle.c", "amv_oracle.h", "Makefile")):
-        subprocess.run(["make", "-C", HERE, "-s", "libamvoracle.so"], check=True)
-    if os.path.isdir("/root/reference") and (force or not os.path.exists(REF) or not os.path.exists(AVCREF)
-                                             or os.path.getmtime(AVCREF) < max(os.path.getmtime(os.path.join(HERE, f))
-                                                                               for f in ("ref_harness.c", "ref_harness_imgconvert.c", "Makefile"))):
-        subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
+    """make -C oracle (the restatement always; _ref only where /root/reference exists).  Several processes may come here
+    at once (the ranks of a multi-GPU bench run each load the checker): the make runs under a file lock, and whoever
+    waited for it looks again before running it a second time."""
+    import fcntl
+    want_lib = force or _stale(LIB, ("amv_oracle.c", "amv_oracle.h", "Makefile"))
+    want_ref = os.path.isdir("/root/reference") and (force or not os.path.exists(REF) or
+                                                     _stale(AVCREF, ("ref_harness.c", "ref_harness_imgconvert.c", "Makefile")))
+    if not (want_lib or want_ref):
+        return
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or _stale(LIB, ("amv_oracle.c", "amv_oracle.h", "Makefile")):
+            subprocess.run(["make", "-C", HERE, "-s", "libamvoracle.so"], check=True)
+        if os.path.isdir("/root/reference") and (force or not os.path.exists(REF) or
+                                                 _stale(AVCREF, ("ref_harness.c", "ref_harness_imgconvert.c", "Makefile"))):
+            subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
 
 
 _lib = None
