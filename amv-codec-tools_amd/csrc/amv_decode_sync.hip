@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void amv_unstuff_kernel(
     if ((uint64_t)len > blob_bytes - off) len = (uint32_t)(blob_bytes - off);
     const uint32_t line0 = ws_line[frame];                 // the frame's window: 16-byte pieces ws_line[frame] .. ws_line[frame + 1]
     uint32_t* const out = ws + (uint64_t)line0 * 4u;
-    const uint32_t cap_bytes = (ws_line[frame + 1u] - line0) * 16u;
+    const uint32_t line1 = ws_line[frame + 1u];
+    // (the layout is monotone; a window that ends before it starts is still read as empty: the frame goes to the retry
+    // list and nothing is written)
+    const uint64_t cap_bytes = line1 > line0 ? (uint64_t)(line1 - line0) * 16u : 0u;
 
     const uint32_t mis = (uint32_t)(off & 3u);
     const uint8_t* base = blob + (off - mis);
@@ -973,7 +976,8 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
         const uint32_t fsafe = live ? frame : 0u;
         const uint32_t line0 = out.rec_line[fsafe];
         uint32_t* const rec = out.rec + (uint64_t)line0 * 32u;
-        const uint32_t cap_rec = (out.rec_line[fsafe + 1u] - line0) * 32u;   // this frame's record space, a multiple of 32
+        const uint32_t line1 = out.rec_line[fsafe + 1u];
+        const uint32_t cap_rec = line1 > line0 ? (line1 - line0) * 32u : 0u;   // this frame's record space, a multiple of 32 (monotone layout; read defensively)
         uint2* const seg_out = reinterpret_cast<uint2*>(out.seg_start) + (uint64_t)fsafe * (sg.count + 1u);
         const uint32_t valid_bits = live ? total * 8u : 0u;
         Stream win{ws + (uint64_t)ws_line[fsafe] * 4u, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
@@ -1139,7 +1143,8 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
         const uint32_t fsafe = live ? frame : 0u;
         const uint32_t line0 = out.rec_line[fsafe];
         uint32_t* const rec = out.rec + (uint64_t)line0 * 32u;
-        const uint32_t cap_rec = (out.rec_line[fsafe + 1u] - line0) * 32u;   // this frame's record space, a multiple of 32
+        const uint32_t line1 = out.rec_line[fsafe + 1u];
+        const uint32_t cap_rec = line1 > line0 ? (line1 - line0) * 32u : 0u;   // this frame's record space, a multiple of 32 (monotone layout; read defensively)
         uint2* const seg_out = reinterpret_cast<uint2*>(out.seg_start) + (uint64_t)fsafe * (sg.count + 1u);
         const uint32_t valid_bits = live ? total * 8u : 0u;
         Stream win{ws + (uint64_t)ws_line[fsafe] * 4u, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
@@ -1481,36 +1486,40 @@ __device__ __forceinline__ uint32_t layout_lines(uint32_t len, const LayoutSpec&
     return (uint32_t)((min(want, (uint64_t)sp.hi) + ((1u << sp.unit_shift) - 1u)) >> sp.unit_shift);
 }
 
-// exclusive scan of two values over the workgroup's 256 threads; returns the workgroup's totals in tot
-__device__ __forceinline__ uint2 block_scan2(uint2 v, uint2* s_wave, uint2& tot) {
+// exclusive scan of two values over the workgroup's 256 threads; returns the workgroup's totals in tot.  The sums are
+// 64 bits wide: a frame may claim up to 0x0fffffff pieces (a chunk length is whatever the caller wrote there), and 17 of
+// those in one workgroup would wrap a 32-bit prefix -- a frame's window would then START BELOW its predecessor's.
+struct Sum2 { uint64_t x, y; };
+__device__ __forceinline__ Sum2 block_scan2(uint2 v, Sum2* s_wave, Sum2& tot) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 inc = v;
+    Sum2 inc{v.x, v.y};
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t ax = (uint32_t)__shfl_up((int)inc.x, d), ay = (uint32_t)__shfl_up((int)inc.y, d);
+        const uint64_t ax = (uint64_t)__shfl_up((unsigned long long)inc.x, d), ay = (uint64_t)__shfl_up((unsigned long long)inc.y, d);
         if (lane >= (uint32_t)d) { inc.x += ax; inc.y += ay; }
     }
     if (lane == 63u) s_wave[wave] = inc;
     __syncthreads();
-    uint2 base = make_uint2(0u, 0u);
-    tot = make_uint2(0u, 0u);
+    Sum2 base{0u, 0u};
+    tot = Sum2{0u, 0u};
     for (uint32_t k = 0; k < kLayoutBlock / 64u; ++k) {
-        const uint2 w = s_wave[k];
+        const Sum2 w = s_wave[k];
         if (k < wave) { base.x += w.x; base.y += w.y; }
         tot.x += w.x; tot.y += w.y;
     }
-    return make_uint2(base.x + inc.x - v.x, base.y + inc.y - v.y);
+    return Sum2{base.x + inc.x - v.x, base.y + inc.y - v.y};
 }
+__device__ __forceinline__ uint32_t sat32(uint64_t v) { return (uint32_t)min(v, (uint64_t)0xffffffffu); }
 }  // namespace
 
 __global__ __launch_bounds__(kLayoutBlock) void amv_layout_sums_kernel(const uint32_t* __restrict__ lens, uint32_t n, LayoutSpec a, LayoutSpec b,
                                                                       uint2* __restrict__ sums) {
-    __shared__ uint2 s_wave[kLayoutBlock / 64u];
+    __shared__ Sum2 s_wave[kLayoutBlock / 64u];
     const uint32_t i = blockIdx.x * kLayoutBlock + threadIdx.x;
     const uint32_t len = i < n ? lens[i] : 0u;
-    uint2 tot;
+    Sum2 tot;
     (void)block_scan2(i < n ? make_uint2(layout_lines(len, a), b.line ? layout_lines(len, b) : 0u) : make_uint2(0u, 0u), s_wave, tot);
-    if (threadIdx.x == 0u) sums[blockIdx.x] = tot;
+    if (threadIdx.x == 0u) sums[blockIdx.x] = make_uint2(sat32(tot.x), sat32(tot.y));   // (both capacities are below 2^32)
 }
 
 // sums[0 .. nb) -> exclusive prefix, saturating at the two capacities; sums[nb] = the totals
@@ -1539,13 +1548,13 @@ __global__ __launch_bounds__(1024) void amv_layout_scan_kernel(uint2* __restrict
 
 __global__ __launch_bounds__(kLayoutBlock) void amv_layout_write_kernel(const uint32_t* __restrict__ lens, uint32_t n, LayoutSpec a, LayoutSpec b,
                                                                        const uint2* __restrict__ sums, uint32_t nb) {
-    __shared__ uint2 s_wave[kLayoutBlock / 64u];
+    __shared__ Sum2 s_wave[kLayoutBlock / 64u];
     const uint32_t i = blockIdx.x * kLayoutBlock + threadIdx.x;
     const uint32_t len = i < n ? lens[i] : 0u;
-    uint2 tot;
-    const uint2 at = block_scan2(i < n ? make_uint2(layout_lines(len, a), b.line ? layout_lines(len, b) : 0u) : make_uint2(0u, 0u), s_wave, tot);
+    Sum2 tot;
+    const Sum2 at = block_scan2(i < n ? make_uint2(layout_lines(len, a), b.line ? layout_lines(len, b) : 0u) : make_uint2(0u, 0u), s_wave, tot);
     const uint2 base = sums[blockIdx.x];
-    if (i < n) {
+    if (i < n) {                                               // monotone: base and the prefix never decrease, the minimum keeps that
         a.line[i] = (uint32_t)min((uint64_t)base.x + at.x, (uint64_t)a.cap_lines);
         if (b.line) b.line[i] = (uint32_t)min((uint64_t)base.y + at.y, (uint64_t)b.cap_lines);
     }

@@ -269,6 +269,7 @@ typedef struct ra_window {
     uint8_t *vblob, *ablob, *vout;
     int16_t *aout;
     size_t vblob_cap, ablob_cap, vout_cap, aout_cap;
+    size_t aout_need;         /* what the window's samples take when that is more than aout holds (set by ra_refill, met by ra_issue) */
     size_t vbytes, abytes;    /* filled part of vblob / ablob */
     uint64_t *voffs, *aoffs, *pcm_offs;
     uint32_t *vlens, *alens;
@@ -443,7 +444,8 @@ static void ra_landed(readahead *r, int ok)
  * meets fatter chunks ends early, and a frame that does not fit an EMPTY window (a noisy picture with
  * AMVHIP_READAHEAD=1, an audio chunk of more than 8 KB) gets larger buffers: the reader has no size limit of its own,
  * as the reference's has none (AMVDec.c:196-231 mallocs what the chunk header says).  Only the chunk buffers are written
- * here; vout / aout -- what a caller may still hold a pointer into -- are written by the decode calls. */
+ * -- or replaced -- here; vout / aout, what a caller may still hold a pointer into, are written (and aout, when a first
+ * frame needs more of it, replaced) by the decode calls of their kind. */
 static int ra_refill(readahead *r, ra_window *w, long pos)
 {
     const double t0 = ra_now();
@@ -454,6 +456,7 @@ static int ra_refill(readahead *r, ra_window *w, long pos)
     w->n = 0;
     w->vstate = w->astate = 0;
     w->vbytes = w->abytes = 0;
+    w->aout_need = 0;
     w->start = w->end = pos;
     want = (size_t)r->cap_frames * (r->frame_bytes ? r->frame_bytes + r->frame_bytes / 8 + 64 : (size_t)r->w * r->h / 4 + 2048) + 65536;
     for (attempt = 0; attempt < 4 && w->n == 0; attempt++) {
@@ -488,9 +491,15 @@ static int ra_refill(readahead *r, ra_window *w, long pos)
                 break;
             }
             slot = alen > 8 ? 8 + round4(alen - 8) : 8;
-            if ((ao + slot + 16 > w->ablob_cap || pcm + 4u * (size_t)(slot - 8) > w->aout_cap) &&
-                (w->n != 0 || ra_grow(r, (void **)&w->ablob, &w->ablob_cap, (size_t)slot + 16) != 0 ||
-                 ra_grow(r, (void **)&w->aout, &w->aout_cap, 4u * (size_t)(slot - 8)) != 0)) break;
+            if (ao + slot + 16 > w->ablob_cap || pcm + 4u * (size_t)(slot - 8) > w->aout_cap) {
+                /* a later frame: the window ends here.  The window's FIRST frame gets room: the chunk buffer (nobody holds
+                 * a pointer into it) at once, the sample buffer NOT here -- this runs inside AmvReadNextFrame and inside
+                 * VIDEO decode calls, while the caller may still hold audiodata out of this window's aout (the last audio
+                 * frame of the window before the one before); the need is noted and met by ra_issue, which for audio only
+                 * runs inside AmvAudioDecode, the call that ends that pointer's life */
+                if (w->n != 0 || ra_grow(r, (void **)&w->ablob, &w->ablob_cap, (size_t)slot + 16) != 0) break;
+                if (4u * (size_t)(slot - 8) > w->aout_cap) w->aout_need = 4u * (size_t)(slot - 8);
+            }
             memcpy(w->ablob + ao, hd + 8, alen);
             memset(w->ablob + ao + alen, 0, slot - alen);   /* the bytes the reference's 4-byte loop reads past the chunk */
             e->pos = pos;
@@ -656,12 +665,19 @@ static readahead *ra_current(AMVDecoder *amv, int video)
 }
 
 /* put the window's video (audio) chunks on the context's stream through the batch ABI, once per window */
-static void ra_issue(ra_window *w, int video, uint32_t width, uint32_t height)
+static void ra_issue(readahead *r, ra_window *w, int video)
 {
     uint32_t i;
+    const uint32_t width = r->w, height = r->h;
     int *state = video ? &w->vstate : &w->astate;
     const double t0 = ra_now();
     if (*state != 0 || w->n == 0) return;
+    /* (audio) inside AmvAudioDecode: nothing the caller holds of this window's samples outlives this call, and nothing is
+     * in flight into them (state 0) -- the moment a sample buffer too small for the window's first frame is replaced */
+    if (!video && w->aout_need > w->aout_cap && ra_grow(r, (void **)&w->aout, &w->aout_cap, w->aout_need) != 0) {
+        *state = -1;
+        return;
+    }
     if (video) {
         for (i = 0; i < w->n; i++) { w->voffs[i] = w->e[i].voff; w->vlens[i] = w->e[i].vlen; }
         *state = amvhip_decode_batch_async(ctx(), w->vblob, w->vbytes + 16, w->voffs, w->vlens, w->n, width, height, 0, w->vout,
@@ -684,7 +700,7 @@ static int ra_decode_window(readahead *r, int video)
 {
     ra_window *w = &r->win[r->c];
     int *state = video ? &w->vstate : &w->astate;
-    ra_issue(w, video, r->w, r->h);
+    ra_issue(r, w, video);
     if (*state == 2) {
         const double t0 = ra_now();
         ra_landed(r, amvhip_sync(ctx()) == AMVHIP_OK);
@@ -706,7 +722,7 @@ static void ra_look_ahead(readahead *r, int video)
         if (got <= 0) { o->n = 0; r->ahead = 0; return; }         /* end of stream / nothing complete: the reader finds out itself */
         r->ahead = 2;
     }
-    ra_issue(o, video, r->w, r->h);
+    ra_issue(r, o, video);
 }
 
 int AmvVideoDecode(AMVDecoder *amv)

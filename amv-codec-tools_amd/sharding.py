@@ -130,7 +130,13 @@ def scatter_stream(blob, offs, lens, device, src=0):
             ops += [dist.P2POp(dist.isend, blob[rb0:rb1], r), dist.P2POp(dist.isend, offs[rlo:rhi], r),
                     dist.P2POp(dist.isend, lens[rlo:rhi], r)]
         _exchange(ops)
-        return blob[b0:b1], (offs[lo:hi] - b0 if b0 else offs[lo:hi]), lens[lo:hi], lo
+        # the source's own range stays a view of its blob -- from the 4-byte boundary at or below its first chunk, because
+        # amvhip_decode_batch_dev wants a 4-byte aligned blob (include/amvhip.h) and a chunk may start anywhere
+        base = b0 & ~3 if blob.data_ptr() % 4 == 0 else b0
+        mine = blob[base:b1]
+        if mine.numel() and mine.data_ptr() % 4:
+            mine = mine.clone()                     # a blob that was itself handed over at an odd address: one copy
+        return mine, (offs[lo:hi] - base if base else offs[lo:hi]), lens[lo:hi], lo
     my_blob = torch.empty(max(b1 - b0, 0), dtype=torch.uint8, device=device)
     my_offs = torch.empty(hi - lo, dtype=torch.int64, device=device)
     my_lens = torch.empty(hi - lo, dtype=torch.int32, device=device)

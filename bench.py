@@ -3,8 +3,12 @@
 bit-exact vs amvlib) on its configs[1].
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (starts the N ranks itself, one child process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W     (--gpus must equal WORLD_SIZE)
+
+Exit codes: 0 clean; 2 more GPUs asked for than visible; 3 the strong-scaling leg hung (the line is written first);
+4 it raised a device / RCCL error (the line is written first).
 
 One step = one pass of the hot path, through the C ABI, over one batch that is already resident in
 HBM when the timed region starts; results stay in HBM.  Frames shard by contiguous range, one
@@ -56,8 +60,28 @@ DECODE_FRAMES = 160000
 STRONG_LEG_SECONDS = float(os.environ.get("AMV_BENCH_STRONG_SECONDS", "240"))
 
 
+EXIT_FAILED = 4         # a leg raised a device / RCCL error: the line is written, the run is not clean
+EXIT_HUNG = 3           # a leg did not end: the line is written by the watchdog, the run is not clean
+EXIT_USAGE = 2          # --gpus asks for more devices than there are
+LAUNCH_GRACE_SECONDS = float(os.environ.get("AMV_BENCH_LAUNCH_GRACE", "60"))   # launch_ranks: after one rank failed
+
+
 class Env:
     json_fd = None
+    failed = None
+    strong_phase = ""
+
+
+def strong_flat(strong, status):
+    """configs[3] as stated, as FLAT scalars of `config` (a record that keeps scalars only still carries them, and a hang or
+    an error of the exchange is a value one can read, not a missing key)"""
+    ph = (strong or {}).get("phase_ms_max_over_ranks", {})
+    return {"rccl_ranks": (strong or {}).get("rccl_ranks", dist.get_world_size() if dist.is_initialized() else 0),
+            "strong10k_status": status,
+            "strong10k_ms": (strong or {}).get("ms_per_step"),
+            "strong10k_fps": (strong or {}).get("frames_per_s"),
+            "strong10k_scatter_ms": ph.get("scatter"), "strong10k_decode_ms": ph.get("decode"),
+            "strong10k_gather_ms": ph.get("gather")}
 
 
 def make_video_stream(E, first, n, w, h, noise_every=0):
@@ -391,28 +415,35 @@ def run_decode(E, args):
 
     if E.dist:          # config 4 as BASELINE.json states it, beside the weak-scaling line above
         result["config"]["scaling_modes"] = {"weak": "value / ms_per_step of this line: every GPU decodes its own %d frames" % n,
-                                             "strong": "config4_strong_10k"}
-        # The exchange has never met more than one GPU (§10): the weak line above must not be lost to it.  An error it raises
-        # on its own (not the gate's verdict, which stops the run) is recorded in its place; if it hangs -- a send nobody
-        # receives -- every rank's watchdog writes the line as it stands and leaves.
+                                             "strong": "config4_strong_10k (flat: strong10k_*)"}
+        # The exchange has never met more than one GPU.  Whatever happens to it, the weak line above goes
+        # out -- and the run then ENDS NON-ZERO: a hang (a send nobody receives) or a device / RCCL error is a finding, never
+        # a clean run.  The verdict is a flat scalar, strong10k_status = "ok" | "error: ..." | "hung in <phase>".
         import threading
         done = threading.Event()
+        E.strong_phase = "setup"
 
         def bail():
             if done.wait(STRONG_LEG_SECONDS):
                 return
-            result["config"]["config4_strong_10k"] = {"skipped": "no end after %g s: left alone" % STRONG_LEG_SECONDS}
+            result["config"].update(strong_flat(None, "hung in %s on rank %d: no end after %g s" % (E.strong_phase, E.rank, STRONG_LEG_SECONDS)))
             if E.rank == 0 and E.json_fd is not None:
                 os.write(E.json_fd, (json.dumps(result) + "\n").encode())
-            os._exit(0)
+            os.write(2, ("bench.py: rank %d: strong-scaling leg hung in phase %r; line written, leaving with code %d\n"
+                         % (E.rank, E.strong_phase, EXIT_HUNG)).encode())
+            os._exit(EXIT_HUNG)
 
         threading.Thread(target=bail, daemon=True).start()
+        strong = None
         try:
             strong = run_strong(E, args, w, h)
+            status = "ok"
         except Exception as e:                       # (SystemExit -- the gate -- is not an Exception)
-            strong = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:400])}
+            status = "error: %s in %s: %s" % (type(e).__name__, E.strong_phase, str(e)[:300])
+            E.failed = status                        # the line goes out, then main() leaves non-zero
         done.set()
-        result["config"]["config4_strong_10k"] = strong
+        result["config"].update(strong_flat(strong, status))
+        result["config"]["config4_strong_10k"] = strong if strong is not None else {"failed": status}
 
     if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
         m = min(args.cpu_sample, n)
@@ -443,6 +474,7 @@ def run_strong(E, args, w, h, n_total=10000):
     to rank 0 -- timed end to end ("scaling": "strong").  Runs next to the weak-scaling line, never instead of it."""
     ctx, dev, stream, sh = E.ctx, E.dev, E.stream, E.sh
     d_blob = d_offs = d_lens = None
+    E.strong_phase = "making the stream"
     if E.rank == 0:
         d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, 0, n_total, w, h)
     maxf = max(hi - lo for lo, hi in (sh.frame_range(n_total, r, E.world) for r in range(E.world)))
@@ -474,6 +506,7 @@ def run_strong(E, args, w, h, n_total=10000):
         return sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode, clock=timed_clock, frame_shape=shape, k=k, out=d_full)
 
     # gate: the gathered frames equal one GPU decoding the whole stream by itself, and the oracle on a sample
+    E.strong_phase = "first exchange (scatter / decode / gather)"
     full, _ = one_step()
     torch.cuda.synchronize()
     ok = 1
@@ -489,6 +522,7 @@ def run_strong(E, args, w, h, n_total=10000):
             ch = d_blob[int(offs_h[i]):int(offs_h[i]) + int(lens_h[i])].cpu().numpy().tobytes()
             ok &= int((full[i].cpu().numpy() == orc.decode_frame(ch, w, h)[0]).all())
         del ref
+    E.strong_phase = "gate all-reduce"
     ok = int(sh.sum_over_ranks(float(ok), dev)) == E.world and int(sh.sum_over_ranks(float(bad.item()), dev)) == 0
     if not ok:
         raise SystemExit("strong-scaling leg: gathered frames differ from the single-GPU decode / the oracle")
@@ -496,6 +530,7 @@ def run_strong(E, args, w, h, n_total=10000):
 
     steps = max(3, min(args.steps, 10))
     phases = {"scatter": 0.0, "decode": 0.0, "gather": 0.0}
+    E.strong_phase = "timed exchange"
     for _ in range(2):
         one_step()
     dist.barrier()
@@ -511,6 +546,7 @@ def run_strong(E, args, w, h, n_total=10000):
                                             "-> gather of BGR frames to rank 0, end to end" % (n_total, w, h),
             "frames": n_total, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "frames_per_s": n_total * steps / elapsed,
             "phase_ms_max_over_ranks": phases, "backend": dist.get_backend(), "n_gpus": E.world, "sub_batches": k,
+            "rccl_ranks": dist.get_world_size(),          # the communicator's size as the backend reports it
             "exchange": "source sends slices of its blob (point to point, one grouped call), frames are received straight into "
                         "slices of one buffer on rank 0, whose own range is decoded in place",
             "gathered_bytes_per_step": n_total * h * ctx.stride(w)}
@@ -884,7 +920,8 @@ def run_secondary(E, args):
 
 def flat_secondary(sec):
     """the secondary entries once more as flat scalars of `config`: a record that keeps scalars only still carries every
-    BASELINE config's rate, roofline fraction and the CPU path beside it"""
+    BASELINE config's rate, roofline fraction and the CPU path beside it (CONFIG_HEAD orders them; cores, single-thread
+    figures and path fractions stay in config.secondary)"""
     names = {"decode_320x240": "c320_decode", "decode_160x120_10k_stream": "stream10k", "encode_320x240": "enc320",
              "coresident_320x240_adpcm": "coresident", "adpcm": "adpcm", "decode_160x120_mixed": "mixed160",
              "decode_amv1_looped": "amv1"}
@@ -898,18 +935,99 @@ def flat_secondary(sec):
         flat["%s_%s" % (p, unit)] = e["value"]
         flat[p + "_ms"] = e["ms_per_step"]
         flat[p + "_frac"] = e["roofline"]["frac"]
-        flat[p + "_path_frac"] = e["roofline"]["path_frac"]
         cb = e.get("cpu_baseline")
         if cb:
             flat["%s_cpu_%s" % (p, unit)] = cb["value"]
-            flat[p + "_cpu_cores"] = cb["cores"]
-            if "single_thread_value" in cb:
-                flat["%s_cpu1_%s" % (p, unit)] = cb["single_thread_value"]
         if "handed_to_serial" in e:
             flat[p + "_handed_to_serial"] = e["handed_to_serial"]
         if "adpcm_samples_per_s" in e:
             flat[p + "_adpcm_sps"] = e["adpcm_samples_per_s"]
     return flat
+
+
+# What a record that keeps only the first scalars of `config` must still carry, in this order: the workload, then per
+# BASELINE config its rate, its roofline fraction and the CPU path beside it (configs[1] is the line itself: value, roofline,
+# cpu_baseline), then the strong leg's verdict when there are ranks, then the headline's own diagnostics.
+CONFIG_HEAD = ("workload", "parallelism",
+               "rccl_ranks", "strong10k_status", "strong10k_ms", "strong10k_fps", "strong10k_scatter_ms", "strong10k_decode_ms",
+               "strong10k_gather_ms",
+               "c320_decode_fps", "c320_decode_frac", "c320_decode_cpu_fps",
+               "enc320_fps", "enc320_frac", "enc320_cpu_fps",
+               "stream10k_fps", "stream10k_frac", "stream10k_cpu_fps",
+               "coresident_fps", "coresident_frac", "coresident_cpu_fps", "coresident_adpcm_sps",
+               "adpcm_sps", "adpcm_frac", "adpcm_cpu_sps",
+               "decode_traffic_ratio", "handed_to_serial", "mixed160_fps", "mixed160_handed_to_serial",
+               "frames_per_gpu", "mean_chunk_bytes")
+
+
+def ordered_config(cfg):
+    """`cfg` with CONFIG_HEAD's keys first (those that exist), everything else behind them in the order it came"""
+    head = {k: cfg[k] for k in CONFIG_HEAD if k in cfg}
+    head.update((k, v) for k, v in cfg.items() if k not in head)
+    return head
+
+
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks -- one CHILD process per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run sets them -- relay rank 0's one JSON line
+    and leave with the worst exit code.  This process never touches the GPU (counting devices does not initialise HIP on
+    this image) and never re-execs itself.  AMV_BENCH_CHILD replaces the child command (the launcher's test:
+    tests/test_bench_launcher.py)."""
+    import shlex
+    import socket
+    import subprocess
+    n = args.gpus
+    if not os.environ.get("AMV_BENCH_CHILD"):
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d: %d devices needed, %d visible -- not measuring fewer GPUs under that name\n" % (n, n, have))
+            return EXIT_USAGE
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    child = shlex.split(os.environ["AMV_BENCH_CHILD"]) if os.environ.get("AMV_BENCH_CHILD") else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen(child + argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    # rank 0's stdout is the line (read by a thread, so that the other ranks are watched meanwhile); everything else the
+    # children print is already on stderr
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = None
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+        if any(c not in (None, 0) for c in codes) and deadline is None:
+            deadline = time.time() + LAUNCH_GRACE_SECONDS      # a rank failed: the others get this long to end by themselves
+        if deadline is not None and time.time() > deadline:
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    sys.stderr.write("bench.py: rank %d still running %g s after another rank failed: killing pid %d\n"
+                                     % (r, LAUNCH_GRACE_SECONDS, pr.pid))
+                    pr.kill()                                    # this exact child, nothing by pattern
+                    pr.wait()
+                    codes[r] = EXIT_HUNG
+        time.sleep(0.05)
+    reader.join(10)
+    line = got[0] if got else b""
+    sys.stdout.buffer.write(line)
+    sys.stdout.flush()
+    worst = 0
+    for r, c in enumerate(codes):
+        if c != 0:
+            sys.stderr.write("bench.py: rank %d left with code %d\n" % (r, c))
+            worst = max(worst, c if c > 0 else 128 - c)
+    return worst
 
 
 def main():
@@ -941,6 +1059,17 @@ def main():
                     help="default line only: skip the other BASELINE configs (config.secondary)")
     args = ap.parse_args()
 
+    # --gpus is the number of ranks.  Under torch.distributed.run (or any launcher that sets WORLD_SIZE) it must agree with
+    # the environment; a plain `python bench.py --gpus N` starts the N ranks itself -- BEFORE anything touches the GPU.
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to report one under the other's name"
+                             % (args.gpus, os.environ["WORLD_SIZE"]))
+    elif args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    elif args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+
     E = Env()
     E.world = int(os.environ.get("WORLD_SIZE", "1"))
     E.rank = int(os.environ.get("RANK", "0"))
@@ -952,6 +1081,9 @@ def main():
     E.json_fd = json_fd
     os.dup2(2, 1)
     E.dist = E.world > 1 or args.strong
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d of %d: %d devices needed, %d visible (the codec path has no CPU fallback)"
+                         % (E.rank, E.world, local + 1, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the codec path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -981,9 +1113,15 @@ def main():
         result = run_amvlib(E, args)
     else:
         result = run_adpcm(E, args, with_video=False)
+    result["config"] = ordered_config(result["config"])
     if E.rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
+    if E.failed:
+        # the line is out; a leg that raised a device / RCCL error must not read as a clean run, and the communicator may be
+        # in no state to be torn down: leave at once
+        os.write(2, ("bench.py: rank %d: %s -- leaving with code %d\n" % (E.rank, E.failed, EXIT_FAILED)).encode())
+        os._exit(EXIT_FAILED)
     E.ctx.close()
     if E.dist:
         dist.destroy_process_group()

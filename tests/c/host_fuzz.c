@@ -50,8 +50,16 @@ static void walk(const char *path, int extras)
      * a few frames of that are as good a test as many */
     most = (uint64_t)d->amvinfo.dwWidth * d->amvinfo.dwHeight > 512u * 512u ? 4 : 150;
     for (pass = 0; pass < 2; pass++) {
+        /* what the caller holds from the decode calls before: the contract (AMVDec.c:277-283, :326-329 free and malloc
+         * them in the NEXT decode call of their kind) keeps them readable across AmvReadNextFrame and across the decode
+         * call of the OTHER kind -- read here, under AddressSanitizer, at both points */
+        const unsigned char *held_v = NULL;
+        const short *held_a = NULL;
+        unsigned held_vlen = 0, held_alen = 0;
         for (k = 0; k < (pass ? 3 : most); k++) {
             rc = AmvReadNextFrame(d);
+            if (held_v != NULL && held_vlen) sink += held_v[0] + held_v[held_vlen - 1];
+            if (held_a != NULL && held_alen >= 2) sink += (unsigned)held_a[0] + (unsigned)held_a[held_alen / 2 - 1];
             if (rc != 0) { if (rc != -1) fail("AmvReadNextFrame", rc); break; }
             if (d->framebuf.framenum == -1) { n_end++; break; }
             n_frames++;
@@ -59,15 +67,21 @@ static void walk(const char *path, int extras)
             if (d->framebuf.videobufflen) sink += d->framebuf.videobuff[0] + d->framebuf.videobuff[d->framebuf.videobufflen - 1];
             if (d->framebuf.audiobufflen) sink += d->framebuf.audiobuff[0] + d->framebuf.audiobuff[d->framebuf.audiobufflen - 1];
             rc = AmvVideoDecode(d);
+            held_v = NULL;
             if (rc == 0) {
                 n_vok++;
                 if (d->videobuf.len) sink += d->videobuf.fbmpdat[0] + d->videobuf.fbmpdat[d->videobuf.len - 1];
+                held_v = d->videobuf.fbmpdat; held_vlen = d->videobuf.len;
             } else if (rc != -1 && rc != -2) fail("AmvVideoDecode", rc);
+            if (held_a != NULL && held_alen >= 2) sink += (unsigned)held_a[0] + (unsigned)held_a[held_alen / 2 - 1];   /* still the caller's */
             rc = AmvAudioDecode(d);
+            held_a = NULL;
             if (rc == 0) {
                 n_aok++;
                 if (d->audiobuf.len >= 2) sink += (unsigned)d->audiobuf.audiodata[0] + (unsigned)d->audiobuf.audiodata[d->audiobuf.len / 2 - 1];
+                held_a = d->audiobuf.audiodata; held_alen = d->audiobuf.len;
             } else if (rc > 0 || rc < -2) fail("AmvAudioDecode", rc);
+            if (held_v != NULL && held_vlen) sink += held_v[0] + held_v[held_vlen - 1];
             if (extras && k == 1) {
                 (void)AmvCreateJpegFileFromBuffer(&d->amvinfo, &d->framebuf, g_aux);
                 (void)AmvConvertJpegFileToBmpFile(g_aux, g_aux2);
@@ -232,6 +246,28 @@ int main(int argc, char **argv)
         }
         if (amvhip_mux_close(mx) != 0) fail("amvhip_mux_close", -1);
         walk(g_path, 1);
+        n_mut++;
+    }
+    /* H. fat chunks where the windows change: an audio chunk (20 KB) or a video chunk (0.6 MB) that no window buffer is sized
+     * for, as frame 0, in the middle, and as the first frame of every window for windows of 1 / 2 / 32 frames -- the reader
+     * has to find room for them without taking anything away from what the caller still holds (the held pointers above) */
+    for (i = 0; i < 12; i++) {
+        const uint32_t period = (i % 3u == 0) ? 1u : (i % 3u == 1) ? 2u : 32u;
+        mx = amvhip_mux_open(g_path, 128, 96, 16, 22050, 200000u, 64000u);
+        if (mx == NULL) continue;
+        for (k = 0; k < 70; k++) {
+            const int fat = (k % period) == (i / 3u) % period || k == 37;
+            const uint32_t vl = (fat && (i & 4u)) ? 600000u : 1u + rnd() % 3000u;
+            const uint32_t al = (fat && !(i & 4u)) || (fat && (i & 8u)) ? 8u + 20000u + (rnd() & 3u) : 8u + rnd() % 800u;
+            uint8_t *v = (uint8_t *)malloc(vl), *a = (uint8_t *)malloc(al);
+            for (j = 0; j < vl; j++) v[j] = (uint8_t)rnd();
+            for (j = 0; j < al; j++) a[j] = (uint8_t)rnd();
+            put32(a + 4, (al - 8) * 2u);
+            if (amvhip_mux_write_frame(mx, v, vl, a, al) != 0) fail("amvhip_mux_write_frame", -1);
+            free(v); free(a);
+        }
+        if (amvhip_mux_close(mx) != 0) fail("amvhip_mux_close", -1);
+        walk(g_path, 0);
         n_mut++;
     }
     if (amvhip_mux_open("/nonexistent-dir/x.amv", 128, 96, 16, 22050, 1, 1) != NULL) fail("mux_open into a missing directory", 0);

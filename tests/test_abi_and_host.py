@@ -284,7 +284,9 @@ def test_host_c_under_sanitizers(amv1, tmp_path):
     call failing as on a machine without a GPU, or delivering zeros of the right size), walked by tests/c/host_fuzz.c over
     ~2 000 mutations of the reference's clip per mode -- truncation at every header byte and around chunk headers, chunk
     lengths of 0 / 2^31 / 2^32 - 1 / file size +- 1, missing AMV_END_, 00dc / 01wb swapped, every header byte forced, seeded
-    random damage -- and over what the muxer writes for ordinary, empty and odd-sized frames.  Every call returns a code
+    random damage -- and over what the muxer writes for ordinary, empty and odd-sized frames and for 20 KB audio / 0.6 MB
+    video chunks at window boundaries (windows of 1, 2, 32, 1 024 frames), the walker reading the pointers the decode calls
+    handed out for as long as the reference's contract keeps them alive.  Every call returns a code
     the reference's API has for it, and the sanitizers (leak check included) stay silent.  Where the reference tree is at
     hand the AVCodec plugin (host/amvhip_lavc.c) and the C host that drives it run the same way."""
     inc = os.path.join(ROOT, "include")
@@ -297,7 +299,7 @@ def test_host_c_under_sanitizers(amv1, tmp_path):
                    check=True)
     env = dict(os.environ, ASAN_OPTIONS="allocator_may_return_null=1:detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
     runs = []
-    for k, (mode, window, iters) in enumerate((("fail", "32", 300), ("zero", "32", 300), ("zero", "1024", 60), ("zero", "1", 40))):
+    for k, (mode, window, iters) in enumerate((("fail", "32", 300), ("zero", "32", 300), ("zero", "1024", 60), ("zero", "1", 40), ("zero", "2", 40))):
         work = tmp_path / ("w%d" % k)
         work.mkdir()
         e = dict(env, HOST_STUB_MODE=mode, AMVHIP_READAHEAD=window)

@@ -1807,7 +1807,8 @@ def test_mixed_stream_keeps_the_parallel_kernels(pkg, orc):
     noise in between, whose chunks are many times the mean -- no frame is handed to the one-lane serial kernel
     (amvhip_entropy_stats), and every byte and status equals the oracle's.  Both parallel entropy kernels: the
     speculative lanes a small batch gets and the one-lane-per-frame kernel of a chip-filling batch (AMVHIP_SYNC_LANES=1).
-    A frame that needs more than the 20 records per block the kernels are ever given still goes to the serial kernel,
+    A frame's record space is two words per byte of its chunk + two per block (amvhip_api.hip: `add_rec`, `hi_rec`), never
+    more than a frame with every coefficient non-zero could fill -- white noise stays on the parallel kernels too --
     and chunks that overlap in the blob (their lengths add up to more than the blob holds) are decoded all the same."""
     import os
     import torch
@@ -1856,6 +1857,54 @@ def test_mixed_stream_keeps_the_parallel_kernels(pkg, orc):
                                torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert (d_st.cpu().numpy() == 0).all() and (d_out.cpu().numpy() == uniq[one][0][None]).all()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_decode_lengths_that_overflow_the_layout(pkg, orc):
+    """Chunk lengths are whatever the caller wrote: 20 consecutive frames claim ~4 GB each (a 32-bit prefix over one
+    workgroup's 256 lengths would wrap after 16 of them, and a frame's workspace window would start below its
+    predecessor's).  The layout saturates instead: those frames (clamped to the blob, as include/amvhip.h promises) and
+    the ones behind them take the serial kernel, every frame decodes to what the oracle makes of the bytes from its offset
+    to the end of the blob, and the frames in front of them are untouched.  Both parallel entropy kernels."""
+    import os
+    w, h = 160, 120
+    chunks = _synth_chunks(orc, 12, w, h)
+    n = 300
+    seq = [chunks[i % len(chunks)] for i in range(n)]
+    blob, offs, lens, nbytes = _blob_of(seq)
+    huge = range(100, 120)
+    lens2 = lens.copy()
+    for i in huge:
+        lens2[i] = 0xfffffff0 - (i & 3)
+    want = np.stack([orc.decode_frame(c, w, h)[0] for c in chunks])
+    want_huge = {i: orc.decode_frame(blob[int(offs[i]):nbytes].tobytes(), w, h) for i in huge}
+    old = os.environ.get("AMVHIP_SYNC_LANES")
+    ctxs = []
+    try:
+        for lanes in (None, "1"):
+            if lanes:
+                os.environ["AMVHIP_SYNC_LANES"] = lanes
+            ctxs.append(pkg.Context(0))
+    finally:
+        if old is None:
+            os.environ.pop("AMVHIP_SYNC_LANES", None)
+        else:
+            os.environ["AMVHIP_SYNC_LANES"] = old
+    import torch
+    try:
+        for c in ctxs:
+            d_out = torch.full((n, h, c.stride(w)), 0x5A, dtype=torch.uint8, device="cuda:0")
+            d_st = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+            c.decode_batch_dev(_t(blob), nbytes, _t(offs), _t(lens2), n, w, h, 0, d_out, d_st, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got, st = d_out.cpu().numpy(), d_st.cpu().numpy()
+            for i in range(n):
+                if i in want_huge:
+                    assert st[i] == want_huge[i][1] and (got[i] == want_huge[i][0]).all(), i
+                else:
+                    assert st[i] == 0 and (got[i] == want[i % len(chunks)]).all(), i
     finally:
         for c in ctxs:
             c.close()

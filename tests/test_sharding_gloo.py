@@ -82,6 +82,21 @@ def _worker(rank, world, port, q):
         my_blob, my_offs, my_lens, first = sh.scatter_stream(blob, offs, lens, dev)
         assert first == lo and my_lens.numel() == hi - lo and int(my_offs[0]) == 0
         assert my_blob.numel() == int(my_offs[-1]) + int(my_lens[-1])
+        # the stream held by rank 1, its chunks packed back to back (chunk starts at any byte): the source's own range is a
+        # view of its blob, and a view the decode ABI accepts -- 4-byte aligned (amvhip_decode_batch_dev rejects others)
+        pb = po = pl = None
+        if rank == 1:
+            b0_, o0_, l0_ = orc.synth_stream(SEED, 0, N, W, H)
+            po = np.concatenate([[1], 1 + np.cumsum(l0_.astype(np.int64))[:-1]]).astype(np.uint64)    # odd starts
+            pb = np.zeros(int(po[-1]) + int(l0_[-1]) + 8, np.uint8)
+            for i in range(N):
+                pb[int(po[i]):int(po[i]) + int(l0_[i])] = b0_[int(o0_[i]):int(o0_[i]) + int(l0_[i])]
+            pl = l0_
+        s_blob, s_offs, s_lens, s_first = sh.scatter_stream(pb, po, pl, dev, src=1)
+        assert s_first == lo and s_lens.numel() == hi - lo
+        assert s_blob.data_ptr() % 4 == 0 and 0 <= int(s_offs[0]) < 4
+        assert s_blob.numel() == int(s_offs[-1]) + int(s_lens[-1])
+        assert torch.equal(decode(s_blob, s_offs, s_lens, s_first), decode(my_blob, my_offs, my_lens, first))
         # gather_frames: the plain form (a decoder that knows nothing of `into`)
         mine = decode(my_blob, my_offs, my_lens, first)
         got = sh.gather_frames(mine, N)
