@@ -727,6 +727,11 @@ namespace {
 constexpr uint32_t kFastRegion = kFastWords * 4u;            // bytes per table in LDS
 constexpr uint32_t kFastTableBytes = 4u * kFastRegion;
 constexpr uint32_t kServicePace = 4u;                         // strides between a wave's stream requests (fast_service_paced)
+// ... of the speculative walks when a frame has sixteen lanes or more -- launches a wave or two per SIMD deep: nothing
+// young is in flight to wait for, and a lane that runs dry asks and waits on the spot -- requests in every stride:
+// 0.434 -> 0.426 ms per 10 000 frames of 160x120; with eight lanes per frame (32 000 frames of 320x240, a chip full of waves)
+// that costs 7 %, so those keep the pace of the one-lane kernel
+template <int L> constexpr uint32_t skip_pace() { return L >= 16 ? 1u : kServicePace; }
 constexpr uint32_t kSlot = kWave * 4u;                       // bytes between a lane's consecutive slots
 constexpr uint32_t kFastRingBytes = (kRingWords + 1u) * kSlot;   // slot 16 mirrors slot 0
 constexpr uint32_t kFastSumBytes = 4u * kSlot;                   // three sums; aligned to its size
@@ -899,6 +904,7 @@ __device__ __forceinline__ void fast_open_at(Stream& s, uint32_t w) {
 // symbols start and how the block position moves, nothing else.  "No such code" (a guessed start) slips one bit and
 // leaves the index alone: the entry says so (one bit used, no advance); an over-long run closes the block.
 // nblk6: blocks finished << 6; nrec8: symbols that carry a value << 8.
+template <uint32_t kPace>
 __device__ __forceinline__ void fast_skip(Stream& win, uint32_t ringb, FastState& s, uint32_t lim1, uint32_t& nblk6, uint32_t& nrec8) {
     nblk6 = nrec8 = 0u;
     bool active = (int32_t)(s.t - lim1) < 0;
@@ -907,7 +913,7 @@ __device__ __forceinline__ void fast_skip(Stream& win, uint32_t ringb, FastState
     bool have = true;            // fast_open_at asked for the next eight words
     uint32_t stride_no = 1u;     // (the first request stride is three strides away: the ring was just filled)
     while (__ballot(active) != 0ull) {
-        fast_service_paced<kServicePace>(win, (s.t + 1u) >> 5, active, have, stride_no++);
+        fast_service_paced<kPace>(win, (s.t + 1u) >> 5, active, have, stride_no++);
 #pragma unroll
         for (int it = 0; it < kStrideWrite; ++it) {
             const uint32_t v = fast_window(ringb, s.t);
@@ -1150,39 +1156,195 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
         Stream win{ws + (uint64_t)ws_line[fsafe] * 4u, live ? ((total + 15u) >> 4) * 4u : 0u, reinterpret_cast<uint32_t*>(s_mem + ringb), 0u,
                    make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
 
-        // ---- 1/2. speculative walks until every lane's start state equals its neighbour's arrival
+        // ---- 1/2. speculative walks until every lane knows the state the decoder is in where its share starts.
+        // Round 4's form: every lane walks its share from a guess, then takes its left neighbour's arrival as its start and
+        // walks again while that changes.  A 10 000-frame launch then lasts as long as its unluckiest frame: a wrong
+        // trajectory that does not fall in step with the true one for k shares in a row (one in five per share, more where
+        // blocks are long) costs k rounds, one lane of the frame walking and the others watching -- 2.5 rounds on
+        // average, 9 for the worst of 10 000 frames (tools/sim_sync.c is a CPU model of this loop).  Now (round 5):
+        //  * a lane REMEMBERS what it has walked: its share's memo, (start -> arrival, blocks, records) of up to kMemo walks,
+        //    in the staging and DC-sum words of its LDS column, which are free until pass 4;
+        //  * FINALITY runs ahead of the walks: lane 0's start is exact; a lane whose left neighbour is final takes that
+        //    lane's arrival as its own final start, and when its share has been walked from that state before -- by
+        //    anybody -- it is final too, at once, and so on to the right (a loop of shuffles, no walk);
+        //  * lanes with nothing to walk HELP: every arrival somebody has found at the end of share x - 1 is a candidate
+        //    start of share x, and where candidates run out the guess "a block starts here" is tried with the other five
+        //    positions in the MCU (the 1-in-6 part of the guess) -- so that when finality reaches a share, the true start
+        //    has, with luck, been walked from already.  One task per lane and round, the frame's leftmost shares first.
+        //  The first non-final lane of a frame always walks from its final start, so a frame is done after at most L - 1
+        //  rounds whatever the helpers found; on the synthetic stream the worst frame of 4 000 takes 4 rounds instead of 9.
         uint32_t S = ((valid_bits + L - 1) / L + 31u) & ~31u;   // bits per lane, a whole number of words
         if (S < 64u) S = 64u;
-        // the last lane of a frame has no right neighbour to feed: it only runs in pass 4
-        const bool walks = live && sub != L - 1;
-        const uint32_t lim1 = walks ? (sub + 1u) * S - 1u : 0u;
-        // position sub * S, "the DC symbol of block 0 comes next"; a lane that does not walk starts past its (empty) share
-        FastState entry{sub * S - 1u, 0u, 5u, 0u, 0u, ~0u};
-        if (!walks) entry.t = lim1;
-        FastState arrive = entry;
-        uint32_t my_blocks6, my_recs8;
-        fast_skip(win, ringb, arrive, lim1, my_blocks6, my_recs8);
-        if (timing) tc[2] = clock64();
-        uint32_t rounds = 0;
+        constexpr uint32_t kMemo = 5u, kPend = 4u;      // words 0..14 of a column: the memo; 15..18: this round's tasks; 19: entries held
+        constexpr uint32_t kGuess = 5u << 11;            // state code: (t - (x * S - 1)) | k << 5 | j << 11; the guess: DC of block 0 comes next
+        const uint32_t stage0 = stageb - lane * 4u, sum0 = sumb - lane * 4u, col0 = slot * L;
         const uint64_t seg = L == 64 ? ~0ull : (((1ull << (L & 63)) - 1ull) << (slot * L));
-        for (int round = 0; round < L; ++round) {
-            const uint32_t lt = __shfl_up(arrive.t, 1, L), lk = __shfl_up(arrive.k, 1, L), lj = __shfl_up(arrive.j, 1, L);
-            const bool changed = live && sub != 0 && (lt != entry.t || lk != entry.k || lj != entry.j);
-            const uint64_t who = __ballot(changed);
-            if (!who) break;
-            if (who & seg) ++rounds;
-            if (changed) {
-                entry.t = lt; entry.k = lk; entry.j = lj; entry.dc = lk ? 0u : ~0u;
-                arrive = entry;
-                if (!walks) arrive.t = max(arrive.t, lim1);   // (the last lane: nothing to walk, its entry is all that counts)
+        auto col_addr = [&](uint32_t col, uint32_t w) { return (w < 16u ? stage0 + w * kSlot : sum0 + (w - 16u) * kSlot) + col * 4u; };
+        // the last lane of a frame has no right neighbour to feed: its share is only walked in pass 4
+        const bool walks = live && sub != L - 1;
+        uint32_t my_blocks6 = 0u, my_recs8 = 0u, seeded = 0u, rounds = 0u;
+        lds_store(col_addr(lane, 19u), 0u);
+        {   // round 0: every lane from its guess (lane 0: the exact state)
+            FastState st{sub * S - 1u, 0u, 5u, 0u, 0u, ~0u};
+            const uint32_t lim1 = walks ? (sub + 1u) * S - 1u : 0u;
+            if (!walks) st.t = lim1;
+            uint32_t b6, r8;
+            fast_skip<skip_pace<L>()>(win, ringb, st, lim1, b6, r8);
+            if (walks) {
+                lds_store(col_addr(lane, 0u), kGuess | (((st.t - lim1) | (st.k << 5) | (st.j << 11)) << 16));
+                lds_store(col_addr(lane, 1u), b6);
+                lds_store(col_addr(lane, 2u), r8);
+                lds_store(col_addr(lane, 19u), 1u);
             }
-            // (every lane goes in: the walk's ballots are wave-wide; an unchanged lane is past its limit and stands still)
-            uint32_t b6 = 0, r8 = 0;
-            FastState again = changed ? arrive : FastState{lim1, 0u, 5u, 0u, 0u, ~0u};
-            fast_skip(win, ringb, again, lim1, b6, r8);
-            if (changed) { arrive = again; my_blocks6 = b6; my_recs8 = r8; }
+        }
+        if (timing) tc[2] = clock64();
+        // which of its memo's walks is a lane's FINAL one (7: none yet), and the start it belongs to
+        constexpr uint32_t kNone = 7u;
+        uint32_t final_at = kNone, final_code = kGuess;
+        bool settled = !live;
+        for (int round = 0; round < L + 1; ++round) {
+            wave_sync();
+            // what the lane's own share and the share to its left have been walked from / arrived at, into registers
+            const uint32_t held = lds_load(col_addr(lane, 19u));
+            const uint32_t left_n = sub ? lds_load(col_addr(lane - 1u, 19u)) : 0u;
+            uint32_t mine[kMemo], cand[kMemo];
+#pragma unroll
+            for (uint32_t q = 0; q < kMemo; ++q) {
+                const uint32_t a = lds_load(col_addr(lane, 3u * q)), b = lds_load(col_addr(sub ? lane - 1u : lane, 3u * q));
+                mine[q] = q < held ? a : kNever;                     // entry code | arrival code << 16
+                cand[q] = q < left_n ? b >> 16 : kNever;             // arrival codes at the end of the share before
+            }
+            // Finality.  A lane's link: "if walk q' of the share to my left is that share's final one, which of MY walks starts
+            // where it arrived?" -- eight 3-bit fields (q' -> q, 7 = none; 7 -> 7).  Lane 0's answer is walk 0 whatever comes
+            // in (the guess IS its start); the frame's last lane, which is never walked ahead, is final as soon as its left
+            // neighbour is.  Links compose, so a prefix scan over the frame's lanes gives every lane its final walk at once
+            // (a loop that moved finality one lane per trip cost a fifth of a round with 64 lanes per frame).
+            uint32_t link = (kNone << 15) | (kNone << 18) | (kNone << 21);
+#pragma unroll
+            for (uint32_t qp = 0; qp < kMemo; ++qp) {
+                uint32_t to = kNone;
+#pragma unroll
+                for (uint32_t q = 0; q < kMemo; ++q) to = (mine[q] != kNever && (mine[q] & 0xffffu) == cand[qp]) ? q : to;
+                if (sub == L - 1) to = cand[qp] != kNever ? 0u : kNone;
+                link |= to << (3u * qp);
+            }
+            if (sub == 0) link = 0u;
+            if (!live) link = 0u;
+#pragma unroll
+            for (int d = 1; d < L; d <<= 1) {
+                const uint32_t before = __shfl_up(link, d, L);       // the links of the d lanes to the left, composed
+                uint32_t both = 0u;
+#pragma unroll
+                for (uint32_t f = 0; f < 8u; ++f) both |= ((link >> (3u * ((before >> (3u * f)) & 7u))) & 7u) << (3u * f);
+                if (sub >= (uint32_t)d) link = both;
+            }
+            final_at = link & 7u;                                    // (every field holds the same: lane 0's link ignores its input)
+            const uint32_t left_at = wave_shr1(final_at);
+            settled = !live || final_at != kNone;
+            const bool front = live && !settled && sub != 0 && left_at != kNone;   // the frame's first open lane: its start is final
+            if (sub == 0) final_code = kGuess;
+            else {
+#pragma unroll
+                for (uint32_t q = 0; q < kMemo; ++q) if (left_at == q) final_code = cand[q];
+            }
+            const uint64_t open = __ballot(!settled);
+            if (!open) {
+                if (walks) {      // the final walk's counts
+                    my_blocks6 = lds_load(col_addr(lane, 3u * final_at + 1u));
+                    my_recs8 = lds_load(col_addr(lane, 3u * final_at + 2u));
+                }
+                break;
+            }
+            if (open & seg) ++rounds;
+            // this round's tasks of the lane's own share: its final start, or else the arrivals found at the end of the share
+            // before that it has not walked from (newest first), then guesses with another position in the MCU
+            uint32_t p = 0u;
+            if (walks && front) {
+                lds_store(col_addr(lane, 15u), final_code);
+                p = 1u;
+            } else if (walks && !settled) {
+                const uint32_t most = min(kMemo - min(held, kMemo), kPend);
+                uint32_t taken[kPend] = {kNever, kNever, kNever, kNever};
+#pragma unroll
+                for (uint32_t qq = 0; qq < kMemo; ++qq) {
+                    const uint32_t c = cand[kMemo - 1u - qq];
+                    bool known = c == kNever;
+#pragma unroll
+                    for (uint32_t m = 0; m < kMemo; ++m) known = known || (mine[m] & 0xffffu) == c;
+#pragma unroll
+                    for (uint32_t m = 0; m < kPend; ++m) known = known || taken[m] == c;
+                    if (!known && p < most) {
+#pragma unroll
+                        for (uint32_t m = 0; m < kPend; ++m) if (m == p) taken[m] = c;
+                        lds_store(col_addr(lane, 15u + p), c);
+                        ++p;
+                    }
+                }
+                while (seeded < 5u && p + 1u < most) {     // (one place stays free for what finality brings)
+                    ++seeded;
+                    lds_store(col_addr(lane, 15u + p), (5u - seeded) << 11);
+                    ++p;
+                }
+            }
+            // one task per lane: a share's first task is its own lane's; the others go to the frame's lanes that have none,
+            // in lane order (a frame's leftmost shares first)
+            const uint32_t extras = p ? p - 1u : 0u;
+            const bool idle = live && p == 0u;
+            uint32_t all_extras, all_idle;
+            const uint32_t ex_at = seg_excl_sum<L>(extras, sub, all_extras);
+            const uint32_t id_at = seg_excl_sum<L>(idle ? 1u : 0u, sub, all_idle);
+            wave_sync();
+            uint32_t owner = sub, rank = 0u;            // whose share, and which of its tasks
+            bool work = p != 0u;
+            if (__ballot(all_extras != 0u) != 0ull) {
+                // the lane whose extras hold number id_at: the last one whose first extra is numbered <= id_at (of several
+                // lanes with the same number the last is the one that has extras)
+                uint32_t lo = 0u;
+#pragma unroll
+                for (int d = L >> 1; d >= 1; d >>= 1) {
+                    const uint32_t probe = __shfl(ex_at, (int)(lo + (uint32_t)d), L);
+                    if (lo + (uint32_t)d < (uint32_t)L && probe <= id_at) lo += (uint32_t)d;
+                }
+                const uint32_t lo_at = __shfl(ex_at, (int)lo, L), lo_n = __shfl(extras, (int)lo, L);
+                if (idle && id_at < all_extras && id_at - lo_at < lo_n) { owner = lo; rank = id_at - lo_at + 1u; work = true; }
+            }
+            FastState st{0u, 0u, 5u, 0u, 0u, ~0u};
+            uint32_t lim1 = 0u, code = 0u;
+            if (work) {
+                code = lds_load(col_addr(col0 + owner, 15u + rank));
+                lim1 = (owner + 1u) * S - 1u;
+                st.t = owner * S - 1u + (code & 31u);
+                st.k = (code >> 5) & 63u;
+                st.j = code >> 11;
+                st.dc = st.k ? 0u : ~0u;
+            }
+            uint32_t b6 = 0u, r8 = 0u;
+            fast_skip<skip_pace<L>()>(win, ringb, st, lim1, b6, r8);
+            if (work) {
+                const uint32_t arr = (st.t - lim1) | (st.k << 5) | (st.j << 11);
+                // the walk from a final start always lands in the memo: in its last place when the memo is full
+                uint32_t at = lds_load(col_addr(col0 + owner, 19u)) + rank;
+                if (rank == 0u && front) at = min(at, kMemo - 1u);
+                if (at < kMemo) {
+                    lds_store(col_addr(col0 + owner, 3u * at), code | (arr << 16));
+                    lds_store(col_addr(col0 + owner, 3u * at + 1u), b6);
+                    lds_store(col_addr(col0 + owner, 3u * at + 2u), r8);
+                }
+            }
+            wave_sync();
+            if (p) {    // how many of this share's tasks found a lane: its own + the extras numbered below the idle lanes' count
+                const uint32_t done = 1u + min(extras, all_idle > ex_at ? all_idle - ex_at : 0u);
+                lds_store(col_addr(lane, 19u), min(held + done, kMemo));
+            }
         }
         if (timing) tc[3] = clock64();
+        // the state every lane starts pass 4 in
+        FastState entry{sub * S - 1u + (final_code & 31u), (final_code >> 5) & 63u, final_code >> 11, 0u, 0u, 0u};
+        entry.dc = entry.k ? 0u : ~0u;
+        if (sub == L - 1 || !live) { my_blocks6 = 0u; my_recs8 = 0u; }
+        // (cannot happen: the first open lane of a frame walks from its final start in every round.  Should a lane be left
+        // without one all the same, the frame goes to the serial kernel rather than out with a guessed state in it.)
+        const bool unsettled = (__ballot(!settled) & seg) != 0ull;
 
         // ---- 3. first block and first record of every lane (the last lane has not walked: its counts are 0, it is last)
         uint32_t all_blocks, all_recs;
@@ -1306,7 +1468,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
                 atomicAdd(&stats[1], (unsigned long long)rounds);
                 atomicMax(&stats[2], (unsigned long long)rounds);
             }
-            if (rec_total > cap_rec) {   // more non-zero coefficients than the record space holds
+            if (rec_total > cap_rec || unsettled) {   // more non-zero coefficients than the record space holds
                 out.rec_count[frame] = kNever;
                 out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
             } else {
