@@ -551,6 +551,7 @@ struct SyncOut {
     uint32_t* seg_start;
     uint32_t* lane_tab;
     SegGeom sg;
+    uint32_t lane_stride;    // entries per frame in lane_tab (>= the lanes of the launch that writes it)
     uint32_t* rec_count;
     uint32_t* retry_list;    // frames for amv_huffman_kernel
     uint32_t* retry_count;
@@ -1074,7 +1075,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
             const uint32_t bits = s.t + 1u + (stop == 1u ? 17u : 0u);   // FORMAT: the reference has read 17 bits by then
             uint32_t st = stop == 1u ? kStFormat : (stop == 2u ? kStOverrun : 0u);
             if (bits > valid_bits) st |= kStTruncated;
-            reinterpret_cast<uint4*>(out.lane_tab)[frame] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4*>(out.lane_tab)[(uint64_t)frame * out.lane_stride] = make_uint4(0u, 0u, 0u, 0u);
             // segments the decoder never started begin (and end) at the total; so does the end of the last one
             for (uint32_t m = seg_next; m <= sg.count; ++m) seg_out[m] = make_uint2(recpos, recpos);
             if (stats) atomicAdd(&stats[0], 1ull);
@@ -1110,6 +1111,9 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
     const uint32_t slot = lane / L, sub = lane % L;
+    // (the heavy frames' launch of a batch that has none: gone before it has touched the tables -- its workgroups hold the
+    // LDS the light frames' launch behind it is waiting for)
+    if (list && *list_count == 0u) return;
     {   // tables, shared by the waves of the workgroup
         const uint4* src = reinterpret_cast<const uint4*>(&img->fast[0][0]);
         uint4* dst = reinterpret_cast<uint4*>(s_mem);
@@ -1453,7 +1457,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
         if (live) {
             // lanes right of the one that met the end (or the first error) walked from states no decoder reaches
             const bool real = (int)lane <= stop_lane && blk0 < blocks_per_frame;
-            reinterpret_cast<uint4*>(out.lane_tab)[(uint64_t)frame * L + sub] = make_uint4(real ? dc_first : kNever, by, bu, bv);
+            reinterpret_cast<uint4*>(out.lane_tab)[(uint64_t)frame * out.lane_stride + sub] = make_uint4(real ? dc_first : kNever, by, bu, bv);
             // segments the decoder never started begin (and end) at the total; so does the end of the last one
             for (uint32_t m = seg_seen + sub; m <= sg.count; m += L) seg_out[m] = make_uint2(rec_total, rec_total);
         }
@@ -1474,7 +1478,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
             } else {
                 status[frame] = (int32_t)st;
                 nmcu_ok[frame] = good_blocks / 6u;
-                out.rec_count[frame] = rec_total;
+                out.rec_count[frame] = rec_total | ((uint32_t)(L - 1) << 24);   // (a frame holds < 2^21 records: amvhip_api.hip)
             }
         }
     }   // next task
@@ -1595,6 +1599,34 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     return fill > full ? fill : full;
 }
 
+// Heavy and light frames of a batch (launch_split_by_weight): thread per frame, a wave's frames of a class appended with one
+// atomic add.  The order inside a list is whatever the waves' turns make it; nothing but the order of work depends on it.
+__global__ __launch_bounds__(256) void amv_split_kernel(const uint32_t* __restrict__ lens, uint32_t n, const uint32_t* __restrict__ ws_line,
+                                                        uint32_t* __restrict__ heavy, uint32_t* __restrict__ light, uint32_t* __restrict__ count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool in = i < n;
+    // a frame's scan has (length + 47) / 16 pieces of the workspace (entropy_front's layout); twice the mean of that is the line
+    const uint64_t all = ws_line[n];
+    const bool is_heavy = in && (uint64_t)((lens[in ? i : 0u] + 47u) >> 4) * n > 2u * all;
+    const uint64_t hm = __ballot(is_heavy), lm = __ballot(in && !is_heavy);
+    uint32_t hb = 0u, lb = 0u;
+    if (lane == 0u) {
+        if (hm) hb = atomicAdd(&count[0], (uint32_t)__builtin_popcountll(hm));
+        if (lm) lb = atomicAdd(&count[1], (uint32_t)__builtin_popcountll(lm));
+    }
+    hb = (uint32_t)__shfl((int)hb, 0);
+    lb = (uint32_t)__shfl((int)lb, 0);
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (is_heavy) heavy[hb + (uint32_t)__builtin_popcountll(hm & below)] = i;
+    else if (in) light[lb + (uint32_t)__builtin_popcountll(lm & below)] = i;
+}
+
+void launch_split_by_weight(const uint32_t* lens, uint32_t n, const uint32_t* ws_line, uint32_t* heavy, uint32_t* light, uint32_t* count,
+                            hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(amv_split_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, lens, n, ws_line, heavy, light, count);
+}
+
 void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offs, const uint32_t* lens, uint32_t n,
                     const uint32_t* ws_line, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
                     hipStream_t s) {
@@ -1610,7 +1642,7 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
     if (n == 0) return;
     const uint32_t per_row = (g.mcu_cols + kSegMcus - 1u) / kSegMcus;
     SyncOut out{sinks.coef, sinks.rec, sinks.rec_line, sinks.seg_start, sinks.lane_tab, SegGeom{g.mcu_cols, per_row, per_row * g.mcu_rows},
-                sinks.rec_count, sinks.retry_list, sinks.retry_count};
+                sinks.lanes, sinks.rec_count, sinks.retry_list, sinks.retry_count};
 #define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, ws_line, d_img, out, status, nmcu_ok, queue, stats, cus, s
     if (sinks.rec) {
         switch (lanes_per_frame) {

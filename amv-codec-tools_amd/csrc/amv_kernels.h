@@ -36,8 +36,9 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels);
 // after `from` with only records of the <= 4 blocks before it in between, and the records of the segment before end
 // ahead of `to`, with only records of this segment's first <= 4 blocks in between (the exact position twice, or the
 // record counts around the eight symbols in which the segment began), lane_tab[lanes] = {first block,
-// DC base Y, Cb, Cr} of each of the `lanes` lanes that decoded the frame, rec_count (total, or ~0 = this frame is in
-// dense form in coef because it went through amv_huffman_kernel).
+// DC base Y, Cb, Cr} of each of the lanes that decoded the frame (a row of `lanes` entries per frame; how many of them a
+// frame used is in its rec_count), rec_count (bits 0-23 total, bits 24-29 lanes that decoded the frame - 1; or ~0 = this
+// frame is in dense form in coef because it went through amv_huffman_kernel).
 struct SyncSinks {
     int16_t* coef;
     uint32_t* rec;
@@ -59,6 +60,11 @@ struct LayoutSpec {
 };
 uint64_t layout_workspace(uint32_t n);
 void launch_layout(const uint32_t* lens, uint32_t n, const LayoutSpec& a, const LayoutSpec& b, void* work, hipStream_t s);
+// Frames whose chunk is more than twice the batch's mean chunk (by the pieces the layout gave their scans: ws_line) ->
+// heavy[0 .. count[0]), the others -> light[0 .. count[1]); count[0..1] zeroed by the caller.  A chip-filling batch decodes
+// the light ones one lane per frame and the heavy ones with several lanes each (amvhip_api.hip: entropy_front).
+void launch_split_by_weight(const uint32_t* lens, uint32_t n, const uint32_t* ws_line, uint32_t* heavy, uint32_t* light, uint32_t* count,
+                            hipStream_t s);
 // list/list_count: optional frame list; *queue: a zeroed task counter per launch
 void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const uint32_t* list,
                          const uint32_t* list_count, const FrameGeom& g, const uint32_t* ws_line, int lanes_per_frame,

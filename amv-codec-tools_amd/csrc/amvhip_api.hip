@@ -40,7 +40,7 @@ struct amvhip_ctx {
     HuffDecodeImage* d_dec = nullptr;
     HuffEncodeImage* d_enc = nullptr;
     // workspace
-    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, enc_retry, stats, ws, ws_line, layout, ws_bytes, rec, rec_line, seg_start, lane_tab, rec_count, scaled, trellis_ws, chain;
+    DevBuf coef, status, nmcu, tmp, lens, offs, flag, map, start, retry, enc_retry, stats, ws, ws_line, layout, ws_bytes, rec, rec_line, seg_start, lane_tab, rec_count, scaled, trellis_ws, chain, split;
     // amvhip_decode_submit_dev / _collect_dev: what the entropy stage hands to the reconstruction exists twice, so that
     // the entropy stage of one batch can run (stream `front`) beside the reconstruction of the batch before (`back`)
     struct DecodeSet { DevBuf nmcu, retry, rec, rec_line, seg_start, lane_tab, rec_count; } second;
@@ -49,6 +49,8 @@ struct amvhip_ctx {
     uint64_t submitted = 0, collected = 0;
     DevBuf* last_decode_retry = nullptr;   // whose first word counts the frames the LAST decode call handed to the serial kernel
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
+    bool split_heavy = true;   // AMVHIP_SPLIT=0: a one-lane-per-frame batch keeps its heavy frames on one lane too
+    uint32_t heavy_lanes = 16; // AMVHIP_SPLIT=n: lanes a heavy frame gets (1, 2, 4 ... 64)
     uint32_t cus = 256;   // compute units of the device
     bool want_stats = false;
     double ws_bytes_per_frame = 0.0;
@@ -279,6 +281,12 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->sync_lanes = v;
     }
+    if (const char* e = getenv("AMVHIP_SPLIT")) {   // tuning / test knob: 0 = no split, a power of two = lanes per heavy frame
+        const int v = atoi(e);
+        c->split_heavy = v != 0;
+        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->heavy_lanes = (uint32_t)v;
+        if (v == -1) c->heavy_lanes = 1;    // two lists, one lane per frame in both (measurements)
+    }
     if (const char* e = getenv("AMVHIP_ADPCM_SWEEPS")) {   // tuning / test knob: "map" = exhaustive route only, or a sweep count
         if (strcmp(e, "nosettle") == 0) {
             c->adpcm_settle = false;   // sweeps by stream length, then nothing: the chain's check sends the stream down the exhaustive route
@@ -306,7 +314,7 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     for (hipEvent_t e : {c->ev_in, c->ev_front, c->ev_done[0], c->ev_done[1]})
         if (e) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->coef, &c->status, &c->nmcu, &c->tmp, &c->lens, &c->offs, &c->flag, &c->map,
-                      &c->start, &c->retry, &c->enc_retry, &c->stats, &c->ws, &c->ws_line, &c->layout, &c->ws_bytes, &c->rec, &c->rec_line, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->chain, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out,
+                      &c->start, &c->retry, &c->enc_retry, &c->stats, &c->ws, &c->ws_line, &c->layout, &c->ws_bytes, &c->rec, &c->rec_line, &c->seg_start, &c->lane_tab, &c->rec_count, &c->scaled, &c->trellis_ws, &c->chain, &c->split, &c->h_in, &c->h_offs, &c->h_lens, &c->h_out, &c->h_status, &c->h_aux, &c->a_in, &c->a_tab, &c->a_out,
                       &c->second.nmcu, &c->second.retry, &c->second.rec, &c->second.rec_line, &c->second.seg_start, &c->second.lane_tab, &c->second.rec_count})
         if (b->p) (void)hipFree(b->p);
     if (c->d_dec) (void)hipFree(c->d_dec);
@@ -345,9 +353,14 @@ struct Fallback {
 
 // unstuffing + the synchronising kernel into `sinks` (dense when sinks.rec == nullptr, records otherwise); fb says
 // what is left for the serial kernel
+// lanes: lanes per frame of the synchronising kernel; heavy_lanes != 0 (records form, a batch that gets ONE lane per frame):
+// frames whose chunk is over twice the batch's mean get that many lanes instead -- a wave's 64 frames finish together, and one
+// noise frame among 63 quiet ones kept them all waiting for six times their own length (a stream with every 16th frame noise
+// spent 4.3 ms per 160 000 frames in the entropy kernel for 1.3 times the uniform stream's symbols).  The split is made on the
+// device (the lengths are there): two frame lists, two launches that take their frames from them.
 static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offs,
                          const uint32_t* d_lens, uint32_t n, const FrameGeom& g, SyncSinks sinks, int32_t* d_status,
-                         uint32_t* d_nmcu_ok, DevBuf& retry, hipStream_t st, Fallback& fb,
+                         uint32_t* d_nmcu_ok, DevBuf& retry, hipStream_t st, Fallback& fb, int lanes, int heavy_lanes = 0,
                          const LayoutSpec& rec_layout = LayoutSpec{0u, 0u, 0u, 0u, 0u, nullptr}) {
     // Window per frame for the unstuffed scan in the global workspace: the frame's own chunk length + the zeroed tail of its
     // last 16-byte piece + a piece of slack, in 16-byte pieces laid out on the device (round 4; 5/16 byte per pixel for every
@@ -379,12 +392,25 @@ static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
                        retry_list, retry_count, st);
     }
     if (int r = check_launch(c, "unstuff")) return r;
-    {
+    unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
+    if (heavy_lanes && sinks.rec) {
+        if (int r = ensure(c, c->split, ((size_t)n * 2 + 8) * 4)) return r;   // [heavy count, light count, 6 spare | heavy list n | light list n]
+        uint32_t* split_count = (uint32_t*)c->split.p;
+        uint32_t *heavy = split_count + 8, *light = heavy + n;
+        HIP_TRY(c, hipMemsetAsync(split_count, 0, 32, st));
+        launch_split_by_weight(d_lens, n, (const uint32_t*)c->ws_line.p, heavy, light, split_count, st);
+        if (int r = check_launch(c, "split")) return r;
         Timed t(c, AMVHIP_K_HUFFMAN, st);
-        unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
+        // the heavy frames first: their launch is a few waves deep and as long as its slowest frame's chain, the light
+        // frames' launch behind it fills the chip
+        launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, heavy, split_count, g, (const uint32_t*)c->ws_line.p,
+                            heavy_lanes, c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 2, stats, c->cus, st);
+        launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, light, split_count + 1, g, (const uint32_t*)c->ws_line.p,
+                            lanes, c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1, stats, c->cus, st);
+    } else {
+        Timed t(c, AMVHIP_K_HUFFMAN, st);
         launch_huffman_sync((const uint32_t*)c->ws.p, (const uint32_t*)c->ws_bytes.p, n, nullptr, nullptr, g, (const uint32_t*)c->ws_line.p,
-                            sinks.rec ? (int)sinks.lanes : huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height),
-                            c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1, stats, c->cus, st);
+                            lanes, c->d_dec, sinks, d_status, d_nmcu_ok, retry_count + 1, stats, c->cus, st);
     }
     fb = Fallback{retry_list, retry_count, n};
     return check_launch(c, "huffman_sync");
@@ -405,7 +431,9 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     hipStream_t st = (hipStream_t)stream;
     SyncSinks sinks{d_coef, nullptr, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr};
     Fallback fb;
-    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu_ok, c->retry, st, fb)) return r;
+    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu_ok, c->retry, st, fb,
+                              huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height)))
+        return r;
     {   // the caller's array has a place for every frame: one launch, lines at the frames' own places
         Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
         launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, fb.list, fb.count, 0u,
@@ -492,6 +520,9 @@ static int decode_core(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes
         if (cap_lines > 0xffffffffull) cap_lines = 0xffffffffull;
     }
     const uint32_t lanes = (uint32_t)huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height);
+    // a batch that gets one lane per frame gives its heavy frames kHeavyLanes (entropy_front); AMVHIP_SPLIT=0: every frame one
+    const uint32_t heavy_lanes = lanes == 1u && c->split_heavy ? c->heavy_lanes : 0u;
+    const uint32_t tab_lanes = heavy_lanes ? heavy_lanes : lanes;       // a frame's row in lane_tab
     const uint32_t segs = ((g.mcu_cols + 9u) / 10u) * g.mcu_rows;
     // dense lines for a round of fall-back frames: by count (above), and never more than 2 GB of them -- at 640x480 a
     // block line is 128 bytes x 7 200 blocks, and 16 384 frames of that would be 15 GB kept for rounds that usually find nothing
@@ -507,14 +538,16 @@ static int decode_core(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes
     if (int r = ensure(c, b.rec_line, ((size_t)n + 1) * 4)) return r;
     const LayoutSpec rec_layout{4u, add_rec, hi_rec, 5u, (uint32_t)cap_lines, (uint32_t*)b.rec_line.p};   // laid out by entropy_front's launch
     if (int r = ensure(c, b.seg_start, (size_t)n * (segs + 1) * 8)) return r;
-    if (int r = ensure(c, b.lane_tab, (size_t)n * lanes * 16)) return r;
+    if (int r = ensure(c, b.lane_tab, (size_t)n * tab_lanes * 16)) return r;
     if (int r = ensure(c, b.rec_count, (size_t)n * 4)) return r;
-    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)b.rec.p, (const uint32_t*)b.rec_line.p, (uint32_t*)b.seg_start.p, (uint32_t*)b.lane_tab.p, lanes,
+    SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)b.rec.p, (const uint32_t*)b.rec_line.p, (uint32_t*)b.seg_start.p, (uint32_t*)b.lane_tab.p, tab_lanes,
                     (uint32_t*)b.rec_count.p, nullptr, nullptr};
     uint32_t* d_nmcu = (uint32_t*)b.nmcu.p;
     c->last_decode_retry = &b.retry;
     Fallback fb;
-    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu, b.retry, front, fb, rec_layout)) return r;
+    if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu, b.retry, front, fb, (int)lanes, (int)heavy_lanes,
+                              rec_layout))
+        return r;
     if (back != front) {
         HIP_TRY(c, hipEventRecord(c->ev_front, front));
         HIP_TRY(c, hipStreamWaitEvent(back, c->ev_front, 0));

@@ -19,6 +19,8 @@ ap.add_argument("--width", type=int, default=160)
 ap.add_argument("--height", type=int, default=120)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--serial", action="store_true")
+ap.add_argument("--noise", action="store_true", help="white-noise frames (every coefficient of every block non-zero)")
+ap.add_argument("--mixed", type=int, default=0, help="every k-th frame white noise")
 ap.add_argument("--same", type=int, default=-1, help="every frame of the batch is a copy of this frame (no spread in sync rounds)")
 a = ap.parse_args()
 pkg = entry.load_package()
@@ -26,7 +28,7 @@ ctx = pkg.Context(0)
 dev = "cuda:0"
 w, h, n = a.width, a.height, a.frames
 s = torch.cuda.current_stream().cuda_stream
-cap = max(1 << 20, n * w * h)
+cap = max(1 << 20, n * w * h * (2 if a.noise or a.mixed else 1))
 blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
 offs = torch.zeros(n, dtype=torch.int64, device=dev)
 lens = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -36,6 +38,15 @@ rgb = torch.empty((2000, h, w, 3), dtype=torch.uint8, device=dev)
 for lo in range(0, n, 2000):
     cnt = min(2000, n - lo)
     ctx.synth_frames_dev(0xA11CE, lo, cnt, w, h, rgb, s)
+    if a.noise:
+        torch.cuda.synchronize()
+        rgb[:cnt] = torch.randint(0, 256, (cnt, h, w, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+    if a.mixed:
+        torch.cuda.synchronize()
+        k = len(range(a.mixed - 1, cnt, a.mixed))
+        rgb[a.mixed - 1:cnt:a.mixed] = torch.randint(0, 256, (k, h, w, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
     ctx.encode_batch_dev(rgb, w * 3, 0, cnt, w, h, 0, blob[pos:], cap - pos, toffs, lens[lo:], s)
     torch.cuda.synchronize()
     offs[lo:lo + cnt] = toffs[:cnt] + pos
@@ -44,7 +55,6 @@ if a.same >= 0:
     offs[:] = offs[a.same].clone()
     lens[:] = lens[a.same].clone()
 nblk = ((w + 15) // 16) * ((h + 15) // 16) * 6
-coef = torch.empty((n, nblk, 64), dtype=torch.int16, device=dev)
 st = torch.empty(n, dtype=torch.int32, device=dev)
 ok = torch.empty(n, dtype=torch.int32, device=dev)
 out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8, device=dev)
