@@ -125,6 +125,7 @@ SYMBOLS = {
     "amvhip_synth_audio_dev": (_int, [_vp, _u32, _u64, _u64, _vp, _vp]),
     "amvhip_set_entropy_mode": (_int, [_vp, _int]),
     "amvhip_entropy_stats": (_int, [_vp, _int, _vp]),
+    "amvhip_decode_split_stats": (_int, [_vp, _vp]),
     "amvhip_adpcm_chain_stats": (_int, [_vp, _vp]),
     "amvhip_adpcm_quotient_table": (None, [_vp]),
     "amvhip_prof_enable": (None, [_vp, _int]),
@@ -324,6 +325,12 @@ class Context:
         return {"frames": out[0], "rounds": out[1], "max_rounds": out[2], "handed_to_serial": out[3], "waves": out[9],
                 "clocks_per_wave": {"zero": out[4] / waves, "first_walk": out[5] / waves, "sync_rounds": out[6] / waves,
                                     "write": out[7] / waves, "dc": out[8] / waves}}
+
+    def decode_split_stats(self):
+        """last decode call: {"heavy": frames that got several entropy lanes, "light": frames that got one} (0, 0: no split)"""
+        out = (ctypes.c_uint32 * 2)()
+        self._check(self.lib.amvhip_decode_split_stats(self.h, out), "decode_split_stats")
+        return {"heavy": int(out[0]), "light": int(out[1])}
 
     def adpcm_chain_stats(self):
         """last chained ADPCM encode: {"exhaustive": bool, "recoded": [chunks coded again in sweep 1, 2, ...]}"""

@@ -51,6 +51,7 @@ struct amvhip_ctx {
     int sync_lanes = 0;   // AMVHIP_SYNC_LANES: 8/16/32/64 lanes per frame; 0 = by batch size (huffman_sync_lanes)
     bool split_heavy = true;   // AMVHIP_SPLIT=0: a one-lane-per-frame batch keeps its heavy frames on one lane too
     uint32_t heavy_lanes = 16; // AMVHIP_SPLIT=n: lanes a heavy frame gets (1, 2, 4 ... 64)
+    bool last_split = false;   // the last decode call made the two lists (amvhip_decode_split_stats)
     uint32_t cus = 256;   // compute units of the device
     bool want_stats = false;
     double ws_bytes_per_frame = 0.0;
@@ -372,6 +373,7 @@ static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
     if (c->entropy_mode == AMVHIP_ENTROPY_SERIAL || g.blocks >= 16384u) {
         if (sinks.rec) HIP_TRY(c, hipMemsetAsync(sinks.rec_count, 0xff, (size_t)n * 4, st));   // every frame dense
         fb = Fallback{nullptr, nullptr, n};
+        c->last_split = false;
         return AMVHIP_OK;
     }
     if (int r = ensure(c, retry, ((size_t)n + 8) * 4)) return r;   // [retry count, task counter, 6 spare | retry list n]
@@ -393,6 +395,7 @@ static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
     }
     if (int r = check_launch(c, "unstuff")) return r;
     unsigned long long* stats = c->want_stats ? (unsigned long long*)c->stats.p : nullptr;
+    c->last_split = heavy_lanes && sinks.rec;
     if (heavy_lanes && sinks.rec) {
         if (int r = ensure(c, c->split, ((size_t)n * 2 + 8) * 4)) return r;   // [heavy count, light count, 6 spare | heavy list n | light list n]
         uint32_t* split_count = (uint32_t*)c->split.p;
@@ -1317,6 +1320,16 @@ extern "C" int amvhip_entropy_stats(amvhip_ctx* c, int enable, uint64_t out[10])
     }
     HIP_TRY(c, hipMemset(c->stats.p, 0, 128));
     c->want_stats = enable != 0;
+    return AMVHIP_OK;
+}
+
+extern "C" int amvhip_decode_split_stats(amvhip_ctx* c, uint32_t out[2]) {
+    if (!c || !out) return AMVHIP_ERR_ARG;
+    if (int r = use_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipDeviceSynchronize());
+    out[0] = out[1] = 0;
+    if (c->last_split && c->split.p) HIP_TRY(c, hipMemcpy(out, c->split.p, 8, hipMemcpyDeviceToHost));
     return AMVHIP_OK;
 }
 

@@ -279,6 +279,12 @@ int amvhip_set_entropy_mode(amvhip_ctx *ctx, int mode);
  * rounds, writing pass, DC pass, and the number of waves}, clears them and switches gathering on
  * or off (off by default; costs a few atomics per frame). */
 int amvhip_entropy_stats(amvhip_ctx *ctx, int enable, uint64_t out[10]);
+/* A batch large enough to give every frame ONE entropy lane (a wave's 64 frames then finish together) gives the frames
+ * whose chunk is over twice the batch's mean chunk several lanes each instead -- the split is made on the device, from
+ * d_lens.  out[] = {frames of the LAST decode call that went the several-lanes way, frames that went one lane per frame};
+ * {0, 0} when the call made no split (a smaller batch: every frame has several lanes anyway).  Synchronises the device.
+ * No analogue in the reference (its decoder takes one frame at a time, AMVDec.c:259). */
+int amvhip_decode_split_stats(amvhip_ctx *ctx, uint32_t out[2]);
 
 /* Stage access for parity tests: entropy stage only.  d_coef: n * nmcu*6*64 int16,
  * DC-predicted quantised coefficients in bitstream order (amvlib MCUBuffer,

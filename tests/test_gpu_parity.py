@@ -1862,6 +1862,92 @@ def test_mixed_stream_keeps_the_parallel_kernels(pkg, orc):
             c.close()
 
 
+def test_heavy_frames_get_several_lanes_in_a_one_lane_batch(pkg, orc):
+    """A batch that gets ONE entropy lane per frame (here forced: AMVHIP_SYNC_LANES=1; on a full-size batch by its size)
+    splits itself on the device: frames whose chunk is over twice the batch's mean go to the several-lanes kernel, the
+    others stay one lane per frame -- two frame lists, two launches, one record layout; the reconstruction reads every
+    frame's lane count from the frame.  Every byte and status equals the oracle's: a stream with a noise frame every
+    sixteenth, the same with the heavy frames in a block at either end, frames just under and just over the threshold,
+    a batch with nothing heavy in it, a batch of one, damaged heavy and light frames -- and the split reports what it
+    did (amvhip_decode_split_stats).  AMVHIP_SPLIT=0 / 8 / 64: no split, other lane counts: the same bytes."""
+    import os
+    w, h = 160, 120
+    rng = np.random.default_rng(20251)
+    light = _synth_chunks(orc, 6, w, h)
+    noise = [orc.encode_frame(rng.integers(0, 256, (h, w, 3)).astype(np.uint8), w, h) for _ in range(3)]
+    mild = [orc.encode_frame(np.clip(orc.synth_frame(SEED, t, w, h).astype(np.int32) + rng.integers(-a, a + 1, (h, w, 3)), 0, 255).astype(np.uint8), w, h)
+            for t, a in ((0, 8), (1, 16), (2, 24), (3, 40))]          # between the two: chunks of 1.2 .. 2.5 times a light one
+    damaged = []
+    for c in (noise[0], light[0]):
+        b = bytearray(c)
+        b[len(b) // 2] ^= 0x5a
+        b[len(b) // 2 + 1] = 0xff
+        damaged.append(bytes(b))
+        damaged.append(c[: len(c) // 3])
+    memo = {}
+
+    def want(c):
+        if c not in memo:
+            memo[c] = orc.decode_frame(c, w, h)
+        return memo[c]
+
+    batches = {
+        "every sixteenth": [noise[(i // 16) % 3] if i % 16 == 15 else light[i % 6] for i in range(400)],
+        "heavy first": [noise[i % 3] for i in range(70)] + [light[i % 6] for i in range(500)],
+        "heavy last": [light[i % 6] for i in range(500)] + [noise[i % 3] for i in range(70)],
+        "around the line": [(light + mild)[i % 10] for i in range(300)] + [noise[0]] * 5,
+        "nothing heavy": [light[i % 6] for i in range(200)],
+        "one frame": [noise[1]],
+        "damaged": [light[i % 6] for i in range(150)] + damaged + [noise[2]] * 3 + damaged[::-1],
+    }
+    old = {k: os.environ.get(k) for k in ("AMVHIP_SYNC_LANES", "AMVHIP_SPLIT")}
+    ctxs = {}
+    try:
+        os.environ["AMVHIP_SYNC_LANES"] = "1"
+        for split in (None, "0", "8", "64"):
+            if split is None:
+                os.environ.pop("AMVHIP_SPLIT", None)
+            else:
+                os.environ["AMVHIP_SPLIT"] = split
+            ctxs[split] = pkg.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        for name, chunks in batches.items():
+            exp = np.stack([want(c)[0] for c in chunks])
+            est = np.array([want(c)[1] for c in chunks], np.int32)
+            mean16 = sum((len(c) + 47) >> 4 for c in chunks) / len(chunks)
+            n_heavy = sum(((len(c) + 47) >> 4) > 2 * mean16 for c in chunks)       # the kernel's own rule (amv_split_kernel)
+            for split, c in ctxs.items():
+                got, st = _gpu_decode(c, chunks, w, h)
+                assert (st == est).all(), (name, split, np.nonzero(st != est)[0][:5])
+                assert (got == exp).all(), (name, split, np.nonzero((got != exp).reshape(len(chunks), -1).any(1))[0][:5])
+                sp = c.decode_split_stats()
+                if split == "0":
+                    assert sp == {"heavy": 0, "light": 0}, (name, sp)
+                else:
+                    assert sp == {"heavy": n_heavy, "light": len(chunks) - n_heavy}, (name, split, sp)
+            if name in ("every sixteenth", "heavy first", "heavy last", "around the line", "damaged"):
+                assert 0 < n_heavy < len(chunks), name
+            if name in ("nothing heavy", "one frame"):
+                assert n_heavy == 0, name
+        # a batch decoded with several lanes per frame anyway makes no split
+        plain = pkg.Context(0)
+        try:
+            got, st = _gpu_decode(plain, batches["every sixteenth"], w, h)
+            assert plain.decode_split_stats() == {"heavy": 0, "light": 0}
+            assert (got == np.stack([want(c)[0] for c in batches["every sixteenth"]])).all()
+        finally:
+            plain.close()
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
 def test_decode_lengths_that_overflow_the_layout(pkg, orc):
     """Chunk lengths are whatever the caller wrote: 20 consecutive frames claim ~4 GB each (a 32-bit prefix over one
     workgroup's 256 lengths would wrap after 16 of them, and a frame's workspace window would start below its
