@@ -852,10 +852,19 @@ __global__ __launch_bounds__(256) void amv_adpcm_settle_kernel(
 // The chain's own check, behind the last round: every chunk's bytes were coded from the start its state names (states are
 // replaced whole), so the stream is the sequential encoder's if and only if every chunk's start is its predecessor's end.
 // A chunk for which that does not hold -- none, unless the list handling above has a hole -- sends the stream down the
-// exhaustive route instead of out of the door.
-__global__ __launch_bounds__(256) void amv_adpcm_check_kernel(const uint2* __restrict__ state, uint32_t n, uint32_t* __restrict__ need_map) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x + 1u;
-    if (i < n && state[i].x != state[i - 1u].y) *need_map = 1u;
+// exhaustive route instead of out of the door.  And the BYTES are looked at, not only the states (round 5): the step index
+// in a chunk's header (adpcm.c:466, byte 2) is the start its nibbles were coded from by whichever lane wrote it last -- a chunk
+// two lanes coded at once from different readings of its predecessor's end (what the front sweep's `listed` bits are there
+// to prevent) can carry a header that is not its state's start, and a state still marked kPredicted has no bytes at all.
+__global__ __launch_bounds__(256) void amv_adpcm_check_kernel(const uint2* __restrict__ state, uint32_t n, const uint8_t* __restrict__ blob,
+                                                             const uint64_t* __restrict__ offs, const uint32_t* __restrict__ nsamp,
+                                                             uint32_t* __restrict__ need_map) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t start = state[i].x;
+    bool bad = i ? start != state[i - 1u].y : start != 0u;
+    bad = bad || (uint32_t)blob[offs[i] + 2u] != start;          // (start > 88 or kPredicted never equals a byte it wrote)
+    if (bad) *need_map = 1u;
 }
 
 // ---- the exhaustive route (queued behind the other; every kernel of it leaves at once unless *need says otherwise) ---
@@ -1204,7 +1213,7 @@ const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs,
                                list[(sweeps + 1u) & 1u], count + sweeps + 1u, list[sweeps & 1u], count + sweeps + 2u, count + 63);
         }
         // (settle == false: a test knob -- the chain is left where its launched sweeps got it, and the check has to notice)
-        hipLaunchKernelGGL(amv_adpcm_check_kernel, dim3((n + 254u) / 256u), dim3(256), 0, s, state, n, count + 63);
+        hipLaunchKernelGGL(amv_adpcm_check_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, state, n, blob, offs, nsamp, count + 63);
     }
     return count + 63;
 }

@@ -109,6 +109,8 @@ __device__ __forceinline__ void put(Emitter& e, uint32_t entry, int extra_bits, 
 // non-zero mask, the position coded last, whether the block's DC symbol is still to come, symbols left in the block.
 struct Cursor {
     uint32_t b, lo, hi, last, left;
+    uint32_t k6, cls;  // block in its MCU; 256 for a chroma block (blocks 4 and 5), else 0: which pair of code books
+    int dcv;           // the block's DC difference
     bool at_dc;
 };
 
@@ -138,8 +140,10 @@ __device__ __forceinline__ uint32_t nth_set_bit(uint32_t lo, uint32_t hi, uint32
 // symbol's number and DC difference in s_aux
 constexpr uint32_t kMaskBase = 60u * 128u;
 
-__device__ __forceinline__ void load_block(Cursor& c, const uint8_t* region) {
+// (everything about the block that a symbol needs is fetched here, once per block: mask, DC difference, code-book class)
+__device__ __forceinline__ void load_block(Cursor& c, const uint8_t* region, const uint32_t* aux) {
     const uint2 m = *reinterpret_cast<const uint2*>(region + kMaskBase + c.b * 8u);
+    c.dcv = (int)aux[c.b] >> 16;
     c.lo = m.x; c.hi = m.y; c.last = 0u; c.at_dc = true;
     c.left = symbols_of(m.x, m.y);
 }
@@ -151,7 +155,7 @@ __device__ __forceinline__ void load_block(Cursor& c, const uint8_t* region) {
 // different kinds would otherwise execute all three).
 template <int kMode>
 __device__ __forceinline__ void code_symbol(Emitter& e, Cursor& c, const uint8_t* region, const uint32_t* aux, const uint32_t* book) {
-    const uint32_t cls = (c.b % 6u) >= 4u ? 256u : 0u;
+    const uint32_t cls = c.cls;
     const bool coef = !c.at_dc && (c.lo | c.hi) != 0u;
     // the coefficient's position (0 when the symbol is not a coefficient: the DC's own place, read but not used)
     const bool low = c.lo != 0u;
@@ -162,7 +166,7 @@ __device__ __forceinline__ void code_symbol(Emitter& e, Cursor& c, const uint8_t
         else c.hi &= c.hi - 1u;
     }
     const int ac = *reinterpret_cast<const int16_t*>(region + line_offset(c.b, k));
-    int v = c.at_dc ? (int)aux[c.b] >> 16 : (coef ? ac : 0);
+    int v = c.at_dc ? c.dcv : (coef ? ac : 0);
     uint32_t run = coef ? k - c.last - 1u : 0u;
     c.last = coef ? k : c.last;
     const uint32_t* acbook = book + 512u + cls;
@@ -176,7 +180,9 @@ __device__ __forceinline__ void code_symbol(Emitter& e, Cursor& c, const uint8_t
     c.at_dc = false;
     if (--c.left == 0u) {
         ++c.b;
-        load_block(c, region);
+        c.k6 = c.k6 == 5u ? 0u : c.k6 + 1u;
+        c.cls = c.k6 >= 4u ? 256u : 0u;
+        load_block(c, region, aux);
     }
 }
 
@@ -188,7 +194,9 @@ __device__ __forceinline__ Cursor seek_symbol(uint32_t j, uint32_t nb, const uin
     for (uint32_t s = 32; s; s >>= 1)                  // the last block that starts at or before j
         if (b + s < nb && (aux[b + s] & 0xffffu) <= j) b += s;
     c.b = b;
-    load_block(c, region);
+    c.k6 = b % 6u;
+    c.cls = c.k6 >= 4u ? 256u : 0u;
+    load_block(c, region, aux);
     const uint32_t p = j - (aux[b] & 0xffffu);         // symbols of the block that lanes before this one code
     if (p) {
         c.at_dc = false;
@@ -230,7 +238,6 @@ __global__ __launch_bounds__(kLanes, 3) void amv_encode_frame_kernel(
     uint8_t* const out = tmp + (uint64_t)f * bound;
 
     const uint32_t segs = g.mcu_rows * nseg;
-    uint32_t carry = 0;                               // bits of the unfinished byte at the head of the window (0..7)
     uint32_t out_pos = 2;                             // bytes of the chunk written so far (FF D8 first)
     __syncthreads();
 
@@ -242,6 +249,42 @@ __global__ __launch_bounds__(kLanes, 3) void amv_encode_frame_kernel(
         cnt = has ? min(per_seg, g.mcu_cols - m0) : 0u;
         return has;
     };
+    // Whole bytes of the window's first `bits` bits leave for memory, 00 after every FF (escape_FF :282-336); after the
+    // frame's last round the tail is padded with ones first (ff_mjpeg_encode_stuffing :338-343).  The unfinished byte moves
+    // to the head of a cleared window; returns the bits it holds.  The whole workgroup calls it, behind a barrier.
+    auto flush = [&](uint32_t bits, bool final_round) -> uint32_t {
+        if (final_round && (bits & 7u)) {
+            if (tl == 0) atomicOr(&s_bits[bits >> 5], ((1u << (8u - (bits & 7u))) - 1u) << (24u - (bits & 24u)));
+            __syncthreads();
+        }
+        const uint32_t nbytes = final_round ? (bits + 7u) >> 3 : bits >> 3;
+        uint32_t ff_before = 0;
+        for (uint32_t w0 = 0; w0 * 4u < nbytes; w0 += kLanes) {
+            const uint32_t wi = w0 + tl;
+            const uint32_t word = wi * 4u < nbytes ? s_bits[wi] : 0u;
+            uint32_t ffs = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j)
+                ffs += (wi * 4u + j < nbytes && ((word >> (24u - 8u * j)) & 0xffu) == 0xffu) ? 1u : 0u;
+            uint32_t tile;
+            uint32_t o = out_pos + wi * 4u + ff_before + group_excl_sum(ffs, lane, wave, tile, s_part);
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                if (wi * 4u + j >= nbytes) break;
+                const uint32_t byte = (word >> (24u - 8u * j)) & 0xffu;
+                out[o++] = (uint8_t)byte;
+                if (byte == 0xffu) out[o++] = 0;
+            }
+            ff_before += tile;
+        }
+        out_pos += nbytes + ff_before;
+        const uint32_t rest = (final_round || !(bits & 7u)) ? 0u : (s_bits[nbytes >> 2] >> (24u - 8u * (nbytes & 3u))) & 0xffu;
+        __syncthreads();
+        for (uint32_t i = tl; i * 32u < bits + 32u && i < kWindowWords; i += kLanes) s_bits[i] = i == 0u ? rest << 24 : 0u;
+        __syncthreads();
+        return final_round ? 0u : bits & 7u;
+    };
+    uint32_t pending = 0;                             // bits in the window
     for (uint32_t s0 = 0, round = 0; s0 < segs; s0 += kWaves, ++round) {
         const uint32_t s = s0 + wave;
         uint32_t my, m0, cnt;
@@ -304,14 +347,24 @@ __global__ __launch_bounds__(kLanes, 3) void amv_encode_frame_kernel(
         if (mine.nacc && mine.wi < kOwnWords) mine.words[mine.wi * kLanes] = (uint32_t)(mine.acc << (32 - mine.nacc));
         const uint32_t nbits = mine.nbits;
 
-        // ---- 3. where the run's bits go
+        // ---- 3. where the run's bits go.  The window holds the bits of several rounds (a round of the bench stream is ~10 000
+        // bits of its 40 960): bytes leave only when it is more than half full or the frame ends -- one pass of step 5 (its
+        // FF count is a workgroup-wide prefix sum: two barriers per tile, a fifth of a round's barriers) per two or three
+        // rounds instead of per round: 0.10 ms of the kernel's 1.43 per 8 000 frames of 320x240 were that pass.
         uint32_t round_bits;
-        const uint32_t pos = carry + group_excl_sum(nbits, lane, wave, round_bits, s_part);
-        const uint32_t total = carry + round_bits;                // bits in the window after this round
-        if (total > kWindowWords * 32u) {                         // (the whole workgroup) the one-lane-per-frame route takes the frame
-            if (tl == 0) retry_list[atomicAdd(retry_count, 1u)] = f;
-            return;
+        const uint32_t before = group_excl_sum(nbits, lane, wave, round_bits, s_part);
+        if (pending + round_bits > kWindowWords * 32u) {          // (the whole workgroup) what is waiting leaves first
+            if (pending >= 8u) {
+                __syncthreads();                                   // the rounds before have been copied
+                pending = flush(pending, false);
+            }
+            if (pending + round_bits > kWindowWords * 32u) {      // a round that does not fit the window by itself: the one-lane-per-frame route
+                if (tl == 0) retry_list[atomicAdd(retry_count, 1u)] = f;
+                return;
+            }
         }
+        const uint32_t pos = pending + before;
+        const uint32_t total = pending + round_bits;               // bits in the window after this round
 
         // ---- 4. ... and the copy: out of the scratch 32 bits at a time, or a second walk for a run that overflowed it
         if (nbits <= kOwnWords * 32u) {
@@ -331,41 +384,14 @@ __global__ __launch_bounds__(kLanes, 3) void amv_encode_frame_kernel(
             for (uint32_t j = j0; j < j1; ++j) code_symbol<kShared>(e, cur, region, aux, s_book);
             if (e.nacc) atomicOr(&e.words[e.wi], (uint32_t)(e.acc << (32 - e.nacc)));
         }
-        __syncthreads();
 
-        // ---- 5. whole bytes out, 00 after every FF; after the last round the tail is padded with ones first
+        // ---- 5. whole bytes out (flush, above the loop) once the window is more than half full, and at the frame's end
         const bool final_round = s0 + kWaves >= segs;
-        if (final_round && (total & 7u)) {
-            if (tl == 0) atomicOr(&s_bits[total >> 5], ((1u << (8u - (total & 7u))) - 1u) << (24u - (total & 24u)));
-            __syncthreads();
+        pending = total;
+        if (final_round || total > kWindowWords * 16u) {
+            __syncthreads();                                       // every run of the round is in the window
+            pending = flush(total, final_round);
         }
-        const uint32_t nbytes = final_round ? (total + 7u) >> 3 : total >> 3;
-        uint32_t ff_before = 0;
-        for (uint32_t w0 = 0; w0 * 4u < nbytes; w0 += kLanes) {
-            const uint32_t wi = w0 + tl;
-            const uint32_t word = wi * 4u < nbytes ? s_bits[wi] : 0u;
-            uint32_t ffs = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j)
-                ffs += (wi * 4u + j < nbytes && ((word >> (24u - 8u * j)) & 0xffu) == 0xffu) ? 1u : 0u;
-            uint32_t tile;
-            uint32_t o = out_pos + wi * 4u + ff_before + group_excl_sum(ffs, lane, wave, tile, s_part);
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                if (wi * 4u + j >= nbytes) break;
-                const uint32_t byte = (word >> (24u - 8u * j)) & 0xffu;
-                out[o++] = (uint8_t)byte;
-                if (byte == 0xffu) out[o++] = 0;
-            }
-            ff_before += tile;
-        }
-        out_pos += nbytes + ff_before;
-        // the unfinished byte moves to the head of a cleared window
-        const uint32_t rest = (final_round || !(total & 7u)) ? 0u : (s_bits[nbytes >> 2] >> (24u - 8u * (nbytes & 3u))) & 0xffu;
-        __syncthreads();
-        for (uint32_t i = tl; i * 32u < total + 32u && i < kWindowWords; i += kLanes) s_bits[i] = i == 0u ? rest << 24 : 0u;
-        carry = final_round ? 0u : total & 7u;
-        __syncthreads();
     }
     if (tl == 0) {
         out[0] = 0xff; out[1] = 0xd8;                              // SOI only, mjpegenc.c:201-204

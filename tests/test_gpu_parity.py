@@ -1538,6 +1538,21 @@ def test_adpcm_index_chain_many_streams(ctx, orc):
             blob = np.full(int(offs[-1]), 0xEE, np.uint8)
             ctx.adpcm_encode_batch(pcm, pcm.size, pcm_offs[:-1].copy(), np.array(sizes, np.uint32), n, None, blob, blob.size, offs[:-1].copy())
             assert blob.tobytes() == want, (it, rep, n, ctx.adpcm_chain_stats())
+        # the property that makes a stream the sequential encoder's, read off the BYTES alone (adpcm.c:461-498 carries
+        # step_index from chunk to chunk): the index in a chunk's header is where the DECODER's index stands at the end of
+        # the chunk before -- checked with the device's own decoder, which knows nothing of the encoder's bookkeeping
+        lens = np.array([8 + s // 2 for s in sizes], np.uint32)
+        out_offs = np.cumsum([0] + [2 * (int(l) - 8) for l in lens]).astype(np.uint64)
+        dec = np.zeros(int(out_offs[-1]) + 8, np.int16)
+        fin = np.full((n, 2), -7, np.int32)
+        ctx.adpcm_decode_batch(blob, blob.size, offs[:-1].copy(), lens, n, dec, dec.size, out_offs[:-1].copy(), fin)
+        head = blob[offs[:-1].astype(np.int64) + 2].astype(np.int32)
+        assert head[0] == 0
+        carried = 0
+        for i in range(n):
+            assert head[i] == carried, (it, i)
+            if sizes[i]:
+                carried = int(fin[i, 1])
 
 
 def test_adpcm_full_size_chain_against_exhaustive_route(pkg, orc):

@@ -38,5 +38,7 @@ for it in range(a.steps + 2):
     ctx.adpcm_encode_batch_dev(pcm, pcm_offs, nsamp, n, None, chunks, offs, s)
 torch.cuda.synchronize()
 launches, ms = ctx.prof_read(pkg.K_ADPCM_ENC)
-print(json.dumps({"lib": os.path.basename(pkg.LIB_PATH), "chunks": n, "encode_ms": ms / max(launches, 1),
+stats = ctx.adpcm_chain_stats()
+print(json.dumps({"lib": os.path.basename(pkg.LIB_PATH), "chunks": n, "encode_ms": ms / max(launches, 1), "sweeps_env": os.environ.get("AMVHIP_ADPCM_SWEEPS"),
+                  "exhaustive": stats["exhaustive"], "recoded": stats["recoded"][:12],
                   "checksum": int(chunks.to(torch.int64).sum().item())}))
