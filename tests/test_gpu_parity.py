@@ -1729,20 +1729,25 @@ def test_c_host_shards_a_stream_over_contexts(pkg, amv1, tmp_path):
 def test_amvlib_adpcm_stereo_decode(ctx, pkg, orc):
     """AdpcmImaDecodeFrame with channel == 2 (AdpcmIma.c:222-237): of every 8 input bytes the first 4 are the left
     channel's nibbles, the last 4 the right's, each channel with a state of its own, samples interleaved L R; the
-    8-byte stride reads up to 7 bytes past buf_size (taken as zero).  Against the reference's own AdpcmIma.c object
-    where it is built (oracle/_ref), and against the oracle's mono decoder channel by channel; the context's state
-    carries from call to call."""
+    8-byte stride reads up to 7 bytes past buf_size (taken as zero).  Against what the REFERENCE's own AdpcmIma.c object made
+    of the same seeded inputs (tests/golden/ref_adpcm_stereo.json, written here from oracle/_ref by
+    tests/golden/make_ref_golden.py: the compiled reference is not loaded on the GPU box), and against the oracle's mono
+    decoder channel by channel; the context's state carries from call to call."""
+    import json
+    import os
+    from conftest import ROOT
+    sys_path_golden = os.path.join(ROOT, "tests", "golden")
+    fixture = json.load(open(os.path.join(sys_path_golden, "ref_adpcm_stereo.json")))
     lib = pkg.load_library()
-    R = orc.ref()
-    rng = np.random.default_rng(23)
-    for size in (8, 16, 689, 690, 1000, 1378, 5):
+    rng = np.random.default_rng(fixture["seed"])
+    for case in fixture["cases"]:
+        size = case["size"]
         buf = rng.integers(0, 256, size, dtype=np.uint8)
         n8 = (size + 7) & ~7
-        mine, ref = pkg.ADPCMContext(), orc.RefADPCMContext()
-        for c in (mine, ref):
-            c.channel = 2
-            c.status[0].predictor, c.status[0].step_index = -1234, 17
-            c.status[1].predictor, c.status[1].step_index = 30000, 80
+        mine = pkg.ADPCMContext()
+        mine.channel = 2
+        for ch in (0, 1):
+            mine.status[ch].predictor, mine.status[ch].step_index = fixture["start"][ch]
         for call in range(2):                                  # the second call starts from the state the first left
             got = np.zeros(2 * n8 + 16, np.int16)
             dl = ctypes.c_int(0)
@@ -1760,13 +1765,10 @@ def test_amvlib_adpcm_stereo_decode(ctx, pkg, orc):
                 ends.append(int(pcm[n8 - 1]))
             assert (got[: 2 * n8] == want).all(), (size, call)
             assert [mine.status[0].predictor, mine.status[1].predictor] == ends
-            if R is not None:
-                theirs = np.zeros(2 * n8 + 16, np.int16)
-                dl2 = ctypes.c_int(0)
-                pad = np.concatenate([buf, np.zeros(16, np.uint8)])        # the reference reads past buf_size: give it zeros
-                assert R.AdpcmImaDecodeFrame(ctypes.byref(ref), theirs.ctypes.data, ctypes.byref(dl2), pad.ctypes.data, size) == n8
-                assert dl2.value == dl.value and (theirs[: 2 * n8] == got[: 2 * n8]).all(), (size, call)
-                assert all((ref.status[ch].predictor, ref.status[ch].step_index) == (mine.status[ch].predictor, mine.status[ch].step_index) for ch in (0, 1))
+            theirs = case["calls"][call]                       # the reference's own run of this call
+            assert theirs["rc"] == rc and theirs["declen"] == dl.value, (size, call)
+            assert "%016x" % orc.fnv1a64(orc.FNV_BASIS, got[: 2 * n8].view(np.uint8)) == theirs["pcm_fnv"], (size, call)
+            assert [[mine.status[ch].predictor, mine.status[ch].step_index] for ch in (0, 1)] == theirs["end"], (size, call)
 
 
 def test_encode_yuv422_entry(ctx, orc):

@@ -473,3 +473,17 @@ def test_plane_encoders_are_the_rgb_encoder_behind_its_conversion(orc):
     out = np.zeros((1, 65536), np.uint8)
     L.amvo_yuv422_to_420(pairs.ctypes.data, 65536, 65536, 2, out.ctypes.data, 65536)
     assert (out[0] == ((a.ravel().astype(np.uint16) + b.ravel() + 1) >> 1)).all()
+
+
+def test_reference_stereo_fixture_is_what_the_reference_build_makes(orc):
+    """tests/golden/ref_adpcm_stereo.json (what the GPU test compares AdpcmImaDecodeFrame's stereo path with, so that the
+    compiled reference object need not be loaded on the GPU box) is regenerated here from oracle/_ref and must equal the
+    committed file; skipped where the reference tree is not at hand."""
+    import importlib.util
+    if orc.ref() is None:
+        pytest.skip("oracle/_ref is not built here")
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("make_ref_golden", os.path.join(ROOT, "tests", "golden", "make_ref_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.compute() == json.load(open(os.path.join(ROOT, "tests", "golden", "ref_adpcm_stereo.json")))

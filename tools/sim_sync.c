@@ -197,7 +197,7 @@ static uint32_t pool_rounds(const uint8_t *bits, uint32_t nb, uint32_t L, uint32
  * walks; per round a share lists its final start or else up to g_pend candidates (arrivals in the left share's memo it has
  * not walked from, newest first) and seeds; a share's first task is its own lane's, the others go to lanes without a task,
  * in lane order. */
-static int g_pend = 4, g_seedres = 1, g_variant = 0;
+static int g_pend = 4, g_seedres = 1, g_variant = 0, g_front_only_from = 0;
 static uint32_t kernel_rounds(const uint8_t *bits, uint32_t nb, uint32_t L, uint32_t S, const st3 *truth, uint32_t *walks)
 {
     static bigmemo_t memo[64];
@@ -243,7 +243,7 @@ static uint32_t kernel_rounds(const uint8_t *bits, uint32_t nb, uint32_t L, uint
         uint32_t p[64] = {0};
         for (uint32_t i = 0; i + 1 < L; i++) {
             if (fin[i] == 1) { pend[i][0] = fin_code[i]; p[i] = 1; }
-            else if (fin[i] == 0) {
+            else if (fin[i] == 0 && !(g_front_only_from && r + 1 >= (uint32_t)g_front_only_from)) {
                 const int room = g_cap - memo[i].n;
                 const uint32_t most = (uint32_t)(room < g_pend ? (room < 0 ? 0 : room) : g_pend);
                 for (int q = memo[i - 1].n - 1; q >= 0; q--) {
@@ -298,6 +298,7 @@ int main(int argc, char **argv)
     if (getenv("SIM_PEND")) g_pend = atoi(getenv("SIM_PEND"));
     if (getenv("SIM_SEEDRES")) g_seedres = atoi(getenv("SIM_SEEDRES"));
     if (getenv("SIM_VARIANT")) g_variant = atoi(getenv("SIM_VARIANT"));
+    if (getenv("SIM_FRONT_ONLY")) g_front_only_from = atoi(getenv("SIM_FRONT_ONLY"));
     uint64_t cap = (uint64_t)n * w * h;
     uint8_t *blob = malloc(cap);
     uint64_t *offs = malloc(n * 8);
