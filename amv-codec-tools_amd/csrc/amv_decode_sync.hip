@@ -1588,13 +1588,17 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     const uint64_t waves = (uint64_t)cus * 10u;
     int fill = 8;                                  // small batch: as many lanes as keep every task resident ...
     if (n <= waves) fill = 64;
-    else if (2u * n <= 3u * waves) fill = 32;
+    else if (n <= 2u * waves) fill = 32;
     else if (n <= 4u * waves) fill = 16;
-    // ... but no share much shorter than the synchronisation length, or the re-walk rounds take over (160x120, lanes
-    // 16 / 32 / 64: 1 250 frames 0.32 / 0.27 / 0.33 ms with 2.5 / 5.1 / 10.3 rounds, 2 500: 0.37 / 0.34 / 0.46,
-    // 5 000: 0.38 / 0.41 / 0.56; 320x240, 2 000 frames: 0.51 / 0.35 / 0.32)
+    // ... but no share much shorter than the synchronisation length, or the re-walk rounds take over.  Round 5 (lanes that
+    // remember their walks, finality by prefix scan, idle lanes walking candidates), 160x120, lanes 8 / 16 / 32 / 64:
+    // 1 250 frames 0.45 / 0.31 / 0.24 / 0.22 ms with 1.2 / 2.2 / 3.5 / 5.3 rounds, 2 500: 0.45 / 0.33 / 0.25 / 0.29,
+    // 5 000: 0.46 / 0.36 / 0.31 / 0.43, 10 000: 0.53 / 0.45 / 0.45 / 0.70, 20 000: 0.68 / 0.69 / 0.83 / 1.20;
+    // 320x240, lanes 16 / 32 / 64: 500 frames 0.53 / 0.36 / 0.26, 2 000: 0.54 / 0.38 / 0.33, 8 000: 0.72 / 0.77 / 0.83
+    // (round 4's kernel: 1 250 frames 0.32 / 0.27 / 0.33 with 16 / 32 / 64, 2 500: 0.37 / 0.34 / 0.46, 5 000: 0.38 / 0.41 / 0.56)
     int cap = 8;
     while (cap < 64 && (uint64_t)cap * 2u * 500u <= pixels) cap *= 2;
+    if (2u * (uint64_t)n <= waves) cap = 64;      // half a generation of waves or less: the shortest shares still win
     if (fill > cap) fill = cap;
     return fill > full ? fill : full;
 }

@@ -9,7 +9,7 @@ import shutil
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 for name in ("bench", "bench_encode", "bench_coresident", "bench_adpcm", "bench_amvlib", "bench_decode320", "bench_decode10k",

@@ -2,13 +2,16 @@
 # The measurement set of a round, on the GPU box (through gpurun): bench lines of every workload, the
 # rocprofv3 kernel statistics of the bench commands, the two HBM-traffic PMC passes of the default one and the SQ
 # counter passes of the decode kernels.
-# usage: tools/profile_round.sh <tag>      (outputs under gpurun_out/<tag>_*; tools/collect_profiles.py copies the
-#                                           summaries to profiles/)
+# usage: tools/profile_round.sh <tag> [bench|stats|pmc|sq|all]   (outputs under gpurun_out/<tag>_*;
+#                                           tools/collect_profiles.py copies the summaries to profiles/; the parts fit
+#                                           one gpurun call each)
 set -e
-tag=${1:-r04}
+tag=${1:-r05}
+part=${2:-all}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd $root
+if [ $part = all ] || [ $part = bench ]; then
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 python3 bench.py --workload encode > $out/${tag}_bench_encode.json 2>> $out/${tag}_bench.err
 python3 bench.py --workload coresident > $out/${tag}_bench_coresident.json 2>> $out/${tag}_bench.err
@@ -20,12 +23,16 @@ python3 bench.py --strong --frames 20000 --no-cpu-baseline > $out/${tag}_bench_s
 python3 bench.py --stream mixed --no-secondary > $out/${tag}_bench_mixed.json 2>> $out/${tag}_bench.err
 python3 bench.py --stream amv1 --frames 200000 --no-secondary > $out/${tag}_bench_amv1.json 2>> $out/${tag}_bench.err
 echo "benches done"
+fi
 cd /tmp && export TMPDIR=/tmp
+if [ $part = all ] || [ $part = stats ]; then
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o run --output-format csv -- python3 $root/bench.py --no-cpu-baseline --no-secondary > $out/${tag}_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_encode -o run --output-format csv -- python3 $root/bench.py --workload encode --no-cpu-baseline > $out/${tag}_stats_encode.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_coresident -o run --output-format csv -- python3 $root/bench.py --workload coresident --no-cpu-baseline > $out/${tag}_stats_coresident.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats_adpcm -o run --output-format csv -- python3 $root/bench.py --workload adpcm --no-cpu-baseline > $out/${tag}_stats_adpcm.log 2>&1
 echo "stats done"
+fi
+if [ $part = all ] || [ $part = pmc ]; then
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o run --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write -o run --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $out/${tag}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch_encode -o run --output-format csv -- python3 $root/bench.py --workload encode --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch_encode.log 2>&1
@@ -35,7 +42,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write_decode320 -o 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch_adpcm -o run --output-format csv -- python3 $root/bench.py --workload adpcm --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch_adpcm.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write_adpcm -o run --output-format csv -- python3 $root/bench.py --workload adpcm --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write_adpcm.log 2>&1
 echo "pmc done"
+fi
+if [ $part = all ] || [ $part = sq ]; then
 bash $root/tools/pmc_sq.sh ${tag}sq 160000
 bash $root/tools/pmc_sq_bench.sh ${tag}sqenc --workload encode
 bash $root/tools/pmc_sq_bench.sh ${tag}sqadpcm --workload adpcm
+fi
 echo done
