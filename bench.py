@@ -416,34 +416,7 @@ def run_decode(E, args):
     if E.dist:          # config 4 as BASELINE.json states it, beside the weak-scaling line above
         result["config"]["scaling_modes"] = {"weak": "value / ms_per_step of this line: every GPU decodes its own %d frames" % n,
                                              "strong": "config4_strong_10k (flat: strong10k_*)"}
-        # The exchange has never met more than one GPU.  Whatever happens to it, the weak line above goes
-        # out -- and the run then ENDS NON-ZERO: a hang (a send nobody receives) or a device / RCCL error is a finding, never
-        # a clean run.  The verdict is a flat scalar, strong10k_status = "ok" | "error: ..." | "hung in <phase>".
-        import threading
-        done = threading.Event()
-        E.strong_phase = "setup"
-
-        def bail():
-            if done.wait(STRONG_LEG_SECONDS):
-                return
-            result["config"].update(strong_flat(None, "hung in %s on rank %d: no end after %g s" % (E.strong_phase, E.rank, STRONG_LEG_SECONDS)))
-            if E.rank == 0 and E.json_fd is not None:
-                os.write(E.json_fd, (json.dumps(result) + "\n").encode())
-            os.write(2, ("bench.py: rank %d: strong-scaling leg hung in phase %r; line written, leaving with code %d\n"
-                         % (E.rank, E.strong_phase, EXIT_HUNG)).encode())
-            os._exit(EXIT_HUNG)
-
-        threading.Thread(target=bail, daemon=True).start()
-        strong = None
-        try:
-            strong = run_strong(E, args, w, h)
-            status = "ok"
-        except Exception as e:                       # (SystemExit -- the gate -- is not an Exception)
-            status = "error: %s in %s: %s" % (type(e).__name__, E.strong_phase, str(e)[:300])
-            E.failed = status                        # the line goes out, then main() leaves non-zero
-        done.set()
-        result["config"].update(strong_flat(strong, status))
-        result["config"]["config4_strong_10k"] = strong if strong is not None else {"failed": status}
+        guarded_strong(E, result, lambda: run_strong(E, args, w, h))
 
     if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
         m = min(args.cpu_sample, n)
@@ -468,6 +441,54 @@ def run_decode(E, args):
 
 
 # ---------------------------------------------------------------------------------------------
+def guarded_strong(E, result, body, seconds=None):
+    """The exchange has never met more than one GPU.  Whatever happens to it, the weak line in `result`
+    goes out -- and the run then ENDS NON-ZERO: a hang (a send nobody receives) or a device / RCCL error is a finding, never
+    a clean run.  The verdict is a flat scalar, strong10k_status = "ok" | "error: ..." | "hung in <phase> on rank r".
+    body() -> the strong leg's dictionary.  An exception is recorded and E.failed set (write_line_and_leave exits with
+    EXIT_FAILED behind the line); no end within `seconds`: this rank's watchdog writes the line (rank 0) and leaves with
+    EXIT_HUNG.  SystemExit -- a gate's verdict -- passes through."""
+    import threading
+    seconds = STRONG_LEG_SECONDS if seconds is None else seconds
+    done = threading.Event()
+    E.strong_phase = "setup"
+
+    def bail():
+        if done.wait(seconds):
+            return
+        result["config"].update(strong_flat(None, "hung in %s on rank %d: no end after %g s" % (E.strong_phase, E.rank, seconds)))
+        result["config"] = ordered_config(result["config"])
+        if E.rank == 0 and E.json_fd is not None:
+            os.write(E.json_fd, (json.dumps(result) + "\n").encode())
+        os.write(2, ("bench.py: rank %d: strong-scaling leg hung in phase %r; line written, leaving with code %d\n"
+                     % (E.rank, E.strong_phase, EXIT_HUNG)).encode())
+        os._exit(EXIT_HUNG)
+
+    threading.Thread(target=bail, daemon=True).start()
+    strong = None
+    try:
+        strong = body()
+        status = "ok"
+    except Exception as e:                       # (SystemExit is not an Exception)
+        status = "error: %s in %s: %s" % (type(e).__name__, E.strong_phase, str(e)[:300])
+        E.failed = status                        # the line goes out, then write_line_and_leave() leaves non-zero
+    done.set()
+    result["config"].update(strong_flat(strong, status))
+    result["config"]["config4_strong_10k"] = strong if strong is not None else {"failed": status}
+
+
+def write_line_and_leave(E, result):
+    """rank 0 writes the one JSON line; a run whose strong leg failed then leaves at once with EXIT_FAILED (the line is out; the
+    communicator may be in no state to be torn down).  Returns normally otherwise."""
+    result["config"] = ordered_config(result["config"])
+    if E.rank == 0:
+        sys.stdout.flush()
+        os.write(E.json_fd, (json.dumps(result) + "\n").encode())
+    if E.failed:
+        os.write(2, ("bench.py: rank %d: %s -- leaving with code %d\n" % (E.rank, E.failed, EXIT_FAILED)).encode())
+        os._exit(EXIT_FAILED)
+
+
 def run_strong(E, args, w, h, n_total=10000):
     """BASELINE.json configs[3] as it is stated: ONE 10 000-frame 160x120 stream, held by rank 0 in HBM, frame-sharded
     over the ranks: scatter-v of the chunks over RCCL, per-rank decode through the C ABI, gather of the BGR frames back
@@ -1113,15 +1134,7 @@ def main():
         result = run_amvlib(E, args)
     else:
         result = run_adpcm(E, args, with_video=False)
-    result["config"] = ordered_config(result["config"])
-    if E.rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(result) + "\n").encode())
-    if E.failed:
-        # the line is out; a leg that raised a device / RCCL error must not read as a clean run, and the communicator may be
-        # in no state to be torn down: leave at once
-        os.write(2, ("bench.py: rank %d: %s -- leaving with code %d\n" % (E.rank, E.failed, EXIT_FAILED)).encode())
-        os._exit(EXIT_FAILED)
+    write_line_and_leave(E, result)
     E.ctx.close()
     if E.dist:
         dist.destroy_process_group()

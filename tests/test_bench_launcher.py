@@ -108,3 +108,68 @@ def test_config_head_fits_the_window_that_records_keep():
     assert list(cfg) == ["workload", "enc320_fps", "zzz", "secondary"]
     flat = bench.strong_flat(None, "hung in setup on rank 0")
     assert flat["strong10k_status"].startswith("hung") and flat["strong10k_ms"] is None and "rccl_ranks" in flat
+
+
+def _guard_script(tmp_path, body):
+    path = tmp_path / "guard.py"
+    path.write_text(textwrap.dedent("""
+        import json, os, sys, time
+        sys.path.insert(0, %r)
+        import bench
+        E = bench.Env()
+        E.rank, E.world, E.json_fd = int(os.environ.get("RANK", "0")), 2, 1
+        result = {"metric": "weak line", "value": 1.0, "config": {"zzz": 1, "workload": "w"}}
+    """ % ROOT) + textwrap.dedent(body))
+    return str(path)
+
+
+def test_strong_leg_error_is_a_flat_status_and_a_nonzero_exit(tmp_path):
+    """an exception of the exchange (how a device or RCCL fault surfaces): the weak line still goes out, with
+    strong10k_status = "error: ..." as a flat scalar in front of it, and the process leaves with EXIT_FAILED -- not 0"""
+    script = _guard_script(tmp_path, """
+        def body():
+            E.strong_phase = "timed exchange"
+            raise RuntimeError("HIP error: an illegal memory access was encountered")
+        bench.guarded_strong(E, result, body)
+        bench.write_line_and_leave(E, result)
+        print("not reached")
+    """)
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 4, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "not reached" not in r.stdout
+    assert line["metric"] == "weak line" and line["value"] == 1.0
+    assert line["config"]["strong10k_status"].startswith("error: RuntimeError in timed exchange: HIP error")
+    assert line["config"]["strong10k_ms"] is None and list(line["config"])[0] == "workload"
+    assert list(line["config"]).index("strong10k_status") < list(line["config"]).index("zzz")
+
+
+def test_strong_leg_hang_writes_the_line_and_leaves_with_its_own_code(tmp_path):
+    """a send nobody receives: the watchdog writes the line (rank 0) with strong10k_status = "hung in <phase> on rank r" and
+    leaves with EXIT_HUNG; a rank other than 0 leaves with the same code and writes nothing"""
+    script = _guard_script(tmp_path, """
+        def body():
+            E.strong_phase = "first exchange (scatter / decode / gather)"
+            time.sleep(600)
+        bench.guarded_strong(E, result, body, seconds=1.0)
+    """)
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["strong10k_status"].startswith("hung in first exchange (scatter / decode / gather) on rank 0")
+    assert line["value"] == 1.0
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=120, env=dict(os.environ, RANK="1"))
+    assert r.returncode == 3 and r.stdout.strip() == ""
+
+
+def test_strong_leg_ok_path_keeps_going(tmp_path):
+    script = _guard_script(tmp_path, """
+        bench.guarded_strong(E, result, lambda: {"ms_per_step": 0.9, "frames_per_s": 1.1e7, "rccl_ranks": 2,
+                                                   "phase_ms_max_over_ranks": {"scatter": 0.1, "decode": 0.5, "gather": 0.3}})
+        bench.write_line_and_leave(E, result)
+        print("reached")
+    """)
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "reached"
+    cfg = json.loads(r.stdout.strip().splitlines()[0])["config"]
+    assert cfg["strong10k_status"] == "ok" and cfg["rccl_ranks"] == 2 and cfg["strong10k_gather_ms"] == 0.3
