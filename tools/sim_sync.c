@@ -197,7 +197,7 @@ static uint32_t pool_rounds(const uint8_t *bits, uint32_t nb, uint32_t L, uint32
  * walks; per round a share lists its final start or else up to g_pend candidates (arrivals in the left share's memo it has
  * not walked from, newest first) and seeds; a share's first task is its own lane's, the others go to lanes without a task,
  * in lane order. */
-static int g_pend = 4, g_seedres = 1, g_variant = 0, g_front_only_from = 0;
+static int g_pend = 4, g_seedres = 1, g_variant = 0, g_front_only_from = 0, g_seeds = 5;
 static uint32_t kernel_rounds(const uint8_t *bits, uint32_t nb, uint32_t L, uint32_t S, const st3 *truth, uint32_t *walks)
 {
     static bigmemo_t memo[64];
@@ -254,6 +254,11 @@ static uint32_t kernel_rounds(const uint8_t *bits, uint32_t nb, uint32_t L, uint
                 }
                 if (g_variant == 0)
                     while (seeded[i] < 5 && p[i] + g_seedres < most) { seeded[i]++; pend[i][p[i]++] = (st3){i * S, 0, (uint32_t)seeded[i]}; }
+                else if (g_variant == 4)      /* more seeds: the six block positions at bit offsets 0, 3, 6, ... of the share's start */
+                    while (seeded[i] < g_seeds && p[i] + g_seedres < most) {
+                        seeded[i]++;
+                        pend[i][p[i]++] = (st3){i * S + 3u * (uint32_t)(seeded[i] / 6), 0, (uint32_t)(seeded[i] % 6)};
+                    }
                 else if (memo[i - 1].n) {
                     /* phase variants of an arrival at the end of the share before: variant 1 the newest, 2 the oldest (the guess's) */
                     const st3 c0 = memo[i - 1].a[g_variant == 1 ? memo[i - 1].n - 1 : 0];
@@ -299,6 +304,7 @@ int main(int argc, char **argv)
     if (getenv("SIM_SEEDRES")) g_seedres = atoi(getenv("SIM_SEEDRES"));
     if (getenv("SIM_VARIANT")) g_variant = atoi(getenv("SIM_VARIANT"));
     if (getenv("SIM_FRONT_ONLY")) g_front_only_from = atoi(getenv("SIM_FRONT_ONLY"));
+    if (getenv("SIM_SEEDS")) g_seeds = atoi(getenv("SIM_SEEDS"));
     uint64_t cap = (uint64_t)n * w * h;
     uint8_t *blob = malloc(cap);
     uint64_t *offs = malloc(n * 8);
