@@ -24,13 +24,18 @@
 //      stall every lane to its right until exact states arrive one lane per round): it slips a
 //      bit / closes the block and carries on.  The true decoder of a valid stream never takes
 //      those branches, and a stream with a real error is caught in pass 4, which is strict;
-//   2. every lane takes its left neighbour's arrival state as its start state and walks again if
-//      that changed.  Lane 0's start is exact, so after round r lanes 0..r are exact; in practice
-//      wrong starts fall into step with the true decoder after ~4 400 bits (the slow part is the
-//      luma/chroma phase of the MCU, a 1-in-6 guess) and the loop ends early (worst case L-1
-//      rounds: still correct).  These walks only look at symbol lengths and index advances;
-//      the number of lanes per frame follows the batch size (huffman_sync_lanes): as many as keep
-//      every task resident at once, because the launch lasts as long as one task does;
+//   2. the lanes find the state the decoder is in where their share starts.  Lane 0's start is exact; a lane whose left
+//      neighbour is final takes that lane's arrival as its own final start.  Dense form (amv_huffman_sync_kernel): every
+//      lane takes its left neighbour's arrival state as its start state and walks again if that changed -- after round r
+//      lanes 0..r are exact, and in practice wrong starts fall into step with the true decoder with a chance of 0.8 per
+//      1 750 bits (the slow part is the luma/chroma phase of the MCU, a 1-in-6 guess), so the loop ends early (worst case
+//      L-1 rounds: still correct).  Records form (amv_huffman_sync2_kernel, round 5): the lanes REMEMBER their walks
+//      (start -> arrival per share), finality is a prefix scan over the lanes' "which of my walks starts where yours
+//      arrived" maps, and lanes with nothing to walk try candidate starts for the shares that are still open: the worst
+//      frame of 10 000 takes 6 rounds instead of 9 (the kernel has the details; tools/sim_sync.c is a CPU model of it).
+//      These walks only look at symbol lengths and index advances;
+//      the number of lanes per frame follows the batch size (huffman_sync_lanes): as many as keep every task resident at
+//      once, because the launch lasts as long as one task does;
 //   3. a prefix sum of "blocks finished per lane" gives every lane its first block number;
 //   3'. records form: a prefix sum of "value-carrying symbols per lane" gives every lane its first record;
 //   4. one strict pass decodes values and writes them: records form, one 32-bit word per DC coefficient

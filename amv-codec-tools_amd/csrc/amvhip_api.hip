@@ -63,6 +63,13 @@ struct amvhip_ctx {
     // host-pointer staging (one in-order stream of the context's own carries every host-buffer entry point)
     DevBuf h_in, h_offs, h_lens, h_out, h_status, h_aux, a_in, a_tab, a_out;
     hipStream_t hstream = nullptr;
+    // amvhip_decode_batch_async: decoded frames go back to the host on a stream of their own, out of two staging buffers used
+    // in turn, so that the copy of one call runs beside the upload and the kernels of the next (a window of the amvlib reader
+    // is 59 MB of frames back for 3.6 MB of chunks in)
+    hipStream_t dstream = nullptr;
+    DevBuf v_out[2], v_status[2];
+    hipEvent_t ev_decoded = nullptr, ev_copied[2] = {nullptr, nullptr};
+    uint64_t async_calls = 0;
     // timing
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -310,6 +317,11 @@ extern "C" void amvhip_destroy(amvhip_ctx* c) {
     drain(c);
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
+    if (c->dstream) { (void)hipStreamSynchronize(c->dstream); (void)hipStreamDestroy(c->dstream); }
+    for (hipEvent_t e : {c->ev_decoded, c->ev_copied[0], c->ev_copied[1]})
+        if (e) (void)hipEventDestroy(e);
+    for (DevBuf* b : {&c->v_out[0], &c->v_out[1], &c->v_status[0], &c->v_status[1]})
+        if (b->p) (void)hipFree(b->p);
     for (hipStream_t q : {c->front, c->back})
         if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     for (hipEvent_t e : {c->ev_in, c->ev_front, c->ev_done[0], c->ev_done[1]})
@@ -666,17 +678,28 @@ extern "C" int amvhip_decode_batch_async(amvhip_ctx* c, const uint8_t* blob, uin
     if (int r = ensure(c, c->h_in, blob_bytes + 16)) return r;
     if (int r = ensure(c, c->h_offs, (size_t)n * 8)) return r;
     if (int r = ensure(c, c->h_lens, (size_t)n * 4)) return r;
-    if (int r = ensure(c, c->h_out, fb * n)) return r;
-    if (int r = ensure(c, c->h_status, (size_t)n * 4)) return r;
+    if (!c->dstream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->dstream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&c->ev_decoded, &c->ev_copied[0], &c->ev_copied[1]}) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    const uint32_t which = (uint32_t)(c->async_calls & 1u);
+    DevBuf &d_frames = c->v_out[which], &d_st = c->v_status[which];
+    if (int r = ensure(c, d_frames, fb * n)) return r;          // (growing one frees the old: hipFree waits for the device)
+    if (int r = ensure(c, d_st, (size_t)n * 4)) return r;
+    // the copy that last read this staging buffer (the call before the last one) must be done before the kernels write it
+    if (c->async_calls >= 2) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_copied[which], 0));
     HIP_TRY(c, hipMemcpyAsync(c->h_in.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, st));
     if (int r = amvhip_decode_batch_dev(c, (const uint8_t*)c->h_in.p, blob_bytes, (const uint64_t*)c->h_offs.p,
-                                        (const uint32_t*)c->h_lens.p, n, w, h, flags, (uint8_t*)c->h_out.p,
-                                        (int32_t*)c->h_status.p, st))
+                                        (const uint32_t*)c->h_lens.p, n, w, h, flags, (uint8_t*)d_frames.p, (int32_t*)d_st.p, st))
         return r;
-    HIP_TRY(c, hipMemcpyAsync(out, c->h_out.p, fb * n, hipMemcpyDeviceToHost, st));
-    if (status) HIP_TRY(c, hipMemcpyAsync(status, c->h_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev_decoded, st));
+    HIP_TRY(c, hipStreamWaitEvent(c->dstream, c->ev_decoded, 0));
+    HIP_TRY(c, hipMemcpyAsync(out, d_frames.p, fb * n, hipMemcpyDeviceToHost, c->dstream));
+    if (status) HIP_TRY(c, hipMemcpyAsync(status, d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->dstream));
+    HIP_TRY(c, hipEventRecord(c->ev_copied[which], c->dstream));
+    ++c->async_calls;
     return AMVHIP_OK;
 }
 
@@ -684,6 +707,7 @@ extern "C" int amvhip_sync(amvhip_ctx* c) {
     if (!c) return AMVHIP_ERR_ARG;
     if (int r = use_device(c)) return r;
     if (c->hstream) HIP_TRY(c, hipStreamSynchronize(c->hstream));
+    if (c->dstream) HIP_TRY(c, hipStreamSynchronize(c->dstream));
     return AMVHIP_OK;
 }
 

@@ -244,8 +244,8 @@ AMVDecoder *AmvOpen(const char *amvname)
  * AMVDec.c:277-283,326), positions advance chunk by chunk, AmvRewindFrameStart and edited framebuf contents work (a
  * decode call whose chunk is not byte for byte the window's falls back to decoding that one chunk).
  * AMVHIP_READAHEAD=<frames> sets the window (default 1 024 -- putting a window on the stream costs ~0.4 ms of API calls
- * whatever its size --, never more than 64 MB of decoded frames; 1 = no read-ahead, one frame per GPU round trip, the
- * copying path). */
+ * whatever its size --, never more than 64 MB of decoded frames per window, of which there are three: the one in hand and
+ * two in flight; 1 = no read-ahead, one frame per GPU round trip, the copying path). */
 
 typedef struct ra_entry {
     long pos;                 /* file position of the frame's "00dc" */
@@ -276,6 +276,12 @@ typedef struct ra_window {
     int32_t *vstatus;
 } ra_window;
 
+/* Three windows (round 5; two before): the one frames are handed out of, and TWO in flight behind it -- a window's results
+ * come back over PCIe in ~1.6 ms (59 MB of frames), a caller walks its 1 024 frames in ~1 ms, so with one window in flight the
+ * caller waited 0.6 ms per window for the link to finish what it had only just been given.  With two in flight the copy
+ * stream never runs dry.  A window's buffers of a kind are still only written from inside a decode call of that kind. */
+#define RA_WINDOWS 3
+
 typedef struct readahead {
     AMVDecoder *owner;
     struct readahead *next;
@@ -285,11 +291,12 @@ typedef struct readahead {
     uint32_t w, h;
     uint64_t fb;              /* bytes of a decoded frame */
     int pinned;               /* buffers came from amvhip_host_alloc (else malloc: no device in this process) */
-    ra_window win[2];
+    ra_window win[RA_WINDOWS];
+    int nwin;                 /* windows in use: RA_WINDOWS, or 1 with AMVHIP_READAHEAD=1 */
     int c;                    /* the window frames are handed out of */
     uint32_t cur;             /* next frame of it to hand out */
     int last;                 /* index (in win[c]) of the frame in framebuf, -1 = none */
-    int ahead;                /* win[c ^ 1]: 0 = nothing, 1 = to be read when the next decode call comes, 2 = holds the frames behind win[c] */
+    long no_more_at;          /* a look-ahead read at this file position found no complete frame (the end of the stream): not tried again; -1 = none */
     /* what the caller holds of ours (never freed by anybody but the window's owner) */
     unsigned char *lent_v;
     short *lent_a;
@@ -343,7 +350,7 @@ static void ra_free(readahead *r)
     if (r == NULL) return;
     if (ctx() != NULL) amvhip_sync(ctx());
     if (r->fp) fclose(r->fp);
-    for (k = 0; k < 2; k++) {
+    for (k = 0; k < RA_WINDOWS; k++) {
         ra_window *w = &r->win[k];
         ra_release(r, w->vblob); ra_release(r, w->ablob); ra_release(r, w->vout); ra_release(r, w->aout);
         ra_release(r, w->voffs); ra_release(r, w->aoffs); ra_release(r, w->pcm_offs);
@@ -380,7 +387,9 @@ static readahead *ra_get(AMVDecoder *amv)
     r->cap_frames = (uint32_t)cap;
     r->fp = fopen(amv->amvfilename, "rb");
     if (r->fp != NULL && fseek(r->fp, 0, SEEK_END) == 0) r->fsize = ftell(r->fp);
-    for (k = 0; k < 2; k++) {
+    r->nwin = cap > 1 ? RA_WINDOWS : 1;                         /* AMVHIP_READAHEAD=1: one frame per round trip, one window */
+    r->no_more_at = -1;
+    for (k = 0; k < r->nwin; k++) {
         ra_window *w = &r->win[k];
         /* chunk space: AMV streams run at ~0.2 byte per pixel; a window that meets fatter chunks just ends early */
         w->vblob_cap = (size_t)cap * ((size_t)r->w * r->h / 2 + 4096) + 64;
@@ -400,7 +409,6 @@ static readahead *ra_get(AMVDecoder *amv)
         w->vstatus = (int32_t *)ra_alloc(r, cap * 4);
         ok = ok && w->e && w->vblob && w->ablob && w->vout && w->aout && w->voffs && w->aoffs && w->pcm_offs && w->vlens &&
              w->alens && w->vstatus;
-        if (cap == 1) break;                                    /* AMVHIP_READAHEAD=1: one frame per round trip, one window */
     }
     if (!r->fp || r->fsize <= 0 || !ok) {
         ra_free(r);
@@ -429,7 +437,7 @@ static int ra_grow(readahead *r, void **buf, size_t *cap, size_t need)
 static void ra_landed(readahead *r, int ok)
 {
     int k;
-    for (k = 0; k < 2; k++) {
+    for (k = 0; k < RA_WINDOWS; k++) {
         if (r->win[k].vstate == 2) r->win[k].vstate = ok ? 1 : -1;
         if (r->win[k].astate == 2) r->win[k].astate = ok ? 1 : -1;
     }
@@ -604,15 +612,14 @@ int AmvReadNextFrame(AMVDecoder *amv)
     if ((r = ra_get(amv)) == NULL) return -1;
     w = &r->win[r->c];
     if (!(r->cur < w->n && w->e[r->cur].pos == amv->fileseekpos)) {   /* window used up, or the position was moved */
-        const int o = r->cap_frames > 1 ? r->c ^ 1 : r->c;
+        const int o = (r->c + 1) % r->nwin;
         ra_window *nw = &r->win[o];
         int got;
-        if (r->ahead == 2 && nw->n > 0 && nw->start == amv->fileseekpos) {
-            got = (int)nw->n;                                     /* read (and being decoded) since the first decode call of this window */
+        if (r->nwin > 1 && nw->n > 0 && nw->start == amv->fileseekpos) {
+            got = (int)nw->n;                                     /* read (and being decoded) since a decode call of the window before */
         } else {
-            got = ra_refill(r, nw, amv->fileseekpos);
+            got = ra_refill(r, nw, amv->fileseekpos);             /* (a window that holds other frames -- the position was moved -- is simply read again) */
         }
-        r->ahead = 0;
         if (got < 0) {                                            /* :173-190 end of stream */
             drop_chunks(amv, r);
             fb->framenum = -1;
@@ -623,7 +630,6 @@ int AmvReadNextFrame(AMVDecoder *amv)
         r->c = o;
         r->cur = 0;
         r->last = -1;
-        r->ahead = r->cap_frames > 1 ? 1 : 0;                     /* the window behind this one: at the next decode call */
         w = nw;
     }
     e = &w->e[r->cur];
@@ -710,19 +716,26 @@ static int ra_decode_window(readahead *r, int video)
 }
 
 /* From inside a decode call of kind `video`: whatever the caller held of that kind from the window before is dead by
- * the call's contract, so the OTHER window's buffers of that kind may be written now -- read the frames behind this
- * window into it (once) and put their decode of this kind on the stream; it runs while the caller walks this window. */
+ * the call's contract, so the OTHER windows' buffers of that kind may be written now -- the frames behind this window are
+ * read into them (once: a window that already holds the frames expected at its place is left alone) and their decode of this
+ * kind is put on the stream; it runs while the caller walks this window and the next.  Called per frame: everything is a few
+ * comparisons once the windows are in place. */
 static void ra_look_ahead(readahead *r, int video)
 {
-    ra_window *o;
-    if (r->ahead == 0 || r->cap_frames <= 1) return;
-    o = &r->win[r->c ^ 1];
-    if (r->ahead == 1) {
-        const int got = ra_refill(r, o, r->win[r->c].end);
-        if (got <= 0) { o->n = 0; r->ahead = 0; return; }         /* end of stream / nothing complete: the reader finds out itself */
-        r->ahead = 2;
+    int k;
+    if (r->nwin <= 1) return;
+    for (k = 1; k < r->nwin; k++) {
+        const ra_window *before = &r->win[(r->c + k - 1) % r->nwin];
+        ra_window *o = &r->win[(r->c + k) % r->nwin];
+        if (before->n == 0) return;
+        if (!(o->n > 0 && o->start == before->end)) {
+            int got;
+            if (r->no_more_at == before->end) return;             /* the end of the stream: the reader finds out itself */
+            got = ra_refill(r, o, before->end);
+            if (got <= 0) { o->n = 0; r->no_more_at = before->end; return; }
+        }
+        ra_issue(r, o, video);
     }
-    ra_issue(r, o, video);
 }
 
 int AmvVideoDecode(AMVDecoder *amv)
