@@ -232,6 +232,51 @@ def test_decode_host_buffers_and_aliases(ctx, pkg, orc):
     assert pkg.load_library().decode_amv_frame(chunks[1][:200], 200, w, h, one.ctypes.data) == -1
 
 
+def test_async_decode_calls_in_flight(ctx, pkg, orc):
+    """amvhip_decode_batch_async, six calls in a row before one amvhip_sync: every call's frames come back on the copy
+    stream out of one of two staging buffers used in turn, so the kernels of call k + 2 must wait for the copy of call k
+    (events), and a grown staging buffer must not be freed under a copy.  Different content, sizes growing and
+    shrinking from call to call (so that the staging buffers are re-allocated in mid-flight), page-locked and pageable
+    destinations; then an encode through the same context's other host entry point, and a synchronous decode."""
+    import torch
+    lib = pkg.load_library()
+    w, h = 160, 120
+    base = _synth_chunks(orc, 8, w, h, first=500)
+    want1 = [orc.decode_frame(c, w, h)[0] for c in base]
+    counts = [3, 40, 7, 120, 1, 64]
+    calls = []
+    for k, n in enumerate(counts):
+        chunks = [base[(k + i) % 8] for i in range(n)]
+        blob, offs, lens, nbytes = _blob_of(chunks, pad_front=0)
+        out = torch.empty((n, h, ctx.stride(w)), dtype=torch.uint8)
+        out = out.pin_memory() if k % 2 == 0 else out
+        out.fill_(0x5A)
+        st = np.full(n, -1, np.int32)
+        calls.append((chunks, blob, offs, lens, nbytes, out, st))
+    for chunks, blob, offs, lens, nbytes, out, st in calls:
+        rc = lib.amvhip_decode_batch_async(ctx.h, blob.ctypes.data, nbytes, offs.ctypes.data, lens.ctypes.data, len(chunks), w, h, 0,
+                                           out.data_ptr(), st.ctypes.data)
+        assert rc == 0, lib.amvhip_last_error(ctx.h)
+    assert lib.amvhip_sync(ctx.h) == 0
+    for k, (chunks, blob, offs, lens, nbytes, out, st) in enumerate(calls):
+        got = out.numpy()
+        assert (st == 0).all(), k
+        for i in range(len(chunks)):
+            assert (got[i] == want1[(k + i) % 8]).all(), (k, i)
+    # the context's other host entry points still work behind that (they share its upload staging)
+    src = np.stack([orc.synth_frame(SEED, 500 + t, w, h) for t in range(4)])
+    eb = np.zeros(ctx.encode_bound(w, h) * 4, np.uint8)
+    eo, el = np.zeros(4, np.uint64), np.zeros(4, np.uint32)
+    ctx.encode_batch(src, w * 3, 0, 4, w, h, 0, eb, eb.size, eo, el)
+    for t in range(4):
+        assert eb[int(eo[t]):int(eo[t]) + int(el[t])].tobytes() == base[t], t
+    out = np.zeros((8, h, ctx.stride(w)), np.uint8)
+    st = np.full(8, -1, np.int32)
+    blob, offs, lens, nbytes = _blob_of(base)
+    ctx.decode_batch(blob, nbytes, offs, lens, 8, w, h, 0, out, st)
+    assert (st == 0).all() and (out == np.stack(want1)).all()
+
+
 # ---------------------------------------------------------------------------------- encode
 
 @pytest.mark.parametrize("w,h,n,bgr,qbias", [(320, 240, 5, 0, 0), (160, 120, 66, 0, 0), (160, 120, 3, 1, 128),
