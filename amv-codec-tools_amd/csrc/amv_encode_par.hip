@@ -161,11 +161,12 @@ __device__ __forceinline__ void code_symbol(Emitter& e, Cursor& c, const uint8_t
     const bool low = c.lo != 0u;
     const uint32_t half = low ? c.lo : c.hi;
     const uint32_t k = coef ? (uint32_t)__builtin_ctz(half) + (low ? 0u : 32u) : 0u;
-    if (coef) {
-        if (low) c.lo &= c.lo - 1u;
-        else c.hi &= c.hi - 1u;
-    }
-    const int ac = *reinterpret_cast<const int16_t*>(region + line_offset(c.b, k));
+    // (selects, not branches: the lanes of a wave are at different kinds of symbol, and every `if` here was a pair of
+    // exec-mask saves and restores in the wave's one instruction stream)
+    const uint32_t lo_less = c.lo & (c.lo - 1u), hi_less = c.hi & (c.hi - 1u);
+    c.lo = coef && low ? lo_less : c.lo;
+    c.hi = coef && !low ? hi_less : c.hi;
+    const int ac = *reinterpret_cast<const int16_t*>(region + line_offset(c.b, k));   // (the DC's own place when the symbol is no coefficient: read, not used)
     int v = c.at_dc ? c.dcv : (coef ? ac : 0);
     uint32_t run = coef ? k - c.last - 1u : 0u;
     c.last = coef ? k : c.last;
