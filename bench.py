@@ -7,8 +7,13 @@ bit-exact vs amvlib) on its configs[1].
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W     (--gpus must equal WORLD_SIZE)
 
-Exit codes: 0 clean; 2 more GPUs asked for than visible; 3 the strong-scaling leg hung (the line is written first);
-4 it raised a device / RCCL error (the line is written first).
+Exit codes: 0 clean; 2 more GPUs asked for than visible; 3 a leg beside the headline hung (the line is written first);
+4 one raised a device / RCCL error, on this rank or on a peer (the line is written first).
+
+The line of a run with ranks is as complete as the single-GPU one: `cpu_baseline` (rank 0 runs the CPU path, the others wait
+in a barrier outside every timed region), configs[3] as stated (`strong10k_*`), and every other BASELINE config run by every
+rank on frames of its own -- rates summed over the ranks, times the slowest rank's -- with `rccl_ranks`, `run_status` and
+`strong10k_status` in front (CONFIG_HEAD_RANKS).
 
 One step = one pass of the hot path, through the C ABI, over one batch that is already resident in
 HBM when the timed region starts; results stay in HBM.  Frames shard by contiguous range, one
@@ -64,12 +69,83 @@ EXIT_FAILED = 4         # a leg raised a device / RCCL error: the line is writte
 EXIT_HUNG = 3           # a leg did not end: the line is written by the watchdog, the run is not clean
 EXIT_USAGE = 2          # --gpus asks for more devices than there are
 LAUNCH_GRACE_SECONDS = float(os.environ.get("AMV_BENCH_LAUNCH_GRACE", "60"))   # launch_ranks: after one rank failed
+LAUNCH_LIMIT_SECONDS = float(os.environ.get("AMV_BENCH_LAUNCH_LIMIT", "3600"))  # launch_ranks: the whole run, whatever it waits for
+# what a leg beside the headline (a few seconds of work each) gets before the line leaves without it
+LEG_SECONDS = float(os.environ.get("AMV_BENCH_LEG_SECONDS", "300"))
+FLAG_KEY = "amv_bench_failed"   # the ranks' side channel: a key of the rendezvous store (class Peers)
 
 
 class Env:
     json_fd = None
     failed = None
-    strong_phase = ""
+    strong_phase = ""       # where the guarded leg of this rank is (the strong leg's phases, a secondary leg's name)
+    verdict = None          # the guarded leg's recorder: verdict(status) writes the leg's status scalars into result["config"]
+    result = None           # the line as far as it has got (what a watchdog or the peers' flag writes out)
+    peers = None
+    world = 1
+    rank = 0
+    dist = False
+
+
+def leave(code):
+    """every exit that does not unwind (a communicator may be in no state to be torn down): flush what Python holds first"""
+    try:
+        sys.stdout.flush()
+        sys.stderr.flush()
+    except (OSError, ValueError):
+        pass
+    os._exit(code)
+
+
+def write_line_now(E, status=None):
+    """the line as far as it has got, from whichever thread has to write it (rank 0 only; the others write nothing)"""
+    if E.result is None:
+        return
+    if status is not None:
+        if E.verdict is not None:
+            E.verdict(status)
+        else:
+            E.result["config"]["run_status"] = status
+    E.result["config"] = ordered_config(E.result["config"])
+    if E.rank == 0 and E.json_fd is not None:
+        os.write(E.json_fd, (json.dumps(E.result) + "\n").encode())
+
+
+class Peers:
+    """The ranks' side channel: one key of the rendezvous store (TCP on the host, nothing to do with the GPUs or RCCL).
+    A rank whose leg raised sets the key BEFORE it leaves; every rank polls it from a thread, so that a rank blocked in a
+    collective its failed peer will never join does not wait for its own watchdog -- and, under a launcher that ends the
+    survivors as soon as one rank has failed (torch.distributed.run does), rank 0 has written the line by then."""
+
+    def __init__(self, E, store, period=0.5):
+        import threading
+        self.E, self.store, self.period = E, store, period
+        self.stop = threading.Event()
+        threading.Thread(target=self.watch, daemon=True).start()
+
+    def raise_flag(self, text, linger=3.0):
+        """tell the others, then give their pollers `linger` seconds to act on it before this rank's exit ends the run"""
+        try:
+            self.store.set(FLAG_KEY, "rank %d: %s" % (self.E.rank, text))
+        except Exception:
+            return
+        if self.E.world > 1:
+            time.sleep(linger)
+
+    def watch(self):
+        E = self.E
+        while not self.stop.wait(self.period):
+            try:
+                if not self.store.check([FLAG_KEY]):
+                    continue
+                text = self.store.get(FLAG_KEY).decode(errors="replace")
+            except Exception:
+                return                                   # the store is gone (its host left): nothing more to learn here
+            if text.startswith("rank %d:" % E.rank):
+                return                                   # this rank's own flag: it is leaving by itself
+            write_line_now(E, "error: peer failed (%s) while this rank was in %s" % (text[:300], E.strong_phase or "the headline"))
+            os.write(2, ("bench.py: rank %d: a peer failed (%s); leaving with code %d\n" % (E.rank, text[:300], EXIT_FAILED)).encode())
+            leave(EXIT_FAILED)
 
 
 def strong_flat(strong, status):
@@ -239,6 +315,18 @@ def cpu_cores():
     n = avail if quota is None else max(1, min(avail, int(math.ceil(quota))))
     cap = os.environ.get("AMV_BENCH_CORES")
     return max(1, min(avail, int(cap))) if cap else n
+
+
+def cpu_leg(E, args):
+    """does THIS rank run the CPU path beside the line?  Rank 0 does, whatever the world size: the host's cores are one
+    resource, the figure is per host, and the other ranks wait for it in cpu_leg_done()'s barrier -- outside every timed
+    region (timed() brackets its own with barriers)"""
+    return E.rank == 0 and not args.no_cpu_baseline
+
+
+def cpu_leg_done(E, args):
+    if E.world > 1 and not args.no_cpu_baseline:
+        dist.barrier()
 
 
 def cpu_note():
@@ -413,12 +501,14 @@ def run_decode(E, args):
             result["roofline"]["path_traffic"] = pt            # all three decode kernels, counter bytes per step
             result["config"]["decode_traffic_ratio"] = pt / (stream_bytes + n * 3 * w * h)
 
-    if E.dist:          # config 4 as BASELINE.json states it, beside the weak-scaling line above
+    if E.dist and getattr(args, "strong_leg", True):   # config 4 as BASELINE.json states it, beside the weak-scaling line above
         result["config"]["scaling_modes"] = {"weak": "value / ms_per_step of this line: every GPU decodes its own %d frames" % n,
                                              "strong": "config4_strong_10k (flat: strong10k_*)"}
         guarded_strong(E, result, lambda: run_strong(E, args, w, h))
+        if E.failed:
+            return result       # this rank is out of step with the others: no further collective (the CPU leg's barrier)
 
-    if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
+    if cpu_leg(E, args):
         m = min(args.cpu_sample, n)
         blob_h = d_blob[: int(offs_h[m - 1]) + int(lens_h[m - 1]) + 16].cpu().numpy()
         o64, l32 = offs_h[:m].astype(np.uint64), lens_h[:m].astype(np.uint32)
@@ -437,56 +527,78 @@ def run_decode(E, args):
                                   "sample": "first %d frames of the same stream, CPU oracle (amvlib algorithm restated in C), "
                                             "frame-sharded over %d OpenMP threads, %d passes" % (m, cores, reps),
                                   "single_thread_value": m / t1, **cpu_note()}
+    cpu_leg_done(E, args)
     return result
 
 
 # ---------------------------------------------------------------------------------------------
-def guarded_strong(E, result, body, seconds=None):
-    """The exchange has never met more than one GPU.  Whatever happens to it, the weak line in `result`
-    goes out -- and the run then ENDS NON-ZERO: a hang (a send nobody receives) or a device / RCCL error is a finding, never
-    a clean run.  The verdict is a flat scalar, strong10k_status = "ok" | "error: ..." | "hung in <phase> on rank r".
-    body() -> the strong leg's dictionary.  An exception is recorded and E.failed set (write_line_and_leave exits with
-    EXIT_FAILED behind the line); no end within `seconds`: this rank's watchdog writes the line (rank 0) and leaves with
-    EXIT_HUNG.  SystemExit -- a gate's verdict -- passes through."""
+def guarded(E, result, body, seconds, verdict, what):
+    """One leg beside the headline, under N ranks: whatever happens to it, the line in `result` goes out -- and the run then
+    ENDS NON-ZERO: a hang (a send nobody receives, a barrier a failed peer never joins) or a device / RCCL error is a
+    finding, never a clean run.  verdict(status) writes the leg's flat status scalars into result["config"]
+    ("ok" | "error: ..." | "hung in <phase> on rank r").  body() -> the leg's value.  An exception is recorded, E.failed set,
+    the peers told (class Peers) and None returned (write_line_and_leave exits with EXIT_FAILED behind the line); no end
+    within `seconds`: this rank's watchdog writes the line (rank 0) and leaves with EXIT_HUNG.  SystemExit -- a gate's
+    verdict -- passes through."""
     import threading
-    seconds = STRONG_LEG_SECONDS if seconds is None else seconds
     done = threading.Event()
-    E.strong_phase = "setup"
+    E.result, E.verdict = result, verdict
+    E.strong_phase = E.strong_phase or what
 
     def bail():
         if done.wait(seconds):
             return
-        result["config"].update(strong_flat(None, "hung in %s on rank %d: no end after %g s" % (E.strong_phase, E.rank, seconds)))
-        result["config"] = ordered_config(result["config"])
-        if E.rank == 0 and E.json_fd is not None:
-            os.write(E.json_fd, (json.dumps(result) + "\n").encode())
-        os.write(2, ("bench.py: rank %d: strong-scaling leg hung in phase %r; line written, leaving with code %d\n"
-                     % (E.rank, E.strong_phase, EXIT_HUNG)).encode())
-        os._exit(EXIT_HUNG)
+        write_line_now(E, "hung in %s on rank %d: no end after %g s" % (E.strong_phase, E.rank, seconds))
+        os.write(2, ("bench.py: rank %d: %s hung in phase %r; line written, leaving with code %d\n"
+                     % (E.rank, what, E.strong_phase, EXIT_HUNG)).encode())
+        leave(EXIT_HUNG)
 
     threading.Thread(target=bail, daemon=True).start()
-    strong = None
+    value = None
     try:
-        strong = body()
+        value = body()
         status = "ok"
     except Exception as e:                       # (SystemExit is not an Exception)
         status = "error: %s in %s: %s" % (type(e).__name__, E.strong_phase, str(e)[:300])
         E.failed = status                        # the line goes out, then write_line_and_leave() leaves non-zero
     done.set()
-    result["config"].update(strong_flat(strong, status))
-    result["config"]["config4_strong_10k"] = strong if strong is not None else {"failed": status}
+    verdict(status)
+    E.verdict = None
+    E.strong_phase = ""
+    return value
+
+
+def guarded_strong(E, result, body, seconds=None):
+    """The exchange has never met more than one GPU: configs[3] as stated under guarded()'s contract.
+    The verdict is a flat scalar, strong10k_status = "ok" | "error: ..." | "hung in <phase> on rank r"."""
+    E.strong_phase = "setup"
+    box = {}
+
+    def verdict(status):
+        result["config"].update(strong_flat(box.get("strong") if status == "ok" else None, status))
+
+    def run():
+        box["strong"] = body()
+        return box["strong"]
+
+    strong = guarded(E, result, run, STRONG_LEG_SECONDS if seconds is None else seconds, verdict, "strong-scaling leg")
+    result["config"]["config4_strong_10k"] = strong if strong is not None else {"failed": E.failed}
 
 
 def write_line_and_leave(E, result):
-    """rank 0 writes the one JSON line; a run whose strong leg failed then leaves at once with EXIT_FAILED (the line is out; the
-    communicator may be in no state to be torn down).  Returns normally otherwise."""
+    """rank 0 writes the one JSON line; a run with a failed leg then leaves at once with EXIT_FAILED (the line is out, the
+    peers are told; the communicator may be in no state to be torn down).  Returns normally otherwise."""
+    if E.dist:
+        result["config"].setdefault("run_status", E.failed or "ok")     # every leg beside the headline, in one scalar
     result["config"] = ordered_config(result["config"])
     if E.rank == 0:
         sys.stdout.flush()
         os.write(E.json_fd, (json.dumps(result) + "\n").encode())
     if E.failed:
         os.write(2, ("bench.py: rank %d: %s -- leaving with code %d\n" % (E.rank, E.failed, EXIT_FAILED)).encode())
-        os._exit(EXIT_FAILED)
+        if E.peers:
+            E.peers.raise_flag(E.failed)
+        leave(EXIT_FAILED)
 
 
 def run_strong(E, args, w, h, n_total=10000):
@@ -629,7 +741,7 @@ def run_encode(E, args):
     result["roofline"] = roofline(kern, stream_bytes + n * 3 * w * h, elapsed / args.steps,
                                   (lambda dom: profiled_traffic("_encode", dom)) if (w, h, n) == (320, 240, 8000) else None)
 
-    if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline:
+    if cpu_leg(E, args):
         import concurrent.futures
         m = min(256, n)
         src = d_rgb[:m].cpu().numpy()
@@ -646,6 +758,7 @@ def run_encode(E, args):
                                   "sample": "first %d frames of the same source x4, CPU oracle (the reference build's encoder "
                                             "algorithm restated in C), one frame per call over %d threads" % (m, cores),
                                   "single_thread_value": m / t1}
+    cpu_leg_done(E, args)
     return result
 
 
@@ -773,7 +886,7 @@ def run_adpcm(E, args, with_video=False):
                             "chunks_per_gpu": na, "parallelism": "chunk-range x%d" % E.world}
         result["roofline"] = roofline(kern, audio_bytes, elapsed / args.steps, profiled_adpcm_traffic if na == 200000 else None)
 
-    if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline and not with_video:
+    if cpu_leg(E, args) and not with_video:
         m = min(na, 4096)
         pcm = d_pcm[: m * spf].cpu().numpy()
         ch = d_chunks[: m * clen].cpu().numpy()
@@ -786,7 +899,7 @@ def run_adpcm(E, args, with_video=False):
         result["cpu_baseline"] = {"value": 2 * m * spf / t1, "unit": "samples/s", "cores": 1, "kind": "port",
                                   "sample": "first %d chunks of the same audio, CPU oracle encode + decode, one thread "
                                             "(includes the ctypes call per chunk)" % m}
-    if E.rank == 0 and E.world == 1 and not args.no_cpu_baseline and with_video:
+    if cpu_leg(E, args) and with_video:
         # the CPU path for the same unit of work: one 320x240 frame decoded + its audio chunk encoded and decoded
         m = min(n, args.cpu_sample, 512)
         blob_h = d_blob[: int(offs_h[m - 1]) + int(lens_h[m - 1]) + 16].cpu().numpy()
@@ -811,6 +924,7 @@ def run_adpcm(E, args, with_video=False):
                                             "frames' audio chunks encoded (index carried: a serial chain) and decoded on one "
                                             "thread" % (m, cores),
                                   "single_thread_value": m / (tv1 + ta)}
+    cpu_leg_done(E, args)
     if with_video:
         E.extra_ctx = []
         actx.close()
@@ -890,12 +1004,18 @@ def run_amvlib(E, args):
     return result
 
 
-def run_secondary(E, args):
+def run_secondary(E, args, result):
     """The other BASELINE.json configs beside the headline, each with its own gate and timed loop (fewer steps), so that
     the one line the driver records carries all five: 320x240 decode, the 10 000-frame 160x120 stream (configs[3]'s
-    stream on one GPU), 320x240 encode (configs[2]), video decode with co-resident ADPCM (configs[4]), ADPCM alone."""
+    stream on one GPU), 320x240 encode (configs[2]), video decode with co-resident ADPCM (configs[4]), ADPCM alone.
+    Under N ranks every rank runs every leg on frames of its own (weak, like the headline: rates summed over the ranks,
+    times the slowest rank's -- base_result / timed do that for any world size), rank 0 runs the CPU path beside each while
+    the others wait in a barrier, and each leg is guarded (guarded()): an error or a hang of one is `run_status` on the line
+    and a non-zero exit, and the legs after it do not run (this rank is out of step with its peers).  Every finished leg is
+    flattened into result["config"] at once, so that a line written early carries what there is."""
     import copy
     out = {}
+    result["config"]["secondary"] = out
     # batch sizes: what fills the chip with ONE entropy lane per frame (320x240: 32 000 / 64 000 / 128 000 frames per step
     # decode at 5.9 / 6.6 / 7.7 M frames/s -- a small batch is cut into several speculative lanes per frame); the
     # 10 000-frame line is there to show the other regime
@@ -906,22 +1026,36 @@ def run_secondary(E, args):
             ("encode_320x240", run_encode, {}),
             ("coresident_320x240_adpcm", lambda e, a: run_adpcm(e, a, with_video=True), {"frames": 64000}),
             ("adpcm", lambda e, a: run_adpcm(e, a, with_video=False), {}))
+
+    def verdict(status):
+        if status != "ok":
+            result["config"]["run_status"] = status
+
     for name, fn, over in plan:
         a = copy.copy(args)
         a.steps, a.warmup = min(args.steps, 10), min(args.warmup, 2)
         a.cpu_sample, a.cpu_seconds = 512, 1.0     # bounded CPU legs: every entry carries the CPU path beside it
+        a.strong_leg = False                       # configs[3] as stated rides on the headline only
         for k, v in over.items():
             setattr(a, k, v)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         t0 = time.perf_counter()
-        try:
-            r = fn(E, a)
-        except torch.OutOfMemoryError as e:        # a smaller part than the 288 GB this is sized for: say so, keep the line
+        if E.dist:
+            E.strong_phase = "leg " + name
+            r = guarded(E, result, lambda: fn(E, a), LEG_SECONDS, verdict, "leg " + name)
             E.extra_ctx = []
-            out[name] = {"skipped": "out of device memory: %s" % str(e).splitlines()[0]}
-            continue
-        E.extra_ctx = []
+            if r is None:
+                break
+        else:
+            try:
+                r = fn(E, a)
+            except torch.OutOfMemoryError as e:    # a smaller part than the 288 GB this is sized for: say so, keep the line
+                E.extra_ctx = []
+                out[name] = {"skipped": "out of device memory: %s" % str(e).splitlines()[0]}
+                result["config"].update(flat_secondary({name: out[name]}))
+                continue
+            E.extra_ctx = []
         roof = r["roofline"]
         entry_ = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
                   "workload": r["config"]["workload"], "kernels": roof["kernels"],
@@ -936,6 +1070,8 @@ def run_secondary(E, args):
             entry_["co_resident_audio_kernels"] = roof["co_resident_audio_kernels"]
         entry_["wall_s"] = time.perf_counter() - t0
         out[name] = entry_
+        result["config"].update(flat_secondary({name: entry_}))
+    result["config"]["secondary"] = result["config"].pop("secondary")     # the nested form behind the flat scalars
     return out
 
 
@@ -968,10 +1104,8 @@ def flat_secondary(sec):
 
 # What a record that keeps only the first scalars of `config` must still carry, in this order: the workload, then per
 # BASELINE config its rate, its roofline fraction and the CPU path beside it (configs[1] is the line itself: value, roofline,
-# cpu_baseline), then the strong leg's verdict when there are ranks, then the headline's own diagnostics.
+# cpu_baseline), then the headline's own diagnostics.
 CONFIG_HEAD = ("workload", "parallelism",
-               "rccl_ranks", "strong10k_status", "strong10k_ms", "strong10k_fps", "strong10k_scatter_ms", "strong10k_decode_ms",
-               "strong10k_gather_ms",
                "c320_decode_fps", "c320_decode_frac", "c320_decode_cpu_fps",
                "enc320_fps", "enc320_frac", "enc320_cpu_fps",
                "stream10k_fps", "stream10k_frac", "stream10k_cpu_fps",
@@ -979,11 +1113,17 @@ CONFIG_HEAD = ("workload", "parallelism",
                "adpcm_sps", "adpcm_frac", "adpcm_cpu_sps",
                "decode_traffic_ratio", "handed_to_serial", "mixed160_fps", "mixed160_handed_to_serial",
                "frames_per_gpu", "mean_chunk_bytes")
+# ... and the line of a run with ranks (a communicator: WORLD_SIZE > 1, or --strong): the communicator's size and the verdicts
+# first (the strong leg's and, in one scalar, every other leg's), configs[3] as stated, then the same sixteen -- all five
+# BASELINE configs inside the first 24 -- and the strong leg's phases behind them.
+CONFIG_HEAD_RANKS = ("workload", "rccl_ranks", "run_status", "strong10k_status", "strong10k_ms", "strong10k_fps") + CONFIG_HEAD[2:18] + (
+    "strong10k_decode_ms", "strong10k_gather_ms", "strong10k_scatter_ms", "parallelism") + CONFIG_HEAD[18:]
 
 
 def ordered_config(cfg):
-    """`cfg` with CONFIG_HEAD's keys first (those that exist), everything else behind them in the order it came"""
-    head = {k: cfg[k] for k in CONFIG_HEAD if k in cfg}
+    """`cfg` with the head's keys first (those that exist), everything else behind them in the order it came"""
+    order = CONFIG_HEAD_RANKS if "rccl_ranks" in cfg or "strong10k_status" in cfg else CONFIG_HEAD
+    head = {k: cfg[k] for k in order if k in cfg}
     head.update((k, v) for k, v in cfg.items() if k not in head)
     return head
 
@@ -992,38 +1132,49 @@ def ordered_config(cfg):
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks -- one CHILD process per
     GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run sets them -- relay rank 0's one JSON line
-    and leave with the worst exit code.  This process never touches the GPU (counting devices does not initialise HIP on
-    this image) and never re-execs itself.  AMV_BENCH_CHILD replaces the child command (the launcher's test:
-    tests/test_bench_launcher.py)."""
+    and leave with the worst exit code.  Like torch.distributed.run's agent, THIS process hosts the rendezvous store (a
+    TCPStore on a port the system picks: nothing is probed and re-bound later, and the store -- the ranks' side channel,
+    class Peers -- outlives any rank) and the ranks join it as clients (TORCHELASTIC_USE_AGENT_STORE).  This process never
+    touches the GPU (counting devices does not initialise HIP on this image) and never re-execs itself.  The whole run has
+    a wall-clock limit (AMV_BENCH_LAUNCH_LIMIT): ranks that hang together -- in the rendezvous, in a barrier -- are ended by
+    their PIDs and the run leaves with EXIT_HUNG.  A run whose rank 0 printed no line is not clean, whatever the exit codes.
+    AMV_BENCH_CHILD replaces the child command (the launcher's test: tests/test_bench_launcher.py)."""
     import shlex
-    import socket
     import subprocess
+    import threading
     n = args.gpus
     if not os.environ.get("AMV_BENCH_CHILD"):
         have = torch.cuda.device_count()
         if have < n:
             sys.stderr.write("bench.py: --gpus %d: %d devices needed, %d visible -- not measuring fewer GPUs under that name\n" % (n, n, have))
             return EXIT_USAGE
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
+    import datetime
+    store = dist.TCPStore("127.0.0.1", int(os.environ.get("MASTER_PORT", "0")), None, True,
+                          datetime.timedelta(seconds=300), wait_for_workers=False)
+    port = store.port
     child = shlex.split(os.environ["AMV_BENCH_CHILD"]) if os.environ.get("AMV_BENCH_CHILD") else [sys.executable, os.path.abspath(__file__)]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_USE_AGENT_STORE="True")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen(child + argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
     # rank 0's stdout is the line (read by a thread, so that the other ranks are watched meanwhile); everything else the
     # children print is already on stderr
-    import threading
     got = []
     reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    started = time.time()
     deadline = None
     codes = [None] * n
+
+    def end(r, why, code):
+        sys.stderr.write("bench.py: rank %d still running %s: killing pid %d\n" % (r, why, procs[r].pid))
+        procs[r].kill()                                              # this exact child, nothing by pattern
+        procs[r].wait()
+        codes[r] = code
+
     while any(c is None for c in codes):
         for r, pr in enumerate(procs):
             if codes[r] is None:
@@ -1031,13 +1182,13 @@ def launch_ranks(args, argv):
         if any(c not in (None, 0) for c in codes) and deadline is None:
             deadline = time.time() + LAUNCH_GRACE_SECONDS      # a rank failed: the others get this long to end by themselves
         if deadline is not None and time.time() > deadline:
-            for r, pr in enumerate(procs):
+            for r in range(n):
                 if codes[r] is None:
-                    sys.stderr.write("bench.py: rank %d still running %g s after another rank failed: killing pid %d\n"
-                                     % (r, LAUNCH_GRACE_SECONDS, pr.pid))
-                    pr.kill()                                    # this exact child, nothing by pattern
-                    pr.wait()
-                    codes[r] = EXIT_HUNG
+                    end(r, "%g s after another rank failed" % LAUNCH_GRACE_SECONDS, EXIT_HUNG)
+        if time.time() - started > LAUNCH_LIMIT_SECONDS:
+            for r in range(n):
+                if codes[r] is None:
+                    end(r, "after the run's limit of %g s (AMV_BENCH_LAUNCH_LIMIT)" % LAUNCH_LIMIT_SECONDS, EXIT_HUNG)
         time.sleep(0.05)
     reader.join(10)
     line = got[0] if got else b""
@@ -1048,10 +1199,32 @@ def launch_ranks(args, argv):
         if c != 0:
             sys.stderr.write("bench.py: rank %d left with code %d\n" % (r, c))
             worst = max(worst, c if c > 0 else 128 - c)
+    if not line.strip() and worst == 0:
+        sys.stderr.write("bench.py: every rank left with code 0 but rank 0 wrote no line (or its pipe is still held open): "
+                         "not a clean run\n")
+        worst = EXIT_FAILED
     return worst
 
 
-def main():
+def run_workload(E, args):
+    """everything between "the ranks, the device and the context are there" and "the line goes out" """
+    if args.workload == "decode":
+        result = run_decode(E, args)
+        plain = not (args.frames or args.width or args.height or args.pipelined or args.stream != "synthetic")
+        if plain and not args.no_secondary and not E.failed:
+            run_secondary(E, args, result)
+    elif args.workload == "encode":
+        result = run_encode(E, args)
+    elif args.workload == "coresident":
+        result = run_adpcm(E, args, with_video=True)
+    elif args.workload == "amvlib":
+        result = run_amvlib(E, args)
+    else:
+        result = run_adpcm(E, args, with_video=False)
+    return result
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -1078,7 +1251,11 @@ def main():
                          "the reference's clip AMV1.amv (128x96) repeated")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default line only: skip the other BASELINE configs (config.secondary)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
 
     # --gpus is the number of ranks.  Under torch.distributed.run (or any launcher that sets WORLD_SIZE) it must agree with
     # the environment; a plain `python bench.py --gpus N` starts the N ranks itself -- BEFORE anything touches the GPU.
@@ -1113,30 +1290,23 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=E.rank, world_size=E.world,    # RCCL over xGMI
                                 device_id=torch.device("cuda", local))
+        E.peers = Peers(E, dist.distributed_c10d._get_default_store())
     E.dev = torch.device("cuda", local)
     E.pkg = entry.load_package()
     E.sh = entry._load(entry.PKG_NAME + ".sharding", os.path.join(entry.PKG_DIR, "sharding.py"))
     E.ctx = E.pkg.Context(local)
     E.stream = torch.cuda.current_stream().cuda_stream
 
-    if args.workload == "decode":
-        result = run_decode(E, args)
-        plain = not (args.frames or args.width or args.height or args.pipelined or args.strong or args.stream != "synthetic")
-        if plain and E.world == 1 and not args.no_secondary:
-            sec = run_secondary(E, args)
-            result["config"].update(flat_secondary(sec))
-            result["config"]["secondary"] = sec
-    elif args.workload == "encode":
-        result = run_encode(E, args)
-    elif args.workload == "coresident":
-        result = run_adpcm(E, args, with_video=True)
-    elif args.workload == "amvlib":
-        result = run_amvlib(E, args)
-    else:
-        result = run_adpcm(E, args, with_video=False)
+    try:
+        result = run_workload(E, args)
+    except BaseException as e:          # a gate's SystemExit included: the peers must not wait for a rank that has left
+        if E.peers and not isinstance(e, KeyboardInterrupt):
+            E.peers.raise_flag("%s: %s" % (type(e).__name__, str(e)[:300]))
+        raise
     write_line_and_leave(E, result)
     E.ctx.close()
     if E.dist:
+        E.peers.stop.set()
         dist.destroy_process_group()
 
 

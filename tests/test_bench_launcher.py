@@ -98,8 +98,8 @@ def test_config_head_fits_the_window_that_records_keep():
     import bench
     # a single-GPU line has no strong leg: the other four BASELINE configs (rate, fraction, CPU path) + the headline's own
     # diagnostics must sit inside the first 24 scalars of `config`
-    single = [k for k in bench.CONFIG_HEAD if not (k.startswith("strong10k_") or k == "rccl_ranks")]
-    first = single[:24]
+    assert not [k for k in bench.CONFIG_HEAD if k.startswith("strong10k_") or k in ("rccl_ranks", "run_status")]
+    first = bench.CONFIG_HEAD[:24]
     for p in ("c320_decode", "enc320", "stream10k", "coresident"):
         assert {p + "_fps", p + "_frac", p + "_cpu_fps"} <= set(first)
     assert {"adpcm_sps", "adpcm_frac", "adpcm_cpu_sps", "coresident_adpcm_sps", "mixed160_fps", "mixed160_handed_to_serial",
@@ -108,6 +108,139 @@ def test_config_head_fits_the_window_that_records_keep():
     assert list(cfg) == ["workload", "enc320_fps", "zzz", "secondary"]
     flat = bench.strong_flat(None, "hung in setup on rank 0")
     assert flat["strong10k_status"].startswith("hung") and flat["strong10k_ms"] is None and "rccl_ranks" in flat
+    # the line of a run WITH ranks: the communicator's size, both verdicts, configs[3] as stated and the same sixteen
+    # scalars -- all five BASELINE configs with their CPU path -- inside the first 24
+    ranks = bench.CONFIG_HEAD_RANKS[:24]
+    assert len(set(bench.CONFIG_HEAD_RANKS)) == len(bench.CONFIG_HEAD_RANKS) and set(bench.CONFIG_HEAD) <= set(bench.CONFIG_HEAD_RANKS)
+    assert {"workload", "rccl_ranks", "run_status", "strong10k_status", "strong10k_ms", "strong10k_fps"} <= set(ranks)
+    for p in ("c320_decode", "enc320", "stream10k", "coresident"):
+        assert {p + "_fps", p + "_frac", p + "_cpu_fps"} <= set(ranks)
+    assert {"adpcm_sps", "adpcm_frac", "adpcm_cpu_sps", "coresident_adpcm_sps"} <= set(ranks)
+    cfg = bench.ordered_config({"zzz": 1, "parallelism": "x2", "enc320_fps": 2.0, "strong10k_status": "ok", "rccl_ranks": 2, "workload": "w"})
+    assert list(cfg) == ["workload", "rccl_ranks", "strong10k_status", "enc320_fps", "parallelism", "zzz"]
+
+
+# A rank of an N-rank run with everything that needs a GPU replaced: gloo instead of RCCL, the three workload functions
+# replaced by stand-ins that go through the SAME reductions, barriers, CPU-leg gate and result builders (base_result,
+# roofline, cpu_leg / cpu_leg_done, guarded_strong) as the real ones.  What runs for real: launch_ranks (the store it hosts,
+# the environment), the ranks' side channel (Peers), run_workload / run_secondary / flat_secondary / ordered_config /
+# write_line_and_leave -- the shape of the record an N-rank run leaves.
+RANK_STUB = """
+    import json, os, sys, time
+    sys.path.insert(0, %(root)r)
+    import torch, torch.distributed as dist
+    import bench
+    args = bench.parse_args(sys.argv[1:])
+    E = bench.Env()
+    E.world, E.rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    E.json_fd = os.dup(1)
+    os.dup2(2, 1)
+    E.dist = True
+    dist.init_process_group("gloo", rank=E.rank, world_size=E.world)
+    E.peers = bench.Peers(E, dist.distributed_c10d._get_default_store(), period=0.1)
+    E.dev = torch.device("cpu")
+    E.sh = bench.entry._load(bench.entry.PKG_NAME + ".sharding", os.path.join(bench.entry.PKG_DIR, "sharding.py"))
+    torch.cuda.synchronize = lambda *a: None
+    torch.cuda.empty_cache = lambda: None
+    FAIL = os.environ.get("STUB_FAIL", "")          # "<rank>:<leg>:<raise|hang>"
+
+    def leg(metric, unit, units, cfg):
+        def run(E, args, **kw):
+            name = E.strong_phase
+            if FAIL and FAIL.split(":")[0] == str(E.rank) and FAIL.split(":")[1] in name:
+                if FAIL.split(":")[2] == "hang":
+                    time.sleep(600)
+                raise RuntimeError("HIP error: stand-in fault")
+            elapsed = E.sh.max_over_ranks(0.01 * (1 + E.rank), E.dev)
+            r = bench.base_result(E, args, metric, unit, units, elapsed)
+            r["config"] = dict({"workload": metric, "parallelism": "frame-range x%%d" %% E.world, "frames_per_gpu": units,
+                                "mean_chunk_bytes": 3500.0, "handed_to_serial": 0}, **cfg)
+            r["roofline"] = bench.roofline({"k": {"launches": 1, "ms_per_step": 1.0, "ms_per_launch": 1.0}}, 1e6, 0.01, None)
+            if metric.startswith("160x120") and E.dist and getattr(args, "strong_leg", True):
+                bench.guarded_strong(E, r, lambda: {"ms_per_step": 0.9, "frames_per_s": 1.1e7, "rccl_ranks": dist.get_world_size(),
+                                                    "phase_ms_max_over_ranks": {"scatter": 0.1, "decode": 0.5, "gather": 0.3}})
+            if bench.cpu_leg(E, args):
+                time.sleep(0.2)
+                r["cpu_baseline"] = {"value": 5.0, "unit": unit, "cores": 1, "kind": "port", "sample": "stand-in"}
+            bench.cpu_leg_done(E, args)
+            return r
+        return run
+
+    def run_decode(E, args):
+        if (args.width, args.frames, args.stream) == (None, None, "synthetic"):
+            E.strong_phase = E.strong_phase or "headline"
+            return leg("160x120 decode", "frames/s", 160000, {})(E, args)
+        return leg("%%sx decode %%s %%s" %% (args.width, args.frames, args.stream), "frames/s", args.frames or 160000, {})(E, args)
+
+    bench.run_decode = run_decode
+    bench.run_encode = leg("encode", "frames/s", 8000, {"round_trip_psnr_db": 30.0})
+    bench.run_adpcm = lambda E, args, with_video=False: leg("coresident" if with_video else "adpcm",
+        "frames/s" if with_video else "samples/s", 64000, {"adpcm_samples_per_s": 1e9} if with_video else {})(E, args)
+    result = bench.run_workload(E, args)
+    bench.write_line_and_leave(E, result)
+    E.peers.stop.set()
+    dist.destroy_process_group()
+"""
+
+
+def test_two_rank_line_carries_every_config_and_the_cpu_path(tmp_path):
+    """WORLD_SIZE = 2: the record an N-rank run leaves -- n_gpus, the weak value summed over the ranks, cpu_baseline (rank 0's
+    CPU leg, the other rank waiting in the barrier), rccl_ranks / run_status / strong10k_status and all five BASELINE configs
+    with their CPU path inside the first 24 scalars of `config`"""
+    child = _stub(tmp_path, RANK_STUB % {"root": ROOT})
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], child)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"]["value"] == 5.0
+    assert abs(line["value"] - 2 * 160000 * 2 / 0.02) < 1e-3             # both ranks' frames over the slower rank's time
+    first = list(line["config"])[:24]
+    assert first[:6] == ["workload", "rccl_ranks", "run_status", "strong10k_status", "strong10k_ms", "strong10k_fps"]
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["run_status"] == "ok" and line["config"]["strong10k_status"] == "ok"
+    for p in ("c320_decode", "enc320", "stream10k", "coresident"):
+        assert {p + "_fps", p + "_frac", p + "_cpu_fps"} <= set(first), (p, first)
+        assert line["config"][p + "_cpu_fps"] == 5.0
+    assert {"adpcm_sps", "adpcm_frac", "adpcm_cpu_sps", "coresident_adpcm_sps"} <= set(first)
+    assert line["config"]["c320_decode_fps"] == 2 * 128000 * 2 / 0.02     # summed over the ranks like the headline
+    assert set(line["config"]["secondary"]) == {"decode_320x240", "decode_160x120_10k_stream", "decode_160x120_mixed",
+                                                "decode_amv1_looped", "encode_320x240", "coresident_320x240_adpcm", "adpcm"}
+    assert list(line["config"])[-1] == "secondary"
+
+
+def test_a_rank_that_fails_in_a_leg_tells_its_peers_and_the_line_still_goes_out(tmp_path):
+    """rank 1 raises inside the co-resident leg: it sets the flag in the store and leaves with EXIT_FAILED; rank 0 -- blocked
+    in that leg's reduction -- learns it from the store (or from the backend), writes the line with what had finished and
+    run_status = "error: ...", and leaves non-zero too.  Seconds, not the leg's watchdog."""
+    child = _stub(tmp_path, RANK_STUB % {"root": ROOT})
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], child, {"STUB_FAIL": "1:coresident:raise"}, timeout=100)
+    assert r.returncode == 4, r.stderr[-3000:]
+    line = json.loads(r.stdout)
+    assert line["config"]["run_status"].startswith("error:") and line["config"]["strong10k_status"] == "ok"
+    assert "enc320_fps" in line["config"] and "coresident_fps" not in line["config"] and "adpcm_sps" not in line["config"]
+    assert line["value"] > 0 and "cpu_baseline" in line
+
+
+def test_a_rank_that_hangs_in_a_leg_ends_the_run_with_the_line_written(tmp_path):
+    """rank 1 never comes back from the encode leg: every rank's watchdog fires after AMV_BENCH_LEG_SECONDS, rank 0 writes
+    the line with run_status = "hung in leg encode_320x240 on rank 0" and both leave with EXIT_HUNG"""
+    child = _stub(tmp_path, RANK_STUB % {"root": ROOT})
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], child, {"STUB_FAIL": "1:encode:hang", "AMV_BENCH_LEG_SECONDS": "3"},
+             timeout=100)
+    assert r.returncode == 3, r.stderr[-3000:]
+    line = json.loads(r.stdout)
+    assert line["config"]["run_status"].startswith("hung in leg encode_320x240 on rank 0")
+    assert "stream10k_fps" in line["config"] and "enc320_fps" not in line["config"]
+
+
+def test_launcher_limit_ends_ranks_that_hang_together_and_an_empty_line_is_not_clean(tmp_path):
+    child = _stub(tmp_path, """
+        import time
+        time.sleep(600)          # every rank waiting: a rendezvous that never completes
+    """)
+    r = _run(["--gpus", "2"], child, {"AMV_BENCH_LAUNCH_LIMIT": "1"}, timeout=60)
+    assert r.returncode == 3 and r.stdout == "" and "AMV_BENCH_LAUNCH_LIMIT" in r.stderr
+    child = _stub(tmp_path, "pass")
+    r = _run(["--gpus", "2"], child, timeout=60)
+    assert r.returncode == 4 and r.stdout == "" and "wrote no line" in r.stderr
 
 
 def _guard_script(tmp_path, body):
