@@ -1245,28 +1245,8 @@ static int adpcm_encode_frame_impl(amvhip_ctx* c, const int16_t* samples, uint32
     return (int)len;
 }
 
-// AMV audio framing of the reference's encoder (adpcm.c:469-477): sample PAIRS of the next chunk for a nominal
-// frame_size -- an odd frame_size puts its extra sample into every second chunk, and a chunk that would straddle a
-// whole second of audio is stretched to end on it.  extra / samples_written are the caller's stream state.
-extern "C" uint32_t amvhip_amv_audio_pairs(uint32_t frame_size, uint32_t sample_rate, uint32_t* extra, uint64_t* samples_written) {
-    uint32_t n = frame_size >> 1;                           // :469
-    *extra += frame_size & 1u;                              // :470
-    n += *extra >> 1;                                       // :471
-    *extra &= 1u;                                           // :472
-    if (sample_rate) {
-        const uint32_t i = (uint32_t)((*samples_written + 2ull * n) % sample_rate);   // :474
-        if (i && i + frame_size > sample_rate) n += (sample_rate - i) >> 1;           // :476-477
-    }
-    *samples_written += 2ull * n;                           // :497
-    return n;
-}
-
-// frame_size the AMV muxer imposes on the audio encoder: sample_rate * time_base (amvenc.c:276-281, av_rescale
-// rounds to nearest)
-extern "C" uint32_t amvhip_amv_audio_frame_size(uint32_t sample_rate, uint32_t tb_num, uint32_t tb_den) {
-    if (!tb_den) return 0;
-    return (uint32_t)(((uint64_t)sample_rate * tb_num + tb_den / 2) / tb_den);
-}
+// (amvhip_amv_audio_pairs / amvhip_amv_audio_frame_size, the AMV audio framing in host arithmetic, live in
+// host/amv_container.c: plain C, no device -- they are part of every link of the host side, the FFmpeg one included)
 
 extern "C" int amvhip_adpcm_wav_encode_frame(amvhip_ctx* c, const int16_t* samples, int frame_size,
                                              int32_t state[2], uint8_t* frame, int buf_size) {

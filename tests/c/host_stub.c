@@ -8,7 +8,8 @@
  *   "zero"            device calls succeed and deliver zeros of the right SIZE (frames, samples, a minimal chunk):
  *                     the read-ahead windows, the lent pointers and the plugin's plane copies run in full, and a
  *                     wrong size anywhere is a sanitizer report.  Nothing here computes a codec result.
- * The pure-arithmetic entry points (sizes, strides) are restated: the host C's buffer sizes depend on them.
+ * The pure-arithmetic entry points of the device half (sizes, strides) are restated: the host C's buffer sizes depend on
+ * them.  (The AMV audio framing arithmetic is host C of the product, host/amv_container.c, and is linked, not restated.)
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -162,6 +163,11 @@ int amvhip_adpcm_encode_frame(amvhip_ctx *ctx, const int16_t *samples, uint32_t 
     sink = (int16_t)(samples[0] ^ samples[nsamp - 1u]);
     (void)sink;
     memset(chunk, 0, 8u + nsamp / 2u);
+    /* the chunk's FRAMING (adpcm.c:464-467: le16 first sample, le16 step index, le32 sample count) -- what a walk over the
+     * muxed file reads; the nibbles stay zero */
+    chunk[0] = (uint8_t)samples[0]; chunk[1] = (uint8_t)((uint16_t)samples[0] >> 8);
+    chunk[2] = (uint8_t)*step_index;
+    chunk[4] = (uint8_t)nsamp; chunk[5] = (uint8_t)(nsamp >> 8); chunk[6] = (uint8_t)(nsamp >> 16); chunk[7] = (uint8_t)(nsamp >> 24);
     return (int)(8u + nsamp / 2u);
 }
 int amvhip_adpcm_encode_frame_trellis(amvhip_ctx *ctx, const int16_t *samples, uint32_t nsamp, int32_t *step_index, uint32_t trellis,
@@ -178,14 +184,4 @@ int amvhip_adpcm_wav_encode_frame(amvhip_ctx *ctx, const int16_t *samples, int f
     if (frame_size < 1 || buf_size < need) return AMVHIP_ERR_ARG;
     memset(frame, 0, (size_t)need);
     return need;
-}
-uint32_t amvhip_amv_audio_pairs(uint32_t frame_size, uint32_t sample_rate, uint32_t *extra, uint64_t *samples_written)
-{
-    (void)sample_rate; (void)extra;
-    *samples_written += frame_size & ~1u;
-    return frame_size / 2u;
-}
-uint32_t amvhip_amv_audio_frame_size(uint32_t sample_rate, uint32_t tb_num, uint32_t tb_den)
-{
-    return tb_den ? (uint32_t)((uint64_t)sample_rate * tb_num / tb_den) : 0u;     /* amvenc.c:276-281 */
 }

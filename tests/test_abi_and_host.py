@@ -327,3 +327,69 @@ def test_host_c_under_sanitizers(amv1, tmp_path):
         outdir.mkdir()
         r = subprocess.run([lavc, amv1["path"], str(outdir)], env=dict(env, HOST_STUB_MODE="zero"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_plugin_inside_the_reference_ffmpeg(pkg, tmp_path):
+    """SURVEY.md section 8(f) row 2 as it is stated: the plugin inside the patched `ffmpeg` CLI and its `make test` recipe
+    (AMVmuxer/Makefile:15-17).  tools/ffmpeg_integration.sh copies the reference's FFmpeg tree to a temporary directory,
+    applies the maintainer's patch of INTEGRATION.md section 3 (the fork's own amv / adpcm_ima_amv tables renamed, one
+    Makefile line), builds it with host/amvhip_lavc.c + host/*.c + tests/c/host_stub.c as the device half, and runs
+    `ffmpeg -i in.avi -f amv -r 16 -s 160x120 -ac 1 -ar 22050 out.amv` and the decode back.  With a device of zeros the
+    pixels mean nothing; checked here: no duplicate / missing symbol, REGISTER_ENCDEC (allcodecs.c:64,255) picked up the
+    plugin's tables, ffmpeg.c's call path and the muxer's frame_size hack (amvenc.c:276-281) met the plugin and both runs
+    completed, and out.amv passes the walk compare_amv.c:29-97 does -- "movi" at 0x138, 00dc / 01wb in strict
+    alternation, every length, every audio chunk's sample count (1378 per chunk at 22 050 Hz / 16 fps, stretched to the
+    second's end as adpcm.c:474-477 does: the sequence amvhip_amv_audio_pairs gives), AMV_END_.  A second link takes the
+    real libamvhip.so as the device half: it links, lists the codecs, and -- no GPU here -- refuses to open them
+    instead of falling back.  Needs the reference tree; skipped on the GPU box."""
+    if not os.path.isdir("/root/reference/AMVmuxer/ffmpeg"):
+        pytest.skip("the reference tree is not on this machine")
+    work = tmp_path / "ffint"
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "ffmpeg_integration.sh"), str(work)], capture_output=True, text=True,
+                       timeout=1500, env=dict(os.environ, AMV_FFMPEG_JOBS="8"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ffmpeg_integration: ok"), (r.stdout[-3000:], r.stderr[-3000:])
+    for log in ("make.log", "make_real.log"):
+        text = open(work / log).read()
+        assert "multiple definition" not in text and "undefined reference" not in text
+    # the four tables in the binary are the plugin's, the fork's own sit beside them under their new names
+    tables = [line.split()[-1] for line in open(work / "tables.txt").read().splitlines()]
+    assert sorted(tables) == ["adpcm_ima_amv_decoder", "adpcm_ima_amv_encoder", "amv_decoder", "amv_decoder_cpu", "amv_encoder",
+                              "amv_encoder_cpu"]
+    for name in ("formats.txt", "formats_real.txt"):
+        fm = open(work / name).read()
+        assert re.search(r"^\s*DEA\s+adpcm_ima_amv\s*$", fm, flags=re.M) and re.search(r"^\s*DEV\s+amv\s*$", fm, flags=re.M)
+        assert re.search(r"^\s*E\s+amv\s+amv format", fm, flags=re.M)
+    enc, dec = open(work / "encode.log").read(), open(work / "decode.log").read()
+    assert "Video: amv, yuvj420p, 160x120" in enc and "Audio: adpcm_ima_amv, 22050 Hz, mono" in enc and "frame=" in enc
+    assert "Input #0, avi, from 'out.amv'" in dec and "Video: amv, yuvj420p, 160x120" in dec and "frame=" in dec
+    assert os.path.getsize(work / "back.avi") > 10000
+    # the real library as the device half: the codec does not open on a machine without a GPU, and nothing is written
+    assert not os.path.exists(work / "real_opened.txt")
+    assert "Error while opening codec for output stream" in open(work / "encode_real.log").read()
+
+    # the walk of compare_amv.c:29-97 (one file against what the recipe must produce)
+    d = open(work / "out.amv", "rb").read()
+    u32 = lambda p: int.from_bytes(d[p:p + 4], "little")
+    assert d[:4] == b"RIFF" and d[8:12] == b"AMV " and d[0x138:0x13c] == b"movi"            # compare_amv.c:30-44
+    assert (u32(0x20 + 0x20), u32(0x20 + 0x24), u32(0x20 + 0x28)) == (160, 120, 16)           # amvh: width, height, fps (AMVHeader.h:18-39)
+    lib = pkg.load_library()
+    extra, written = ctypes.c_uint32(0), ctypes.c_uint64(0)
+    frame_size = lib.amvhip_amv_audio_frame_size(22050, 1, 16)
+    assert frame_size == 1378
+    p, video, audio, samples = 0x13c, 0, 0, []
+    while d[p:p + 4] != b"AMV_":
+        tag, ln = d[p:p + 4], u32(p + 4)
+        assert tag == (b"00dc" if (video + audio) % 2 == 0 else b"01wb"), (p, tag)        # strict alternation (amvenc.c:378-406)
+        if tag == b"00dc":
+            video += 1
+            assert d[p + 8:p + 10] == b"\xff\xd8" and d[p + 8 + ln - 2:p + 8 + ln] == b"\xff\xd9"
+        else:
+            audio += 1
+            pairs = lib.amvhip_amv_audio_pairs(frame_size, 22050, ctypes.byref(extra), ctypes.byref(written))
+            assert ln == 8 + pairs and u32(p + 12) == 2 * pairs, (audio, ln, u32(p + 12), pairs)    # compare_amv.c:81-86
+            samples.append(2 * pairs)
+        p += 8 + ln                                                                          # no even-byte padding (amvenc.c:317-321)
+        assert p < len(d)
+    assert d[p:] == b"AMV_END_" and video >= 40 and video - audio in (0, 1)
+    # two whole seconds were crossed, each by a chunk stretched to end on it (adpcm.c:474-477): 15 x 1378 + 1380 = 22 050
+    assert set(samples) == {1378, 1380} and samples[15] == samples[31] == 1380 and sum(samples[:16]) == 22050
