@@ -249,7 +249,7 @@ def profiled_traffic(tag, dom):
                 if kname.split(" grid=")[0].split("<")[0].endswith(dom) and rec["hbm_corrected"] > 1e6]
         if hits:
             return max(hits), {"file": os.path.relpath(path, ROOT), "head": prof.get("head", ""),
-                               "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + WRITE_SIZE, separate passes"}
+                               "method": "rocprofv3 --pmc FETCH_SIZE (x2: every fabric read is a 128-byte line tallied at 64, calibrated per load shape in profiles/r06_fetch_shapes.json) + WRITE_SIZE, separate passes"}
     except (OSError, ValueError, KeyError):
         pass
     return None, None
@@ -282,7 +282,7 @@ def profiled_adpcm_traffic(dom):
         else:
             total = sum(v["hbm_corrected"] * v.get("launches_per_step", 1) for k, v in rows.items() if "adpcm_decode" not in k)
         return total, {"file": os.path.relpath(path, ROOT), "head": prof.get("head", ""),
-                       "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + WRITE_SIZE, separate passes; "
+                       "method": "rocprofv3 --pmc FETCH_SIZE (x2: every fabric read is a 128-byte line tallied at 64, profiles/r06_fetch_shapes.json) + WRITE_SIZE, separate passes; "
                                  "one row per kernel and grid size, summed over the chain's kernels"}
     except (OSError, ValueError, KeyError):
         return None, None
