@@ -125,6 +125,7 @@ SYMBOLS = {
     "amvhip_synth_audio_dev": (_int, [_vp, _u32, _u64, _u64, _vp, _vp]),
     "amvhip_set_entropy_mode": (_int, [_vp, _int]),
     "amvhip_entropy_stats": (_int, [_vp, _int, _vp]),
+    "amvhip_entropy_trace": (_int, [_vp, _vp, _u32]),
     "amvhip_decode_split_stats": (_int, [_vp, _vp]),
     "amvhip_adpcm_chain_stats": (_int, [_vp, _vp]),
     "amvhip_adpcm_quotient_table": (None, [_vp]),
@@ -325,6 +326,15 @@ class Context:
         return {"frames": out[0], "rounds": out[1], "max_rounds": out[2], "handed_to_serial": out[3], "waves": out[9],
                 "clocks_per_wave": {"zero": out[4] / waves, "first_walk": out[5] / waves, "sync_rounds": out[6] / waves,
                                     "write": out[7] / waves, "dc": out[8] / waves}}
+
+    def entropy_trace(self, tasks):
+        """per task (wave) of the last several-lanes-per-frame launch with gathering on: [tasks, 8] uint64 (include/amvhip.h)"""
+        import numpy as np
+        out = np.zeros((tasks, 8), np.uint64)
+        got = self.lib.amvhip_entropy_trace(self.h, out.ctypes.data, tasks)
+        if got < 0:
+            self._check(got, "entropy_trace")
+        return out[:got]
 
     def decode_split_stats(self):
         """last decode call: {"heavy": frames that got several entropy lanes, "light": frames that got one} (0, 0: no split)"""

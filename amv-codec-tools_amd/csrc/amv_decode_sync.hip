@@ -1143,7 +1143,8 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
 
         const bool timing = stats != nullptr && lane == 0;   // optional phase clock (amvhip_entropy_stats)
         unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
-        if (timing) tc[0] = tc[1] = clock64();
+        unsigned long long wall0 = 0;
+        if (timing) { tc[0] = tc[1] = clock64(); wall0 = wall_clock64(); }
 
         const uint32_t idx = task * kFrames + slot;
         const uint32_t frame = idx < n ? (list ? list[idx] : idx) : kNever;
@@ -1466,10 +1467,23 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
             // segments the decoder never started begin (and end) at the total; so does the end of the last one
             for (uint32_t m = seg_seen + sub; m <= sg.count; m += L) seg_out[m] = make_uint2(rec_total, rec_total);
         }
+        uint32_t wave_rounds = rounds;                        // the wave's frame that needed most
+        if (stats) {
+#pragma unroll
+            for (int off = 32; off; off >>= 1) wave_rounds = max(wave_rounds, (uint32_t)__shfl_xor((int)wave_rounds, off));
+        }
         if (timing) {
             tc[5] = clock64();
             for (int q = 0; q < 5; ++q) atomicAdd(&stats[4 + q], tc[q + 1] - tc[q]);
             atomicAdd(&stats[9], 1ull);
+            if (task < kTraceTasks) {   // the task's own line (amvhip_entropy_trace): where the launch's slowest waves spend their time
+                unsigned long long* tr = stats + kTraceBase + (unsigned long long)task * 8ull;
+                tr[0] = wall0;                              // constant-rate clock, 100 MHz: when the task began ...
+                tr[1] = wall_clock64();                     // ... and ended
+                for (int q = 0; q < 4; ++q) tr[2 + q] = tc[q + 2] - tc[q + 1];   // first walk, rounds, strict pass, DC pass (shader clocks)
+                tr[6] = wave_rounds | (unsigned long long)S << 32;
+                tr[7] = (unsigned long long)blockIdx.x << 32 | (unsigned long long)wave << 16 | (unsigned long long)L;
+            }
         }
         if (live && sub == 0) {
             if (stats) {   // optional: how hard the synchronisation worked (amvhip_entropy_stats)
@@ -1767,10 +1781,83 @@ __global__ __launch_bounds__(kLayoutBlock) void amv_layout_write_kernel(const ui
     }
 }
 
+// The three launches above as ONE workgroup, for batches of up to kLayoutSmall frames (round 6): a 10 000-frame stream's
+// decode is nine launches of which these three and the memset of the retry counters behind them do next to nothing --
+// 5 us each of a 0.7-ms step, and of the 0.3 ms of a rank's 1 250-frame share of it.  Sixteen threads take a block of 256
+// frames, sixteen frames each; the arithmetic is the three kernels' own, saturation for saturation (a block's total
+// through sat32, the blocks' prefix clamped at the capacity, a frame's line = min(prefix + its place in the block, capacity)),
+// so the lines are the same numbers whatever route made them (tests/test_gpu_parity.py::test_layout_routes_agree).
+// zero[0 .. nzero) is cleared on the way: the retry counter and the task queues of the kernels behind.
+constexpr uint32_t kLayoutSmall = 16384;
+__global__ __launch_bounds__(1024) void amv_layout_small_kernel(const uint32_t* __restrict__ lens, uint32_t n, LayoutSpec a, LayoutSpec b,
+                                                                uint32_t* __restrict__ zero, uint32_t nzero) {
+    __shared__ uint64_t s_tx[kLayoutSmall / kLayoutBlock], s_ty[kLayoutSmall / kLayoutBlock];   // per block: total, then prefix
+    const uint32_t t = threadIdx.x, blk = t >> 4, sub = t & 15u;
+    const uint32_t nb = (n + kLayoutBlock - 1u) / kLayoutBlock;
+    if (t < nzero) zero[t] = 0u;
+    const uint32_t first = blk * kLayoutBlock + sub * 16u;
+    uint32_t va[16], vb[16];
+    uint64_t mx = 0, my = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) {
+        const uint32_t i = first + k;
+        const uint32_t len = i < n ? lens[i] : 0u;
+        va[k] = i < n ? layout_lines(len, a) : 0u;
+        vb[k] = i < n && b.line ? layout_lines(len, b) : 0u;
+        mx += va[k]; my += vb[k];
+    }
+    // the sixteen threads of a block: inclusive scan of their sums (they are sixteen consecutive lanes of one wave)
+    uint64_t ix = mx, iy = my;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const uint64_t ax = (uint64_t)__shfl_up((unsigned long long)ix, d, 16), ay = (uint64_t)__shfl_up((unsigned long long)iy, d, 16);
+        if (sub >= (uint32_t)d) { ix += ax; iy += ay; }
+    }
+    if (sub == 15u) { s_tx[blk] = sat32(ix); s_ty[blk] = sat32(iy); }   // amv_layout_sums_kernel: the block's total
+    __syncthreads();
+    if (t < 64u) {   // amv_layout_scan_kernel: exclusive prefix of the blocks' totals, clamped at the capacities
+        const uint32_t cap_a = a.cap_lines, cap_b = b.line ? b.cap_lines : 0u;
+        const uint64_t vx = t < nb ? s_tx[t] : 0u, vy = t < nb ? s_ty[t] : 0u;
+        uint64_t px = vx, py = vy;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t ax = (uint64_t)__shfl_up((unsigned long long)px, d), ay = (uint64_t)__shfl_up((unsigned long long)py, d);
+            if (t >= (uint32_t)d) { px += ax; py += ay; }
+        }
+        const uint64_t allx = (uint64_t)__shfl((unsigned long long)px, 63), ally = (uint64_t)__shfl((unsigned long long)py, 63);
+        s_tx[t] = min(px - vx, (uint64_t)cap_a);
+        s_ty[t] = min(py - vy, (uint64_t)cap_b);
+        if (t == 0u) {                                         // the end of the last frame's space
+            a.line[n] = (uint32_t)min(allx, (uint64_t)cap_a);
+            if (b.line) b.line[n] = (uint32_t)min(ally, (uint64_t)cap_b);
+        }
+    }
+    __syncthreads();
+    // amv_layout_write_kernel: base of the block + the frame's place in it
+    uint64_t atx = s_tx[blk] + (ix - mx), aty = s_ty[blk] + (iy - my);
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) {
+        const uint32_t i = first + k;
+        if (i < n) {
+            a.line[i] = (uint32_t)min(atx, (uint64_t)a.cap_lines);
+            if (b.line) b.line[i] = (uint32_t)min(aty, (uint64_t)b.cap_lines);
+        }
+        atx += va[k]; aty += vb[k];
+    }
+}
+
 uint64_t layout_workspace(uint32_t n) { return ((uint64_t)(n + kLayoutBlock - 1u) / kLayoutBlock + 1u) * sizeof(uint2); }
 
-void launch_layout(const uint32_t* lens, uint32_t n, const LayoutSpec& a, const LayoutSpec& b, void* work, hipStream_t s) {
+// zero[0 .. nzero): words the launches behind the layout expect cleared (nzero <= 64); force_large: the three-launch route
+// whatever the batch size (the test that holds the two routes to the same numbers)
+void launch_layout(const uint32_t* lens, uint32_t n, const LayoutSpec& a, const LayoutSpec& b, void* work, uint32_t* zero, uint32_t nzero,
+                   bool force_large, hipStream_t s) {
     if (n == 0) return;
+    if (n <= kLayoutSmall && !force_large) {
+        hipLaunchKernelGGL(amv_layout_small_kernel, dim3(1), dim3(1024), 0, s, lens, n, a, b, zero, nzero);
+        return;
+    }
+    if (nzero) (void)hipMemsetAsync(zero, 0, (size_t)nzero * 4u, s);
     const uint32_t nb = (n + kLayoutBlock - 1u) / kLayoutBlock;
     uint2* sums = static_cast<uint2*>(work);
     hipLaunchKernelGGL(amv_layout_sums_kernel, dim3(nb), dim3(kLayoutBlock), 0, s, lens, n, a, b, sums);

@@ -28,6 +28,10 @@ void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
                     hipStream_t s);
 // lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units (amv_decode_sync.hip)
 int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels);
+// the statistics buffer of the synchronising entropy kernel (amvhip_entropy_stats / _trace): 16 words of counters, then
+// one line of eight 64-bit words per task (wave) for the first kTraceTasks tasks of a launch
+constexpr uint32_t kTraceBase = 16, kTraceTasks = 16384;
+constexpr size_t kStatsBytes = (size_t)(kTraceBase + 8u * kTraceTasks) * 8u;
 // Where the entropy stage puts its result.  rec == nullptr: dense coefficient lines in coef
 // ([n][blocks][64] int16).  Otherwise the records form, per frame: its lines of rec (one word per DC coefficient and
 // per non-zero AC coefficient, stream order: bits 0-5 index in block (0 = DC), 6-11 (block - blocks per frame) modulo 64, bit 15 filler,
@@ -59,7 +63,8 @@ struct LayoutSpec {
     uint32_t* line;
 };
 uint64_t layout_workspace(uint32_t n);
-void launch_layout(const uint32_t* lens, uint32_t n, const LayoutSpec& a, const LayoutSpec& b, void* work, hipStream_t s);
+void launch_layout(const uint32_t* lens, uint32_t n, const LayoutSpec& a, const LayoutSpec& b, void* work, uint32_t* zero, uint32_t nzero,
+                   bool force_large, hipStream_t s);
 // Frames whose chunk is more than twice the batch's mean chunk (by the pieces the layout gave their scans: ws_line) ->
 // heavy[0 .. count[0]), the others -> light[0 .. count[1]); count[0..1] zeroed by the caller.  A chip-filling batch decodes
 // the light ones one lane per frame and the heavy ones with several lanes each (amvhip_api.hip: entropy_front).

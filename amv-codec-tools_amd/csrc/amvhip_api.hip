@@ -54,6 +54,7 @@ struct amvhip_ctx {
     bool last_split = false;   // the last decode call made the two lists (amvhip_decode_split_stats)
     uint32_t cus = 256;   // compute units of the device
     bool want_stats = false;
+    bool layout_large = false;   // AMVHIP_LAYOUT=large: the three-launch layout whatever the batch size (test knob)
     double ws_bytes_per_frame = 0.0;
     int entropy_mode = AMVHIP_ENTROPY_AUTO;
     int adpcm_sweeps = 0;            // AMVHIP_ADPCM_SWEEPS: sweeps of the guessed-start route (-1: exhaustive route only)
@@ -295,6 +296,7 @@ extern "C" int amvhip_create(amvhip_ctx** out, int device) {
         if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->heavy_lanes = (uint32_t)v;
         if (v == -1) c->heavy_lanes = 1;    // two lists, one lane per frame in both (measurements)
     }
+    if (const char* e = getenv("AMVHIP_LAYOUT")) c->layout_large = strcmp(e, "large") == 0;   // test knob: the three-launch layout for small batches too
     if (const char* e = getenv("AMVHIP_ADPCM_SWEEPS")) {   // tuning / test knob: "map" = exhaustive route only, or a sweep count
         if (strcmp(e, "nosettle") == 0) {
             c->adpcm_settle = false;   // sweeps by stream length, then nothing: the chain's check sends the stream down the exhaustive route
@@ -393,13 +395,14 @@ static int entropy_front(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_byt
     if (int r = ensure(c, c->ws_line, ((size_t)n + 1) * 4)) return r;
     if (int r = ensure(c, c->ws_bytes, (size_t)n * 4)) return r;
     if (int r = ensure(c, c->layout, layout_workspace(n))) return r;
-    launch_layout(d_lens, n, LayoutSpec{2u, 32u, 0xffffffe0u, 4u, (uint32_t)ws_lines, (uint32_t*)c->ws_line.p}, rec_layout, c->layout.p, st);
-    if (int r = check_launch(c, "layout")) return r;
     uint32_t* retry_count = (uint32_t*)retry.p;
     uint32_t* retry_list = retry_count + 8;
     sinks.retry_list = retry_list;
     sinks.retry_count = retry_count;
-    HIP_TRY(c, hipMemsetAsync(retry_count, 0, 32, st));
+    // (the layout launch also clears the retry counter and the task queues behind it: retry_count[0 .. 8))
+    launch_layout(d_lens, n, LayoutSpec{2u, 32u, 0xffffffe0u, 4u, (uint32_t)ws_lines, (uint32_t*)c->ws_line.p}, rec_layout, c->layout.p,
+                  retry_count, 8u, c->layout_large, st);
+    if (int r = check_launch(c, "layout")) return r;
     {
         Timed t(c, AMVHIP_K_UNSTUFF, st);
         launch_unstuff(d_blob, blob_bytes, d_offs, d_lens, n, (const uint32_t*)c->ws_line.p, (uint32_t*)c->ws.p, (uint32_t*)c->ws_bytes.p,
@@ -1311,7 +1314,7 @@ extern "C" int amvhip_entropy_stats(amvhip_ctx* c, int enable, uint64_t out[10])
     if (!c) return AMVHIP_ERR_ARG;
     if (int r = use_device(c)) return r;
     std::lock_guard<std::mutex> lk(c->mu);
-    if (int r = ensure(c, c->stats, 128)) return r;
+    if (int r = ensure(c, c->stats, amv::kStatsBytes)) return r;
     HIP_TRY(c, hipDeviceSynchronize());
     if (out) {
         if (c->want_stats) HIP_TRY(c, hipMemcpy(out, c->stats.p, 80, hipMemcpyDeviceToHost));
@@ -1325,6 +1328,17 @@ extern "C" int amvhip_entropy_stats(amvhip_ctx* c, int enable, uint64_t out[10])
     HIP_TRY(c, hipMemset(c->stats.p, 0, 128));
     c->want_stats = enable != 0;
     return AMVHIP_OK;
+}
+
+extern "C" int amvhip_entropy_trace(amvhip_ctx* c, uint64_t* out, uint32_t tasks) {
+    if (!c || (tasks && !out)) return AMVHIP_ERR_ARG;
+    if (int r = use_device(c)) return r;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (tasks > amv::kTraceTasks) tasks = amv::kTraceTasks;
+    if (!c->stats.p || c->stats.cap < amv::kStatsBytes) return fail(c, AMVHIP_ERR_ARG, "entropy_trace: gathering was never switched on");
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out, (const uint64_t*)c->stats.p + amv::kTraceBase, (size_t)tasks * 64, hipMemcpyDeviceToHost));
+    return (int)tasks;
 }
 
 extern "C" int amvhip_decode_split_stats(amvhip_ctx* c, uint32_t out[2]) {

@@ -279,6 +279,12 @@ int amvhip_set_entropy_mode(amvhip_ctx *ctx, int mode);
  * rounds, writing pass, DC pass, and the number of waves}, clears them and switches gathering on
  * or off (off by default; costs a few atomics per frame). */
 int amvhip_entropy_stats(amvhip_ctx *ctx, int enable, uint64_t out[10]);
+/* ... and, per task (wave) of the last launch of the several-lanes-per-frame kernel while gathering was on, a line of
+ * eight words: {constant-rate clock (100 MHz) at the task's begin, at its end, shader clocks of the first walk, the
+ * synchronisation rounds, the strict pass, the DC pass, rounds of the wave's worst frame | share length in bits << 32,
+ * workgroup << 32 | wave << 16 | lanes per frame}.  out: 8 * tasks words; returns the lines copied (< 0: error).
+ * What a launch one generation of waves deep lasts as long as: its slowest task (tools/time_kernels.py --trace). */
+int amvhip_entropy_trace(amvhip_ctx *ctx, uint64_t *out, uint32_t tasks);
 /* A batch large enough to give every frame ONE entropy lane (a wave's 64 frames then finish together) gives the frames
  * whose chunk is over twice the batch's mean chunk several lanes each instead -- the split is made on the device, from
  * d_lens.  out[] = {frames of the LAST decode call that went the several-lanes way, frames that went one lane per frame};

@@ -2017,46 +2017,59 @@ def test_decode_lengths_that_overflow_the_layout(pkg, orc):
     workgroup's 256 lengths would wrap after 16 of them, and a frame's workspace window would start below its
     predecessor's).  The layout saturates instead: those frames (clamped to the blob, as include/amvhip.h promises) and
     the ones behind them take the serial kernel, every frame decodes to what the oracle makes of the bytes from its offset
-    to the end of the blob, and the frames in front of them are untouched.  Both parallel entropy kernels."""
+    to the end of the blob, and the frames in front of them are untouched.  Both parallel entropy kernels, and BOTH layout
+    routes -- the one-workgroup kernel a batch of up to 16 384 frames gets (round 6) and the three launches of larger ones
+    (AMVHIP_LAYOUT=large) -- which must lay out the same lines: the same frames handed to the serial kernel, the same bytes.
+    The huge lengths sit inside one block of 256 frames, and across the boundary of two."""
     import os
+    import torch
     w, h = 160, 120
     chunks = _synth_chunks(orc, 12, w, h)
-    n = 300
+    n = 600
     seq = [chunks[i % len(chunks)] for i in range(n)]
     blob, offs, lens, nbytes = _blob_of(seq)
-    huge = range(100, 120)
-    lens2 = lens.copy()
-    for i in huge:
-        lens2[i] = 0xfffffff0 - (i & 3)
     want = np.stack([orc.decode_frame(c, w, h)[0] for c in chunks])
-    want_huge = {i: orc.decode_frame(blob[int(offs[i]):nbytes].tobytes(), w, h) for i in huge}
-    old = os.environ.get("AMVHIP_SYNC_LANES")
-    ctxs = []
+    keep = {k: os.environ.get(k) for k in ("AMVHIP_SYNC_LANES", "AMVHIP_LAYOUT")}
+    ctxs = {}
     try:
         for lanes in (None, "1"):
-            if lanes:
-                os.environ["AMVHIP_SYNC_LANES"] = lanes
-            ctxs.append(pkg.Context(0))
+            for layout in (None, "large"):
+                for k, v in (("AMVHIP_SYNC_LANES", lanes), ("AMVHIP_LAYOUT", layout)):
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                ctxs[(lanes, layout)] = pkg.Context(0)
     finally:
-        if old is None:
-            os.environ.pop("AMVHIP_SYNC_LANES", None)
-        else:
-            os.environ["AMVHIP_SYNC_LANES"] = old
-    import torch
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     try:
-        for c in ctxs:
-            d_out = torch.full((n, h, c.stride(w)), 0x5A, dtype=torch.uint8, device="cuda:0")
-            d_st = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
-            c.decode_batch_dev(_t(blob), nbytes, _t(offs), _t(lens2), n, w, h, 0, d_out, d_st, torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            got, st = d_out.cpu().numpy(), d_st.cpu().numpy()
-            for i in range(n):
-                if i in want_huge:
-                    assert st[i] == want_huge[i][1] and (got[i] == want_huge[i][0]).all(), i
-                else:
-                    assert st[i] == 0 and (got[i] == want[i % len(chunks)]).all(), i
+        for huge in (range(100, 120), range(250, 270), range(0, 0)):
+            lens2 = lens.copy()
+            for i in huge:
+                lens2[i] = 0xfffffff0 - (i & 3)
+            want_huge = {i: orc.decode_frame(blob[int(offs[i]):nbytes].tobytes(), w, h) for i in huge}
+            handed = {}
+            for key, c in ctxs.items():
+                d_out = torch.full((n, h, c.stride(w)), 0x5A, dtype=torch.uint8, device="cuda:0")
+                d_st = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+                c.decode_batch_dev(_t(blob), nbytes, _t(offs), _t(lens2), n, w, h, 0, d_out, d_st, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                handed[key] = c.entropy_stats(False)["handed_to_serial"]
+                got, st = d_out.cpu().numpy(), d_st.cpu().numpy()
+                for i in range(n):
+                    if i in want_huge:
+                        assert st[i] == want_huge[i][1] and (got[i] == want_huge[i][0]).all(), (key, i)
+                    else:
+                        assert st[i] == 0 and (got[i] == want[i % len(chunks)]).all(), (key, i)
+            for lanes in (None, "1"):          # the two routes laid out the same windows: the same frames ran out of them
+                assert handed[(lanes, None)] == handed[(lanes, "large")], (list(huge)[:1], handed)
+            assert (handed[(None, None)] > 0) == (len(huge) > 0), handed
     finally:
-        for c in ctxs:
+        for c in ctxs.values():
             c.close()
 
 

@@ -22,6 +22,7 @@ ap.add_argument("--serial", action="store_true")
 ap.add_argument("--noise", action="store_true", help="white-noise frames (every coefficient of every block non-zero)")
 ap.add_argument("--mixed", type=int, default=0, help="every k-th frame white noise")
 ap.add_argument("--same", type=int, default=-1, help="every frame of the batch is a copy of this frame (no spread in sync rounds)")
+ap.add_argument("--trace", default="", help="write the per-wave lines of the several-lanes-per-frame launch (amvhip_entropy_trace) to this file")
 a = ap.parse_args()
 pkg = entry.load_package()
 ctx = pkg.Context(0)
@@ -75,4 +76,22 @@ ctx.decode_batch_dev(blob, cap, offs, lens, n, w, h, 0, out, st, s)
 es = ctx.entropy_stats(False)
 res["sync"] = {"mean_rounds": round(es["rounds"] / max(es["frames"], 1), 2), "max_rounds": es["max_rounds"],
                "kclk_per_wave": {k: round(v / 1e3, 1) for k, v in es["clocks_per_wave"].items()}}
+if a.trace:
+    import numpy as np
+    tr = ctx.entropy_trace(16384)
+    tr = tr[tr[:, 1] != 0]
+    if len(tr):
+        t0 = int(tr[:, 0].min())
+        dur = (tr[:, 1] - tr[:, 0]).astype(np.int64) / 100.0          # us (100 MHz)
+        beg = (tr[:, 0].astype(np.int64) - t0) / 100.0
+        end = beg + dur
+        rounds = (tr[:, 6] & np.uint64(0xffffffff)).astype(np.int64)
+        share = (tr[:, 6] >> np.uint64(32)).astype(np.int64)
+        order = np.argsort(-end)
+        res["trace"] = {"waves": int(len(tr)), "launch_us": float(end.max()), "begin_us_p50_max": [float(np.median(beg)), float(beg.max())],
+                        "duration_us_p50_p99_max": [float(np.percentile(dur, q)) for q in (50, 99, 100)],
+                        "rounds_hist": {int(k): int((rounds == k).sum()) for k in np.unique(rounds)},
+                        "last_to_end": [{"end_us": float(end[i]), "begin_us": float(beg[i]), "rounds": int(rounds[i]), "share_bits": int(share[i]),
+                                         "kclk": [int(tr[i, 2 + q]) // 1000 for q in range(4)]} for i in order[:12]]}
+        np.save(a.trace, tr)
 print(json.dumps(res))
