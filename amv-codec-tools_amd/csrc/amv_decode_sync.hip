@@ -1554,8 +1554,9 @@ void launch_fast(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, const
     uint32_t waves = (tasks + cus - 1u) / cus;
     if (waves < 4u) waves = 4u;
     if (waves > kMaxWaves) waves = kMaxWaves;
-    uint32_t grid = (tasks + waves - 1u) / waves;
-    if (grid > cus) grid = cus;
+    // a workgroup on EVERY compute unit the tasks can reach (round 6: 2 500 tasks in workgroups of ten were 250 workgroups
+    // on a chip of 256 units; the waves that find the queue empty leave at once)
+    const uint32_t grid = tasks < cus ? tasks : cus;
     hipLaunchKernelGGL((amv_huffman_fast_kernel<kFlush>), dim3(grid), dim3(kWave * waves), kFastTableBytes + waves * fast_per_wave(kFlush), s,
                        ws, ws_bytes, n, list, list_count, g.blocks, ws_line, d_img, out, status, nmcu_ok, queue, stats);
 }
@@ -1580,8 +1581,7 @@ void launch_sync2(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, cons
     uint32_t waves = (tasks + cus - 1u) / cus;
     if (waves < 4u) waves = 4u;
     if (waves > kMaxWaves) waves = kMaxWaves;
-    uint32_t grid = (tasks + waves - 1u) / waves;
-    if (grid > cus) grid = cus;
+    const uint32_t grid = tasks < cus ? tasks : cus;   // (every compute unit the tasks can reach: launch_fast)
     hipLaunchKernelGGL((amv_huffman_sync2_kernel<L>), dim3(grid), dim3(kWave * waves), kFastTableBytes + waves * fast_per_wave(8u), s, ws,
                        ws_bytes, n, list, list_count, g.blocks, ws_line, d_img, out, status, nmcu_ok, queue, stats);
 }

@@ -32,6 +32,8 @@ template <bool kYuv>
 __global__ __launch_bounds__(kWave) void amv_forward_kernel(Source in, uint32_t n, FrameSel sel, FrameGeom g, uint32_t nseg, uint32_t per_seg,
                                                             uint32_t qbias, int16_t* __restrict__ coef) {
     __shared__ __attribute__((aligned(16))) int16_t s_planes[kPlaneSamples];
+    __shared__ __attribute__((aligned(16))) uint32_t s_qmul[kQuantMulWords];
+    load_quant_mul(s_qmul, threadIdx.x, kWave);
     int16_t* const s_y = s_planes;
     int16_t* const s_cb = s_planes + 16 * kPitchY;
     int16_t* const s_cr = s_cb + 8 * kPitchC;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(kWave) void amv_forward_kernel(Source in, uint32_t 
         __syncthreads();
         if (lane < nb) {
             uint32_t out[32], nz_lo, nz_hi;
-            transform_block(s_y, s_cb, s_cr, lane, qbias, out, nz_lo, nz_hi);
+            transform_block(s_y, s_cb, s_cr, s_qmul, lane, qbias, out, nz_lo, nz_hi);
             uint4* dst = reinterpret_cast<uint4*>(coef + ((uint64_t)slot * g.mcus + (uint64_t)my * g.mcu_cols + m0) * 384u + lane * 64u);
 #pragma unroll
             for (int i = 0; i < 8; ++i) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);

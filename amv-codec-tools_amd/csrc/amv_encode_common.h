@@ -27,6 +27,12 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t w, int c) {
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(w), "v"(c));
     return d;
 }
+// x * w + c with x inside 24 bits and w a constant: one full-rate instruction, the low 32 bits of the exact result
+__device__ __forceinline__ int mad24s(int x, int w, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(w), "v"(c));
+    return d;
+}
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) {   // the low halves of two values side by side
     return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
 }
@@ -57,9 +63,12 @@ __device__ __forceinline__ void fdct8(int (&d)[8]) {
     } else {
         d[0] = descale(t10 + t11, kPass1Bits);
         d[4] = descale(t10 - t11, kPass1Bits);
-        const int z1 = (t12 + t13) * 4433;
-        d[2] = descale(z1 + t13 * 6270, kShift);
-        d[6] = descale(z1 - t12 * 15137, kShift);
+        // t12, t13 are sums of four row-pass outputs (each inside +-16385: see transform_block), their sum stays inside 19
+        // bits: every factor fits 24 bits and the products 31, so these are full-rate 24-bit multiply-adds too (as plain
+        // C the compiler made them v_mul_lo_u32 / v_mad_u64_u32, a quarter of the rate)
+        const int z1 = mad24s(t12 + t13, 4433, kHalf);
+        d[2] = mad24s(t13, 6270, z1) >> kShift;
+        d[6] = mad24s(t12, -15137, z1) >> kShift;
     }
     // z5 = (t4 + t5 + t6 + t7) * 9633; z1 = (t4 + t7) * -7373; z2 = (t5 + t6) * -20995; z3 = (t4 + t6) * -16069 + z5;
     // z4 = (t5 + t7) * -3196 + z5; d[7] = t4 * 2446 + z1 + z3; d[5] = t5 * 16819 + z2 + z4; d[3] = t6 * 25172 + z2 + z3;
@@ -243,22 +252,71 @@ __device__ __forceinline__ void convert_segment(const Source& in, uint32_t f, co
     convert_patches<kYuv>(in, px, f, g, my, m0, cnt, lane, s_y, s_cb, s_cr);
 }
 
+// The AC quantiser's multipliers, (1 << 22) / (8 * Q[scan]) (ff_convert_matrix, mpegvideo_enc.c:80-91, qscale 8), in the
+// order the column pass delivers coefficients -- entry c * 8 + r belongs to row r of column c -- luma then chroma.  A
+// workgroup copies them to LDS once (load_quant_mul) and a lane reads its component's eight per column as two 16-byte
+// pieces: round 5 selected each of the 63 between two literals per lane (a compare, a select and a constant to load per
+// coefficient, sixty-three registers held for them and the kernel's eight spills).
+struct QuantMul { uint32_t m[2][64]; };
+constexpr QuantMul make_quant_mul() {
+    QuantMul q{};
+    for (int c = 0; c < 8; ++c)
+        for (int r = 0; r < 8; ++r) {
+            const int scan = kScanOfNatural[r * 8 + c];
+            q.m[0][c * 8 + r] = (1u << 22) / (8u * kQuantLuma[scan]);
+            q.m[1][c * 8 + r] = (1u << 22) / (8u * kQuantChroma[scan]);
+        }
+    return q;
+}
+__device__ const QuantMul kQuantMul = make_quant_mul();
+constexpr uint32_t kQuantMulWords = 128;
+__device__ __forceinline__ void load_quant_mul(uint32_t* s_qmul, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < kQuantMulWords; i += nthreads) s_qmul[i] = (&kQuantMul.m[0][0])[i];
+}
+
+// x * m + c for x, m inside 24 bits: one full-rate instruction, the low 32 bits of the exact result
+__device__ __forceinline__ int mad24v(int x, uint32_t m, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(m), "v"(c));
+    return d;
+}
+// both 16-bit halves of w: 0 stays 0, anything else becomes 1
+__device__ __forceinline__ uint32_t halves_nonzero(uint32_t w) {
+    uint32_t d;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(w), "s"(0x00010001u));
+    return d;
+}
+// bits 0..15 of x to the even positions, bits 16..31 to the odd ones (bit i -> 2 i, bit 16 + i -> 2 i + 1)
+__device__ __forceinline__ uint32_t interleave_halves(uint32_t x) {
+    uint32_t t;
+    t = (x ^ (x >> 8)) & 0x0000ff00u; x = x ^ t ^ (t << 8);
+    t = (x ^ (x >> 4)) & 0x00f000f0u; x = x ^ t ^ (t << 4);
+    t = (x ^ (x >> 2)) & 0x0c0c0c0cu; x = x ^ t ^ (t << 2);
+    t = (x ^ (x >> 1)) & 0x22222222u; x = x ^ t ^ (t << 1);
+    return x;
+}
+
 // Stage 2: lane's block (lane = 6 * MCU in segment + block in MCU) out of the planes, in registers: 8 row passes,
 // DCTELEM truncation, 8 column passes, dct_quantize_c.  out: the 64 quantised coefficients, scan order, int16 pairs;
-// nz_lo / nz_hi: bit k set where coefficient k (scan order, k >= 1) is not zero.  Pairs and mask are put together
+// nz_lo / nz_hi: bit k set where coefficient k (scan order, k >= 1) is not zero.  Pairs are put together
 // as the columns come out: holding all 64 values for a pass in scan order cost registers, spills and 8 % of the
 // one-kernel encoder's time (and sending them to the LDS line two bytes at a time instead of through out[] cost 3 %).
 // The AC quantiser (mpegvideo_enc.c:3702-3712) is sign(x) * ((|x| * m + bias) >> 22) with m = (1 << 22) / (8 * Q)
 // (ff_convert_matrix :80-91, qscale 8); for x < 0 that is ceil((x * m - bias) / 2^22) = (x * m + (2^22 - 1 - bias)) >> 22,
 // so both signs are one multiply-add and one arithmetic shift: (x * m + (bias ^ (sign & (2^22 - 1)))) >> 22.
 // |x * m| stays under 2^31: x is an fdct output of 8-bit samples (|x| <= 2^14), m <= 2^22 / 40.
-__device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_t* s_cb, const int16_t* s_cr, uint32_t lane,
-                                                uint32_t qbias, uint32_t (&out)[32], uint32_t& nz_lo, uint32_t& nz_hi) {
+// The mask is read off the finished pairs (round 6; a compare, a select and an OR per coefficient before): both halves
+// of a pair reduced to 0 / 1 by one packed minimum, sixteen pairs shifted into one word -- even scan positions in its low
+// half, odd ones in its high half -- and the halves interleaved by four exchange steps.
+// s_qmul: the workgroup's copy of kQuantMul (load_quant_mul).
+__device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_t* s_cb, const int16_t* s_cr, const uint32_t* s_qmul,
+                                                uint32_t lane, uint32_t qbias, uint32_t (&out)[32], uint32_t& nz_lo, uint32_t& nz_hi) {
     const uint32_t m = lane / 6u, k6 = lane - 6u * m;
     const bool is_c = k6 >= 4u;
     const int16_t* in = is_c ? (k6 == 4u ? s_cb : s_cr) + m * 8u
                              : s_y + ((k6 >> 1) * 8u) * kPitchY + m * 16u + (k6 & 1u) * 8u;
     const uint32_t pitch = is_c ? kPitchC : kPitchY;
+    const uint4* const qm = reinterpret_cast<const uint4*>(s_qmul + (is_c ? 64u : 0u));
     int d[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {                                  // get_pixels + row_fdct
@@ -267,11 +325,12 @@ __device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_
 #pragma unroll
         for (int c = 0; c < 8; ++c) d[r][c] = (c & 1) ? ((int)ws[c >> 1] >> 16) : (int)(int16_t)(ws[c >> 1] & 0xffffu);
         fdct8<0>(d[r]);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) d[r][c] = (int16_t)d[r][c];    // DCTELEM is 16 bit (dsputil.h:38)
+        // DCTELEM is 16 bit (dsputil.h:38): nothing to truncate -- the planes hold samples of -128..127 (luma / chroma_u /
+        // chroma_v, the level-shifted bytes of a YUVJ420P source), for which every row-pass output is inside +-16385
+        // (the sum of |weight| * 128 over its eight inputs: 16384 for d[0], d[4], under 15138 for the others), and a
+        // column-pass output inside +-8193 (tests/test_oracle_pin.py::test_fdct_outputs_fit_dctelem)
     }
     const int bias = (int)(qbias << 14);   // intra_quant_bias << (QMAT_SHIFT - QUANT_BIAS_SHIFT), :3679
-    nz_lo = nz_hi = 0u;
 #pragma unroll
     for (int i = 0; i < 32; ++i) out[i] = 0u;
 #pragma unroll
@@ -279,11 +338,13 @@ __device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_
         int col[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) col[r] = d[r][c];
+        const uint4 ma = qm[2 * c], mb = qm[2 * c + 1];            // this column's multipliers (on their way during the pass)
+        const uint32_t mul[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
         fdct8<1>(col);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int scan = kScanOfNatural[r * 8 + c];
-            const int x = (int16_t)col[r];
+            const int x = col[r];
             int q;
             if (r == 0 && c == 0) {        // DC: (block[0] + q/2) / q with q = 8 * step, :3670-3676
                 constexpr int ql = 8 * kQuantLuma[0], qc = 8 * kQuantChroma[0];
@@ -291,16 +352,20 @@ __device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_
                 const int a = is_c ? (ax + (qc >> 1)) / qc : (ax + (ql >> 1)) / ql;
                 q = x < 0 ? -a : a;
             } else {
-                const int ml = (int)((1u << 22) / (8u * kQuantLuma[scan])), mc = (int)((1u << 22) / (8u * kQuantChroma[scan]));
                 const int sign = x >> 31;
-                q = (x * (is_c ? mc : ml) + (bias ^ (sign & 0x3fffff))) >> 22;
-                const uint32_t bit = q != 0 ? 1u : 0u;
-                if (scan >= 32) nz_hi |= bit << (scan - 32);
-                else nz_lo |= bit << scan;
+                q = mad24v(x, mul[r], bias ^ (sign & 0x3fffff)) >> 22;
             }
             out[scan >> 1] |= ((uint32_t)q & 0xffffu) << (16 * (scan & 1));
         }
     }
+    uint32_t even_odd_lo = 0u, even_odd_hi = 0u;                  // bit i: coefficient 2 i (32 + 2 i) != 0, bit 16 + i: coefficient 2 i + 1
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        even_odd_lo |= halves_nonzero(out[i]) << i;
+        even_odd_hi |= halves_nonzero(out[16 + i]) << i;
+    }
+    nz_lo = interleave_halves(even_odd_lo) & ~1u;                  // (the DC is not in the mask)
+    nz_hi = interleave_halves(even_odd_hi);
 }
 
 // coefficient k of lane `lane`'s 128-byte line in an LDS region of 64 lines: 16-byte granules XOR-swizzled by lane, so

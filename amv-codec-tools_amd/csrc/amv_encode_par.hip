@@ -40,7 +40,7 @@ constexpr uint32_t kLanes = kWave * kWaves;
 constexpr uint32_t kOwnWords = 8;                 // a lane's scratch: 256 bits (a block takes ~41 on the bench stream)
 constexpr uint32_t kWindowWords = 1280;           // the round's bit string: 5 KB
 // LDS: four regions of planes / lines (32 KB), the scratch (8 KB), the window (5 KB), the code book (4 KB), the
-// symbol numbers (1 KB): 50 KB, three workgroups per CU
+// symbol numbers (1 KB), the quantiser's multipliers (0.5 KB): 50.5 KB, three workgroups per CU
 constexpr uint32_t kRegionBytes = kPlaneSamples * 2;
 
 __device__ __forceinline__ void wave_sync() {
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kLanes, 3) void amv_encode_frame_kernel(
     __shared__ uint32_t s_bits[kWindowWords];
     __shared__ uint32_t s_book[4 * 256];
     __shared__ uint32_t s_part[kWaves];
+    __shared__ __attribute__((aligned(16))) uint32_t s_qmul[kQuantMulWords];   // the quantiser's multipliers (load_quant_mul)
     __shared__ uint32_t s_aux[kWaves][kWave + 1];      // per block of a wave's segment: number of its first symbol | DC difference << 16
     __shared__ int s_lastdc[2][kWaves][4];            // DC of the last MCU's Y3, Cb, Cr of the segment a wave took, by round parity
 
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(kLanes, 3) void amv_encode_frame_kernel(
     const uint32_t f = blockIdx.x;
     for (uint32_t i = tl; i < 1024u; i += kLanes) s_book[i] = (&img->code[0][0])[i];
     for (uint32_t i = tl; i < kWindowWords; i += kLanes) s_bits[i] = 0u;
+    load_quant_mul(s_qmul, tl, kLanes);
     uint8_t* const region = s_region[wave];
     int16_t* const s_y = reinterpret_cast<int16_t*>(region);
     int16_t* const s_cb = s_y + 16 * kPitchY;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(kLanes, 3) void amv_encode_frame_kernel(
             convert_segment<kYuv>(in, f, g, my, m0, cnt, lane, s_y, s_cb, s_cr);
             wave_sync();
             uint32_t line[32];
-            if (live) transform_block(s_y, s_cb, s_cr, lane, qbias, line, nz_lo, nz_hi);
+            if (live) transform_block(s_y, s_cb, s_cr, s_qmul, lane, qbias, line, nz_lo, nz_hi);
             wave_sync();                                          // every lane has its samples: the planes become the lines
             if (live) {
                 dc = (int)(int16_t)(line[0] & 0xffffu);

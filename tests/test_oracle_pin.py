@@ -80,6 +80,64 @@ def test_fdct_matches_reference_build(orc):
         assert (a == b).all()
 
 
+def test_fdct_outputs_fit_dctelem(orc):
+    """What lets the device's transform_block (csrc/amv_encode_common.h) leave out DCTELEM's 16-bit truncation
+    (dsputil.h:38) and use 24-bit multiply-adds in the column pass: for samples of -128..127 -- all the planes ever hold --
+    every output of jfdctint.c's row pass is inside +-16385 and every output of the column pass inside +-8193.  The passes
+    are restated here in exact integer arithmetic (checked against the oracle's amvo_fdct_islow, itself pinned by the
+    reference's jfdctint.c), the bound is the sum of |weight| over a pass's eight inputs, and the inputs that reach it --
+    every output's own sign pattern at full swing -- go through both passes."""
+    def one_pass(d, row):
+        shift, up = (13 - 4, 4) if row else (13 + 4, None)
+        desc = lambda v, n: (v + (1 << (n - 1))) >> n
+        t0, t7, t1, t6 = d[0] + d[7], d[0] - d[7], d[1] + d[6], d[1] - d[6]
+        t2, t5, t3, t4 = d[2] + d[5], d[2] - d[5], d[3] + d[4], d[3] - d[4]
+        t10, t13, t11, t12 = t0 + t3, t0 - t3, t1 + t2, t1 - t2
+        o = [0] * 8
+        o[0] = (t10 + t11) << up if row else desc(t10 + t11, 4)
+        o[4] = (t10 - t11) << up if row else desc(t10 - t11, 4)
+        z1 = (t12 + t13) * 4433
+        o[2], o[6] = desc(z1 + t13 * 6270, shift), desc(z1 - t12 * 15137, shift)
+        z1, z2, z3, z4 = t4 + t7, t5 + t6, t4 + t6, t5 + t7
+        z5 = (z3 + z4) * 9633
+        a4, a5, a6, a7 = t4 * 2446, t5 * 16819, t6 * 25172, t7 * 12299
+        z1, z2, z3, z4 = z1 * -7373, z2 * -20995, z3 * -16069 + z5, z4 * -3196 + z5
+        o[7], o[5], o[3], o[1] = desc(a4 + z1 + z3, shift), desc(a5 + z2 + z4, shift), desc(a6 + z2 + z3, shift), desc(a7 + z1 + z4, shift)
+        return o
+
+    def fdct2(block):                      # jfdctint.c:262-: rows, then columns
+        rows = [one_pass([int(v) for v in block[r]], True) for r in range(8)]
+        cols = [one_pass([rows[r][c] for r in range(8)], False) for c in range(8)]
+        return rows, [[cols[c][r] for c in range(8)] for r in range(8)]
+
+    rng = np.random.default_rng(12)
+    for it in range(300):                  # the restatement is the oracle's transform
+        a = rng.integers(-128, 128, (8, 8)).astype(np.int16)
+        b = a.copy().reshape(64)
+        orc.lib().amvo_fdct_islow(b.ctypes.data)
+        assert (np.array(fdct2(a)[1]).reshape(64) == b).all()
+    # weights of a pass: the response to unit inputs, exact in rational arithmetic = the integer pass without its rounding
+    big = 1 << 20
+    w = np.array([one_pass([big if i == k else 0 for i in range(8)], True) for k in range(8)], dtype=np.float64) / big   # [input][output]
+    worst_row = worst_col = 0
+    for u in range(8):
+        for v in range(8):
+            # the block that drives output (v, u) hardest: every sample at the end of its range that the output's sign pattern asks for
+            pat = np.sign(np.outer(w[:, v], w[:, u]))
+            for lo_hi in ((-128, 127), (127, -128)):
+                blk = np.where(pat >= 0, lo_hi[1], lo_hi[0])
+                rows, out = fdct2(blk)
+                worst_row = max(worst_row, max(abs(x) for r in rows for x in r))
+                worst_col = max(worst_col, max(abs(x) for r in out for x in r))
+    for it in range(2000):                 # ... and two-level blocks at random
+        rows, out = fdct2(rng.choice([-128, 127], (8, 8)))
+        worst_row = max(worst_row, max(abs(x) for r in rows for x in r))
+        worst_col = max(worst_col, max(abs(x) for r in out for x in r))
+    assert 16000 < worst_row <= 16385 and 8000 < worst_col <= 8193, (worst_row, worst_col)
+    bound_row = max(np.abs(w[:, k]).sum() * 128 for k in range(8))
+    assert bound_row <= 16385, bound_row
+
+
 def test_wav_layout_encoder_matches_reference_build(orc):
     R = orc.ref()
     if R is None:

@@ -1,0 +1,160 @@
+// How many instructions does each phase of the encoder's front half take?  (amv_encode_common.h: transform_block and the
+// colour conversion in front of it.)  Every phase is compiled as a kernel of its own -- inputs from memory, outputs to
+// memory, so that nothing is folded away -- and tools/count_encode_phases.py counts the instructions of each in the
+// disassembly and subtracts the load / store scaffolding measured by the empty probes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fwrapv -fno-strict-aliasing -c tools/count_encode_phases.hip -o /tmp/phases.o
+#include "../amv-codec-tools_amd/csrc/amv_encode_common.h"
+
+using namespace amv;
+using namespace amv::enc;
+
+// 64 ints in, 64 ints out: the scaffolding every probe below shares
+extern "C" __global__ void probe_copy64(const int* in, int* out) {
+    int d[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) d[i] = in[threadIdx.x * 64 + i];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = d[i];
+}
+// get_pixels: eight 16-byte LDS rows unpacked into 64 sign-extended samples
+extern "C" __global__ void probe_unpack(const int16_t* planes, int* out) {
+    __shared__ __attribute__((aligned(16))) int16_t s[kPlaneSamples];
+    for (uint32_t i = threadIdx.x; i < kPlaneSamples; i += 64) s[i] = planes[i];
+    __syncthreads();
+    const int16_t* in = s + (threadIdx.x / 6u) * 16u;
+    int d[64];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint4 q = *reinterpret_cast<const uint4*>(in + r * kPitchY);
+        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) d[r * 8 + c] = (c & 1) ? ((int)ws[c >> 1] >> 16) : (int)(int16_t)(ws[c >> 1] & 0xffffu);
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = d[i];
+}
+extern "C" __global__ void probe_unpack_base(const int16_t* planes, int* out) {   // the same without the unpacking: LDS fill + stores
+    __shared__ __attribute__((aligned(16))) int16_t s[kPlaneSamples];
+    for (uint32_t i = threadIdx.x; i < kPlaneSamples; i += 64) s[i] = planes[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = s[threadIdx.x + i];
+}
+extern "C" __global__ void probe_rows(const int* in, int* out) {       // 8 row passes
+    int d[8][8];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) d[i >> 3][i & 7] = in[threadIdx.x * 64 + i];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        fdct8<0>(d[r]);
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = d[i >> 3][i & 7];
+}
+extern "C" __global__ void probe_cols(const int* in, int* out) {       // 8 column passes
+    int d[8][8];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) d[i >> 3][i & 7] = in[threadIdx.x * 64 + i];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int col[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) col[r] = d[r][c];
+        fdct8<1>(col);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d[r][c] = col[r];
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = d[i >> 3][i & 7];
+}
+// dct_quantize_c on 64 values: round 6's form (multipliers from LDS, one multiply-add and one shift per coefficient, pairs packed)
+extern "C" __global__ void probe_quant(const int* in, uint32_t* out, uint32_t qbias) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_qmul[kQuantMulWords];
+    load_quant_mul(s_qmul, threadIdx.x, 64);
+    __syncthreads();
+    const bool is_c = threadIdx.x % 6u >= 4u;
+    const uint4* const qm = reinterpret_cast<const uint4*>(s_qmul + (is_c ? 64u : 0u));
+    int x[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) x[i] = (int16_t)in[threadIdx.x * 64 + i];
+    const int bias = (int)(qbias << 14);
+    uint32_t o[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[i] = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint4 ma = qm[2 * c], mb = qm[2 * c + 1];
+        const uint32_t mul[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int scan = kScanOfNatural[r * 8 + c];
+            const int v = x[r * 8 + c];
+            int q;
+            if (r == 0 && c == 0) {
+                constexpr int ql = 8 * kQuantLuma[0], qc = 8 * kQuantChroma[0];
+                const int ax = abs(v);
+                const int a = is_c ? (ax + (qc >> 1)) / qc : (ax + (ql >> 1)) / ql;
+                q = v < 0 ? -a : a;
+            } else {
+                q = mad24v(v, mul[r], bias ^ ((v >> 31) & 0x3fffff)) >> 22;
+            }
+            o[scan >> 1] |= ((uint32_t)q & 0xffffu) << (16 * (scan & 1));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) out[threadIdx.x * 32 + i] = o[i];
+}
+extern "C" __global__ void probe_quant_base(const int* in, uint32_t* out, uint32_t qbias) {   // loads, int16 truncation, 32 stores
+    int x[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) x[i] = (int16_t)in[threadIdx.x * 64 + i];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) out[threadIdx.x * 32 + i] = (uint32_t)(x[2 * i] + x[2 * i + 1]) + qbias;
+}
+extern "C" __global__ void probe_mask(const uint32_t* in, uint32_t* out) {   // the non-zero mask off the 32 finished pairs
+    uint32_t o[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[i] = in[threadIdx.x * 32 + i];
+    uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { lo |= halves_nonzero(o[i]) << i; hi |= halves_nonzero(o[16 + i]) << i; }
+    out[threadIdx.x * 2] = interleave_halves(lo) & ~1u;
+    out[threadIdx.x * 2 + 1] = interleave_halves(hi);
+}
+extern "C" __global__ void probe_mask_base(const uint32_t* in, uint32_t* out) {
+    uint32_t o[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[i] = in[threadIdx.x * 32 + i];
+    uint32_t a = 0u, b = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a += o[i]; b += o[16 + i]; }
+    out[threadIdx.x * 2] = a;
+    out[threadIdx.x * 2 + 1] = b;
+}
+// the colour conversion of a ten-MCU segment: five trips of 4x2-pixel patches per lane (pixels already in registers / from memory)
+extern "C" __global__ void probe_colour(Source in, FrameGeom g, int16_t* out) {
+    __shared__ __attribute__((aligned(16))) int16_t s[kPlaneSamples];
+    convert_segment<false>(in, blockIdx.x, g, 0u, 0u, 10u, threadIdx.x, s, s + 16 * kPitchY, s + 16 * kPitchY + 8 * kPitchC);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kPlaneSamples; i += 64) out[i] = s[i];
+}
+extern "C" __global__ void probe_colour_base(Source in, FrameGeom g, int16_t* out) {
+    __shared__ __attribute__((aligned(16))) int16_t s[kPlaneSamples];
+    s[threadIdx.x] = (int16_t)in.pix[threadIdx.x + g.width];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kPlaneSamples; i += 64) out[i] = s[i];
+}
+// the whole of stage 2 as the kernels run it
+extern "C" __global__ void probe_transform_block(const int16_t* planes, uint32_t* out, uint32_t qbias) {
+    __shared__ __attribute__((aligned(16))) int16_t s[kPlaneSamples];
+    __shared__ __attribute__((aligned(16))) uint32_t s_qmul[kQuantMulWords];
+    for (uint32_t i = threadIdx.x; i < kPlaneSamples; i += 64) s[i] = planes[i];
+    load_quant_mul(s_qmul, threadIdx.x, 64);
+    __syncthreads();
+    uint32_t o[32], lo, hi;
+    transform_block(s, s + 16 * kPitchY, s + 16 * kPitchY + 8 * kPitchC, s_qmul, threadIdx.x % 60u, qbias, o, lo, hi);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) out[threadIdx.x * 34 + i] = o[i];
+    out[threadIdx.x * 34 + 32] = lo;
+    out[threadIdx.x * 34 + 33] = hi;
+}

@@ -48,7 +48,7 @@ for i in np.argsort(-end)[:16]:
 # what the launch would last if every wave with more rounds than r had needed only r (its rounds phase scaled down)
 out["if_rounds_were_capped"] = {}
 for cap in (3, 4, 5):
-    d2 = dur - np.where(rounds > cap, (ph[:, 1] * (1.0 - cap / np.maximum(rounds, 1))) / 2.4e3 * 1e3 / 1e3, 0.0)
+    d2 = dur - np.where(rounds > cap, ph[:, 1] * (1.0 - cap / np.maximum(rounds, 1)) / 2.4, 0.0)    # kclk at 2.4 GHz -> us
     out["if_rounds_were_capped"][str(cap)] = round(float((beg + d2).max()), 1)
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k not in ("last_to_end",)}, indent=1)[:3000])
