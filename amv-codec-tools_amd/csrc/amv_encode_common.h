@@ -80,6 +80,39 @@ __device__ __forceinline__ void fdct8(int (&d)[8]) {
     d[1] = dot2(o67, pair16(9633, 12299 - 7373 - 3196 + 9633), dot2(o45, pair16(-7373 + 9633, -3196 + 9633), kHalf)) >> kShift;
 }
 
+// The row pass (jfdctint.c:184-258) straight off the eight samples as they lie in the planes -- four dwords of two int16
+// each, (d0, d1) (d2, d3) (d4, d5) (d6, d7) -- with the butterflies in packed 16-bit arithmetic (round 6): samples are
+// -128..127, so t0 .. t7 stay inside +-255 and t10 .. t13 inside +-510; every pair the dot products want is a register the
+// packed adds and subtracts leave behind (their halves the other way round: the weights swap places instead), and
+// d[0], d[4] -- (t10 +- t11) << 4 -- are dot products with (16, +-16).  27 instructions instead of 33.
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ void fdct_row_packed(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int (&d)[8]) {
+    constexpr int kShift = 13 - 4, kHalf = 1 << (kShift - 1);
+    const uint32_t r3 = __builtin_amdgcn_alignbit(w3, w3, 16), r2 = __builtin_amdgcn_alignbit(w2, w2, 16);   // (d7, d6), (d5, d4)
+    const uint32_t a = pk_add16(w0, r3), s = pk_sub16(w0, r3);     // (t0, t1), (t7, t6)
+    const uint32_t b = pk_add16(w1, r2), t = pk_sub16(w1, r2);     // (t2, t3), (t5, t4)
+    const uint32_t rb = __builtin_amdgcn_alignbit(b, b, 16);       // (t3, t2)
+    const uint32_t e = pk_add16(a, rb), f = pk_sub16(a, rb);       // (t10, t11), (t13, t12)
+    d[0] = dot2(e, pair16(16, 16), 0);                             // (t10 + t11) << PASS1_BITS
+    d[4] = dot2(e, pair16(16, -16), 0);
+    d[2] = dot2(f, pair16(4433 + 6270, 4433), kHalf) >> kShift;    // (t12 + t13) * 4433 + t13 * 6270
+    d[6] = dot2(f, pair16(4433, 4433 - 15137), kHalf) >> kShift;   // (t12 + t13) * 4433 - t12 * 15137
+    // the odd half as in fdct8: t = (t5, t4), s = (t7, t6)
+    d[7] = dot2(s, pair16(-7373 + 9633, -16069 + 9633), dot2(t, pair16(9633, 2446 - 7373 - 16069 + 9633), kHalf)) >> kShift;
+    d[5] = dot2(s, pair16(-3196 + 9633, -20995 + 9633), dot2(t, pair16(16819 - 20995 - 3196 + 9633, 9633), kHalf)) >> kShift;
+    d[3] = dot2(s, pair16(9633, 25172 - 20995 - 16069 + 9633), dot2(t, pair16(-20995 + 9633, -16069 + 9633), kHalf)) >> kShift;
+    d[1] = dot2(s, pair16(12299 - 7373 - 3196 + 9633, 9633), dot2(t, pair16(-3196 + 9633, -7373 + 9633), kHalf)) >> kShift;
+}
+
 struct __attribute__((packed, aligned(1))) Px12 { uint32_t w[3]; };   // four RGB pixels, any alignment
 
 // LDS plane pitches in samples: multiples of 8 (16-byte rows for ds_read_b128), padded so that the
@@ -257,6 +290,11 @@ __device__ __forceinline__ void convert_segment(const Source& in, uint32_t f, co
 // workgroup copies them to LDS once (load_quant_mul) and a lane reads its component's eight per column as two 16-byte
 // pieces: round 5 selected each of the 63 between two literals per lane (a compare, a select and a constant to load per
 // coefficient, sixty-three registers held for them and the kernel's eight spills).
+constexpr int natural_of_scan(int scan) {
+    for (int i = 0; i < 64; ++i)
+        if (kScanOfNatural[i] == scan) return i;
+    return 0;
+}
 struct QuantMul { uint32_t m[2][64]; };
 constexpr QuantMul make_quant_mul() {
     QuantMul q{};
@@ -321,18 +359,14 @@ __device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_
 #pragma unroll
     for (int r = 0; r < 8; ++r) {                                  // get_pixels + row_fdct
         const uint4 q = *reinterpret_cast<const uint4*>(in + r * pitch);
-        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) d[r][c] = (c & 1) ? ((int)ws[c >> 1] >> 16) : (int)(int16_t)(ws[c >> 1] & 0xffffu);
-        fdct8<0>(d[r]);
+        fdct_row_packed(q.x, q.y, q.z, q.w, d[r]);
         // DCTELEM is 16 bit (dsputil.h:38): nothing to truncate -- the planes hold samples of -128..127 (luma / chroma_u /
         // chroma_v, the level-shifted bytes of a YUVJ420P source), for which every row-pass output is inside +-16385
         // (the sum of |weight| * 128 over its eight inputs: 16384 for d[0], d[4], under 15138 for the others), and a
         // column-pass output inside +-8193 (tests/test_oracle_pin.py::test_fdct_outputs_fit_dctelem)
     }
     const int bias = (int)(qbias << 14);   // intra_quant_bias << (QMAT_SHIFT - QUANT_BIAS_SHIFT), :3679
-#pragma unroll
-    for (int i = 0; i < 32; ++i) out[i] = 0u;
+    int held[64];                          // a coefficient waiting for the other half of its pair (the scan's neighbours sit a column apart at most)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {                                  // column pass + dct_quantize_c
         int col[8];
@@ -355,7 +389,11 @@ __device__ __forceinline__ void transform_block(const int16_t* s_y, const int16_
                 const int sign = x >> 31;
                 q = mad24v(x, mul[r], bias ^ (sign & 0x3fffff)) >> 22;
             }
-            out[scan >> 1] |= ((uint32_t)q & 0xffffu) << (16 * (scan & 1));
+            // the pair (scan 2 i, 2 i + 1) is put together by one byte permute when its second half arrives (a mask and an
+            // OR per coefficient before)
+            const int mate = natural_of_scan(scan ^ 1), mr = mate >> 3, mc = mate & 7;
+            if (mc < c || (mc == c && mr < r)) out[scan >> 1] = (scan & 1) ? pack16(held[scan ^ 1], q) : pack16(q, held[scan ^ 1]);
+            else held[scan] = q;
         }
     }
     uint32_t even_odd_lo = 0u, even_odd_hi = 0u;                  // bit i: coefficient 2 i (32 + 2 i) != 0, bit 16 + i: coefficient 2 i + 1

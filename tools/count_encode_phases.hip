@@ -40,13 +40,22 @@ extern "C" __global__ void probe_unpack_base(const int16_t* planes, int* out) { 
 #pragma unroll
     for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = s[threadIdx.x + i];
 }
-extern "C" __global__ void probe_rows(const int* in, int* out) {       // 8 row passes
+extern "C" __global__ void probe_rows(const uint32_t* in, int* out) {       // 8 row passes off the packed samples
     int d[8][8];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) d[i >> 3][i & 7] = in[threadIdx.x * 64 + i];
+    for (int r = 0; r < 8; ++r) {
+        const uint4 q = reinterpret_cast<const uint4*>(in)[threadIdx.x * 8 + r];
+        fdct_row_packed(q.x, q.y, q.z, q.w, d[r]);
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = d[i >> 3][i & 7];
+}
+extern "C" __global__ void probe_rows_base(const uint32_t* in, int* out) {
+    int d[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        fdct8<0>(d[r]);
+        const uint4 q = reinterpret_cast<const uint4*>(in)[threadIdx.x * 8 + r];
+        d[r][0] = q.x; d[r][1] = q.y; d[r][2] = q.z; d[r][3] = q.w; d[r][4] = q.x + 1; d[r][5] = q.y + 1; d[r][6] = q.z + 1; d[r][7] = q.w + 1;
     }
 #pragma unroll
     for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = d[i >> 3][i & 7];
@@ -79,8 +88,7 @@ extern "C" __global__ void probe_quant(const int* in, uint32_t* out, uint32_t qb
     for (int i = 0; i < 64; ++i) x[i] = (int16_t)in[threadIdx.x * 64 + i];
     const int bias = (int)(qbias << 14);
     uint32_t o[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) o[i] = 0u;
+    int held[64];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const uint4 ma = qm[2 * c], mb = qm[2 * c + 1];
@@ -98,7 +106,9 @@ extern "C" __global__ void probe_quant(const int* in, uint32_t* out, uint32_t qb
             } else {
                 q = mad24v(v, mul[r], bias ^ ((v >> 31) & 0x3fffff)) >> 22;
             }
-            o[scan >> 1] |= ((uint32_t)q & 0xffffu) << (16 * (scan & 1));
+            const int mate = natural_of_scan(scan ^ 1), mr = mate >> 3, mc = mate & 7;
+            if (mc < c || (mc == c && mr < r)) o[scan >> 1] = (scan & 1) ? pack16(held[scan ^ 1], q) : pack16(q, held[scan ^ 1]);
+            else held[scan] = q;
         }
     }
 #pragma unroll

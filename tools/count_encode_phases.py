@@ -49,8 +49,7 @@ def row(name, k, base=None):
 print("Instructions per 8x8 block (one lane's block: the wave executes them once for its 60 blocks), gfx950, hipcc -O3;")
 print("each phase compiled as a kernel of its own, its load / store scaffolding (the probe named *_base / probe_copy64) subtracted.\n")
 print("%-34s %6s %6s %5s %5s   %s" % ("phase", "VALU", "all", "LDS", "VMEM", "most frequent vector instructions"))
-print(row("get_pixels (8 LDS rows -> 64 ints)", "probe_unpack", "probe_unpack_base"))
-print(row("row pass x 8", "probe_rows", "probe_copy64"))
+print(row("row pass x 8 (off the packed samples)", "probe_rows", "probe_rows_base"))
 print(row("column pass x 8", "probe_cols", "probe_copy64"))
 print(row("quantiser x 63 + DC, pairs packed", "probe_quant", "probe_quant_base"))
 print(row("non-zero mask off the pairs", "probe_mask", "probe_mask_base"))
