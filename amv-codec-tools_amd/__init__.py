@@ -78,6 +78,7 @@ SYMBOLS = {
     "AmvCreateJpegFileFromFrameBuffer": (_int, [ctypes.POINTER(AMVDecoder), ctypes.c_char_p]),
     "AmvCreateJpegFileFromBuffer": (_int, [ctypes.POINTER(AMVInfo), ctypes.POINTER(FRAMEBUFF), ctypes.c_char_p]),
     "AmvConvertJpegFileToBmpFile": (_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "ConvertJpegFileToBmpFile": (_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "AmvCreateWavFileFromAmvFile": (_int, [ctypes.POINTER(AMVDecoder), _int, ctypes.c_char_p]),
     "decode_amv_frame": (_int, [_vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, _vp]),
     "encode_amv_frame": (_int, [_vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, _int, _vp, ctypes.c_uint]),

@@ -856,9 +856,9 @@ __global__ __launch_bounds__(256) void amv_adpcm_settle_kernel(
 // in a chunk's header (adpcm.c:466, byte 2) is the start its nibbles were coded from by whichever lane wrote it last -- a chunk
 // two lanes coded at once from different readings of its predecessor's end (what the front sweep's `listed` bits are there
 // to prevent) can carry a header that is not its state's start, and a state still marked kPredicted has no bytes at all.
+// (every chunk has a header, also one of no samples: encode_chunk writes the eight bytes whenever the lane has a chunk)
 __global__ __launch_bounds__(256) void amv_adpcm_check_kernel(const uint2* __restrict__ state, uint32_t n, const uint8_t* __restrict__ blob,
-                                                             const uint64_t* __restrict__ offs, const uint32_t* __restrict__ nsamp,
-                                                             uint32_t* __restrict__ need_map) {
+                                                             const uint64_t* __restrict__ offs, uint32_t* __restrict__ need_map) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t start = state[i].x;
@@ -1213,7 +1213,7 @@ const uint32_t* launch_adpcm_chain(const int16_t* pcm, const uint64_t* pcm_offs,
                                list[(sweeps + 1u) & 1u], count + sweeps + 1u, list[sweeps & 1u], count + sweeps + 2u, count + 63);
         }
         // (settle == false: a test knob -- the chain is left where its launched sweeps got it, and the check has to notice)
-        hipLaunchKernelGGL(amv_adpcm_check_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, state, n, blob, offs, nsamp, count + 63);
+        hipLaunchKernelGGL(amv_adpcm_check_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, state, n, blob, offs, count + 63);
     }
     return count + 63;
 }

@@ -1258,13 +1258,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
                 for (uint32_t q = 0; q < kMemo; ++q) if (left_at == q) final_code = cand[q];
             }
             const uint64_t open = __ballot(!settled);
-            if (!open) {
-                if (walks) {      // the final walk's counts
-                    my_blocks6 = lds_load(col_addr(lane, 3u * final_at + 1u));
-                    my_recs8 = lds_load(col_addr(lane, 3u * final_at + 2u));
-                }
-                break;
-            }
+            if (!open) break;
             if (open & seg) ++rounds;
             // this round's tasks of the lane's own share: its final start, or else the arrivals found at the end of the share
             // before that it has not walked from (newest first), then guesses with another position in the MCU
@@ -1347,8 +1341,18 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
                 lds_store(col_addr(lane, 19u), min(held + done, kMemo));
             }
         }
+        // the final walk's counts, for EVERY lane that has one -- also when the loop ended on its bound with a frame of the
+        // wave still open (that frame goes to the serial kernel below; the wave's other frames are settled, and their
+        // block and record prefix sums need their counts all the same)
+        if (walks && final_at != kNone) {
+            my_blocks6 = lds_load(col_addr(lane, 3u * final_at + 1u));
+            my_recs8 = lds_load(col_addr(lane, 3u * final_at + 2u));
+        }
         if (timing) tc[3] = clock64();
-        // the state every lane starts pass 4 in
+        // the state every lane starts pass 4 in: the bit offset inside the share's first word takes the code's five low bits --
+        // a symbol is at most 16 + 11 = 27 bits long, so a walk that stops at the first symbol STARTING at or behind the
+        // share's end arrives 0 .. 26 bits behind it
+        static_assert(16 + 11 < 32, "an arrival's offset behind the share's end must fit the state code's five bits");
         FastState entry{sub * S - 1u + (final_code & 31u), (final_code >> 5) & 63u, final_code >> 11, 0u, 0u, 0u};
         entry.dc = entry.k ? 0u : ~0u;
         if (sub == L - 1 || !live) { my_blocks6 = 0u; my_recs8 = 0u; }
@@ -1630,7 +1634,8 @@ __global__ __launch_bounds__(256) void amv_split_kernel(const uint32_t* __restri
     const bool in = i < n;
     // a frame's scan has (length + 47) / 16 pieces of the workspace (entropy_front's layout); twice the mean of that is the line
     const uint64_t all = ws_line[n];
-    const bool is_heavy = in && (uint64_t)((lens[in ? i : 0u] + 47u) >> 4) * n > 2u * all;
+    // (the frame's pieces as the layout counts them: 64-bit, so that a length of 0xffffffd1 or more does not wrap into a light frame)
+    const bool is_heavy = in && (((uint64_t)lens[in ? i : 0u] + 47u) >> 4) * n > 2u * all;
     const uint64_t hm = __ballot(is_heavy), lm = __ballot(in && !is_heavy);
     uint32_t hb = 0u, lb = 0u;
     if (lane == 0u) {

@@ -699,10 +699,19 @@ extern "C" int amvhip_decode_batch_async(amvhip_ctx* c, const uint8_t* blob, uin
         return r;
     HIP_TRY(c, hipEventRecord(c->ev_decoded, st));
     HIP_TRY(c, hipStreamWaitEvent(c->dstream, c->ev_decoded, 0));
-    HIP_TRY(c, hipMemcpyAsync(out, d_frames.p, fb * n, hipMemcpyDeviceToHost, c->dstream));
-    if (status) HIP_TRY(c, hipMemcpyAsync(status, d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->dstream));
-    HIP_TRY(c, hipEventRecord(c->ev_copied[which], c->dstream));
+    // From the first copy queued on dstream on, a failure must not leave this staging buffer with a copy in flight that
+    // no event stands for: the call after the next would pick the buffer again, wait for an event recorded two calls
+    // earlier, and let its kernels write under the orphaned copy.  So whatever fails below, dstream is drained before
+    // the call returns, and the call counts (the buffers keep taking turns).
+    hipError_t e = hipMemcpyAsync(out, d_frames.p, fb * n, hipMemcpyDeviceToHost, c->dstream);
+    if (e == hipSuccess && status) e = hipMemcpyAsync(status, d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->dstream);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_copied[which], c->dstream);
     ++c->async_calls;
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(c->dstream);
+        (void)hipEventRecord(c->ev_copied[which], c->dstream);   // (what the call after the next will wait for: nothing pending)
+        return fail(c, AMVHIP_ERR_DEVICE, "decode_batch_async: copy back: %s", hipGetErrorString(e));
+    }
     return AMVHIP_OK;
 }
 

@@ -882,6 +882,13 @@ int AmvCreateJpegFileFromFrameBuffer(AMVDecoder *amv, const char *dirname)
 static void wr16(unsigned char *p, unsigned v) { p[0] = (unsigned char)v; p[1] = (unsigned char)(v >> 8); }
 static void wr32(unsigned char *p, uint32_t v) { wr16(p, v & 0xffffu); wr16(p + 2, v >> 16); }
 
+/* AmvJpeg.h:94 / AmvJpeg.c:1289-1393: the name amvlib's own AmvConvertJpegFileToBmpFile forwards to (AMVDec.c:376-382);
+ * same file-level contract as that one (it has no NULL check of its own in the reference: here it gets the wrapper's) */
+int ConvertJpegFileToBmpFile(const char *jpgname, const char *bmpname)
+{
+    return AmvConvertJpegFileToBmpFile(jpgname, bmpname);
+}
+
 int AmvConvertJpegFileToBmpFile(const char *jpgname, const char *bmpname)
 {
     FILE *fp;

@@ -28,9 +28,46 @@ import torch
 import torch.distributed as dist
 
 
+# How a stream is cut.  Equal contiguous ranges unless `configure` gives the rank that holds the stream a
+# larger one: that rank pays no link for its own frames -- its range is decoded in place in the gathered buffer -- while
+# every other rank's frames cross its ONE xGMI link to the source (~153 GB/s), and a rank's decode of configs[3]'s share is
+# nearly flat in the number of frames (a launch one wave deep: 0.22 ms for 1 250 frames, 0.25 for 2 500).  With 8 ranks and
+# the source keeping a share s of a 10 000-frame 160x120 stream the gather is (1 - s) / 7 x 576 MB per link: s = 1/8 ->
+# 72 MB = 0.47 ms, s = 1/4 -> 62 MB = 0.40 ms, s = 1/2 -> 41 MB = 0.27 ms, against the source's own decode of s x 10 000
+# frames (0.24 / 0.25 / 0.31 ms) -- DESIGN.md section 10 has the arithmetic; NOTHING of it has been measured on more than
+# one GPU.  A knob, not a claim.
+_SPLIT = {"src": 0, "src_share": None}
+
+
+def configure(src_share=None, src=0):
+    """src_share: the fraction of a stream's frames rank `src` keeps (None: equal ranges); the others share the rest equally"""
+    if src_share is not None and not 0.0 <= float(src_share) <= 1.0:
+        raise ValueError("src_share must be inside [0, 1]")
+    _SPLIT["src"], _SPLIT["src_share"] = int(src), None if src_share is None else float(src_share)
+    _INDEX_CACHE.clear()
+
+
+def range_bounds(n_total, world):
+    """b[0 .. world]: rank r owns frames [b[r], b[r + 1]) -- contiguous, in rank order, covering [0, n_total)"""
+    share, src = _SPLIT["src_share"], _SPLIT["src"]
+    if share is None or world == 1 or not 0 <= src < world:
+        return [(r * n_total) // world for r in range(world + 1)]
+    mine = min(n_total, int(round(share * n_total)))
+    rest, others = n_total - mine, world - 1
+    sizes = [((k + 1) * rest) // others - (k * rest) // others for k in range(others)]
+    sizes.insert(src, mine)
+    b = [0]
+    for sz in sizes:
+        b.append(b[-1] + sz)
+    return b
+
+
 def frame_range(n_total, rank, world):
-    """contiguous slice [lo, hi) of rank `rank`: r*n/G .. (r+1)*n/G"""
-    return (rank * n_total) // world, ((rank + 1) * n_total) // world
+    """contiguous slice [lo, hi) of rank `rank`: r*n/G .. (r+1)*n/G, or what `configure` made of it"""
+    if _SPLIT["src_share"] is None:
+        return (rank * n_total) // world, ((rank + 1) * n_total) // world
+    b = range_bounds(n_total, world)
+    return b[rank], b[rank + 1]
 
 
 def shard_tables(offs, lens, rank, world):

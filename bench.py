@@ -607,6 +607,10 @@ def run_strong(E, args, w, h, n_total=10000):
     to rank 0 -- timed end to end ("scaling": "strong").  Runs next to the weak-scaling line, never instead of it."""
     ctx, dev, stream, sh = E.ctx, E.dev, E.stream, E.sh
     d_blob = d_offs = d_lens = None
+    # AMV_BENCH_SRC_SHARE: the fraction of the stream rank 0 -- which holds it and pays no link for its own frames -- keeps
+    # (sharding.configure; default: equal ranges).  Unmeasured on more than one GPU: a knob, not a claim.
+    share = os.environ.get("AMV_BENCH_SRC_SHARE")
+    sh.configure(src_share=float(share) if share else None)
     E.strong_phase = "making the stream"
     if E.rank == 0:
         d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, 0, n_total, w, h)
@@ -680,6 +684,7 @@ def run_strong(E, args, w, h, n_total=10000):
             "frames": n_total, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "frames_per_s": n_total * steps / elapsed,
             "phase_ms_max_over_ranks": phases, "backend": dist.get_backend(), "n_gpus": E.world, "sub_batches": k,
             "rccl_ranks": dist.get_world_size(),          # the communicator's size as the backend reports it
+            "src_share": float(share) if share else None, "frames_by_rank": [b - a for a, b in (sh.frame_range(n_total, r, E.world) for r in range(E.world))],
             "exchange": "source sends slices of its blob (point to point, one grouped call), frames are received straight into "
                         "slices of one buffer on rank 0, whose own range is decoded in place",
             "gathered_bytes_per_step": n_total * h * ctx.stride(w)}

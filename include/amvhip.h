@@ -137,6 +137,7 @@ void AmvJpegPutHeader(FILE *fp, unsigned short height, unsigned short width);
 int AmvCreateJpegFileFromFrameBuffer(AMVDecoder *amv, const char *dirname);
 int AmvCreateJpegFileFromBuffer(AMVInfo *amvinfo, FRAMEBUFF *framebuf, const char *filename);
 int AmvConvertJpegFileToBmpFile(const char *jpgname, const char *bmpname);
+int ConvertJpegFileToBmpFile(const char *jpgname, const char *bmpname);   /* AmvJpeg.h:94: the same function under its AmvJpeg.c name */
 int AmvCreateWavFileFromAmvFile(AMVDecoder *amv, int type, const char *wavfile);
 
 /* the names BASELINE.json's north_star uses; thin aliases of the single-frame paths.
@@ -255,7 +256,11 @@ int amvhip_decode_batch(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_byte
  * read-ahead behind AmvReadNextFrame uses them): copies and kernels are queued on a stream the context owns and
  * the call returns; amvhip_sync waits for everything queued so far.  blob/offs/lens must stay untouched, and
  * out/status unread, until then.  Page-locked buffers (amvhip_host_alloc) make the copies truly asynchronous;
- * pageable ones work but block.  Every host-buffer entry point of one context runs on that one stream, in order.
+ * pageable ones work but block.  The host-buffer entry points of one context queue their uploads and kernels on that
+ * one stream, in order; the decoded frames of amvhip_decode_batch_async come back on a second stream of the context
+ * (so that the copy of one call runs beside the upload and the kernels of the next).  The results of an *_async call
+ * are therefore complete only after amvhip_sync, which waits for both streams -- not after some other blocking
+ * host-buffer call (the blocking encode and ADPCM entry points synchronise the first stream alone).
  */
 int amvhip_decode_batch_async(amvhip_ctx *ctx, const uint8_t *blob, uint64_t blob_bytes,
                               const uint64_t *offs, const uint32_t *lens, uint32_t n,

@@ -681,6 +681,8 @@ def test_amvlib_export_helpers(ctx, pkg, orc, amv1, tmp_path):
         jpg = base + "-amvjpg_%06d_.jpg" % dec.contents.framebuf.framenum   # the counter runs on across rewinds (AMVDec.c:233,253)
         bmp = base + ".bmp"
         assert lib.AmvConvertJpegFileToBmpFile(jpg.encode(), bmp.encode()) == 0
+        bmp2 = bmp + ".by_its_amvjpeg_name.bmp"                    # AmvJpeg.h:94: the same function under the name AmvJpeg.c gives it
+        assert lib.ConvertJpegFileToBmpFile(jpg.encode(), bmp2.encode()) == 0 and open(bmp2, "rb").read() == open(bmp, "rb").read()
         b = open(bmp, "rb").read()
         want, st, _ = orc.decode_frame(amv1["video"][k], 128, 96)
         assert st == 0 and b[:2] == b"BM" and int.from_bytes(b[2:6], "little") == len(b) == 54 + want.size

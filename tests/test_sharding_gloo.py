@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, src_share=None):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as entry
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -32,6 +32,8 @@ def _worker(rank, world, port, q):
     try:
         orc = entry.load_oracle()
         sh = entry._load("amv_codec_tools_amd.sharding", os.path.join(entry.PKG_DIR, "sharding.py"))
+        if src_share is not None:
+            sh.configure(src_share=src_share)       # rank 0, which holds the stream, keeps this fraction of the frames
         dev = torch.device("cpu")
         blob = offs = lens = None
         if rank == 0:
@@ -80,8 +82,9 @@ def _worker(rank, world, port, q):
         assert [c[:2] for c in calls] == [(a, b - a) for a, b in sh.sub_ranges(lo, hi, 3)]
         # the scattered slices are exactly the rank's bytes: nothing padded
         my_blob, my_offs, my_lens, first = sh.scatter_stream(blob, offs, lens, dev)
-        assert first == lo and my_lens.numel() == hi - lo and int(my_offs[0]) == 0
-        assert my_blob.numel() == int(my_offs[-1]) + int(my_lens[-1])
+        assert first == lo and my_lens.numel() == hi - lo
+        if hi > lo:
+            assert int(my_offs[0]) == 0 and my_blob.numel() == int(my_offs[-1]) + int(my_lens[-1])
         # the stream held by rank 1, its chunks packed back to back (chunk starts at any byte): the source's own range is a
         # view of its blob, and a view the decode ABI accepts -- 4-byte aligned (amvhip_decode_batch_dev rejects others)
         pb = po = pl = None
@@ -92,10 +95,16 @@ def _worker(rank, world, port, q):
             for i in range(N):
                 pb[int(po[i]):int(po[i]) + int(l0_[i])] = b0_[int(o0_[i]):int(o0_[i]) + int(l0_[i])]
             pl = l0_
+        if src_share is not None:
+            sh.configure(src_share=src_share, src=1)  # (the larger range moves to the rank that holds this stream)
+            lo, hi = sh.frame_range(N, rank, world)
+            my_blob, my_offs, my_lens, first = sh.scatter_stream(blob, offs, lens, dev)   # rank 0's stream under the same cut
+            assert first == lo and my_lens.numel() == hi - lo
         s_blob, s_offs, s_lens, s_first = sh.scatter_stream(pb, po, pl, dev, src=1)
         assert s_first == lo and s_lens.numel() == hi - lo
-        assert s_blob.data_ptr() % 4 == 0 and 0 <= int(s_offs[0]) < 4
-        assert s_blob.numel() == int(s_offs[-1]) + int(s_lens[-1])
+        if hi > lo:
+            assert s_blob.data_ptr() % 4 == 0 and 0 <= int(s_offs[0]) < 4
+            assert s_blob.numel() == int(s_offs[-1]) + int(s_lens[-1])
         assert torch.equal(decode(s_blob, s_offs, s_lens, s_first), decode(my_blob, my_offs, my_lens, first))
         # gather_frames: the plain form (a decoder that knows nothing of `into`)
         mine = decode(my_blob, my_offs, my_lens, first)
@@ -113,12 +122,14 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_scatter_decode_gather(world):
+@pytest.mark.parametrize("world,src_share", [(2, None), (3, None), (3, 0.5), (2, 0.9), (3, 0.0)])
+def test_scatter_decode_gather(world, src_share):
+    """src_share: the rank that holds the stream keeps that fraction of the frames (sharding.configure) -- half of them among
+    three ranks, nine tenths among two, none at all (a source that only distributes): the same exchange, the same frames"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, src_share)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -137,3 +148,19 @@ def test_frame_ranges_cover_everything():
             assert rs[0][0] == 0 and rs[-1][1] == n
             assert all(rs[i][1] == rs[i + 1][0] for i in range(g - 1))
             assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+    # a larger range for the rank that holds the stream: still contiguous, in rank order, covering everything; the others equal
+    try:
+        for n in (0, 1, 7, 10000, 10001):
+            for g in (2, 3, 8):
+                for src in (0, 1, g - 1):
+                    for share in (0.0, 0.125, 0.25, 0.5, 1.0):
+                        sh.configure(src_share=share, src=src)
+                        rs = [sh.frame_range(n, r, g) for r in range(g)]
+                        assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(g - 1))
+                        assert rs[src][1] - rs[src][0] == min(n, int(round(share * n)))
+                        rest = [b - a for r, (a, b) in enumerate(rs) if r != src]
+                        assert max(rest) - min(rest) <= 1
+                        assert sh.range_bounds(n, g) == [rs[0][0]] + [b for _, b in rs]
+    finally:
+        sh.configure()
+    assert sh.frame_range(10, 1, 2) == (5, 10)
