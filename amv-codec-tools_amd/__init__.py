@@ -16,6 +16,7 @@ OK, ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_SPACE = 0, -1, -2, -3, -4
 ST_FORMAT, ST_OVERRUN, ST_TRUNCATED = 1, 2, 4
 FLAG_ZIGZAG_FIXED = 1
 FLAG_FFMPEG = 2
+FLAG_FFMPEG_KEEP = 4
 QBIAS_AMV, QBIAS_MJPEG = 0, 128
 K_HUFFMAN, K_RECON, K_FDCT, K_PACK, K_ADPCM_DEC, K_ADPCM_ENC, K_SYNTH, K_HUFFMAN_SERIAL, K_UNSTUFF, K_PACK_SERIAL, K_COMPACT = range(11)
 ENTROPY_AUTO, ENTROPY_SERIAL = 0, 1

@@ -64,8 +64,11 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
     if (skip) return false;
     int dc_base = 0;
     if (records) {   // records -> dense image of the segment's blocks in LDS
-        const uint32_t cnt_ok = ok > mcu0 ? min(cnt, ok - mcu0) : 0u;   // MCUs of this segment that were decoded
-        if (!cnt_ok) r1 = r0;
+        // blocks of this segment that were decoded: whole MCUs' (ok counts MCUs), or -- AMVHIP_FLAG_FFMPEG_KEEP -- every
+        // whole block before the frame's first error (ok counts blocks then: SyncSinks::ok_in_blocks)
+        const uint32_t ok_blocks = in.ok_in_blocks ? ok : ok * 6u;
+        const uint32_t blocks_ok_here = ok_blocks > mcu0 * 6u ? min(nb, ok_blocks - mcu0 * 6u) : 0u;
+        if (!blocks_ok_here) r1 = r0;
         // The segment's records are asked for all at once, four consecutive ones per lane and instruction (a loop of
         // one 4-byte load per lane and trip waited for memory eight times in a row: 1.6 of the kernel's 4.4 ms); the
         // image is zeroed while they are on their way.
@@ -89,7 +92,7 @@ __device__ __forceinline__ bool load_segment_blocks(const SyncSinks& in, uint32_
         // "blocks decoded << 7" rejects fillers and other segments' blocks alike, and a record past the range's end
         // compares against 0.  A rejected record goes to the lane's spare slot behind the image.
         const uint32_t first7 = (64u - ((mcu0 * 6u - g.blocks) & 63u)) << 7;   // the block field counts from the frame's end
-        const uint32_t ok7 = cnt_ok * 6u << 7;
+        const uint32_t ok7 = blocks_ok_here << 7;
         const uint32_t spare = kSegImageBytes + lane * 2u;
         for (uint32_t base = 0;;) {
 #pragma unroll

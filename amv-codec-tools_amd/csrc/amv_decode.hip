@@ -124,6 +124,8 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
     // p - base of a workspace that holds one round of items (amvhip_api.hip), else to the frame's own place.
     const uint32_t lane = threadIdx.x;
     const uint32_t f0 = base + blockIdx.x * kWave;
+    const bool ok_in_blocks = (by_slot & 2u) != 0u;   // AMVHIP_FLAG_FFMPEG_KEEP: nmcu_ok counts whole blocks (amv_kernels.h)
+    by_slot &= 1u;
     if (list) n = *list_count;
     if (f0 >= n) return;
     const uint32_t frame = f0 + lane < n ? (list ? list[f0 + lane] : f0 + lane) : 0xffffffffu;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
 
     BitReader r;
     bool live = frame != 0xffffffffu;
-    uint32_t st = 0, mcu_done = 0;
+    uint32_t st = 0, mcu_done = 0, blocks_done = 0;
     {
         uint64_t off = live ? offs[frame] : 0;
         uint32_t len = live ? lens[frame] : 0;
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
                     ++k;
                 }
             }
+            if (live) ++blocks_done;
         }
         __syncthreads();
         // 64 slots -> 64 lines of the coefficient array, then clear
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(kWave) void amv_huffman_kernel(
     if (frame != 0xffffffffu) {
         if (r.pad > r.nbits) st |= kStTruncated;  // consumed bits that the chunk does not hold
         status[frame] = (int32_t)st;
-        nmcu_ok[frame] = mcu_done;
+        nmcu_ok[frame] = ok_in_blocks ? blocks_done : mcu_done;
     }
 }
 
@@ -220,11 +223,11 @@ void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
                     const uint32_t* lens, uint32_t n, const FrameGeom& g,
                     const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
                     uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, uint32_t base, uint32_t items,
-                    bool by_slot, hipStream_t s) {
+                    bool by_slot, bool ok_in_blocks, hipStream_t s) {
     if (items == 0) return;
     const uint32_t grid = (items + kWave - 1) / kWave;   // an upper bound: groups past the end of the work exit at once
     hipLaunchKernelGGL(amv_huffman_kernel, dim3(grid), dim3(kWave), 0, s, blob, blob_bytes, offs,
-                       lens, n, g.blocks, d_img, coef, status, nmcu_ok, list, list_count, base, by_slot ? 1u : 0u);
+                       lens, n, g.blocks, d_img, coef, status, nmcu_ok, list, list_count, base, (by_slot ? 1u : 0u) | (ok_in_blocks ? 2u : 0u));
 }
 
 }  // namespace amv

@@ -560,6 +560,7 @@ struct SyncOut {
     uint32_t* rec_count;
     uint32_t* retry_list;    // frames for amv_huffman_kernel
     uint32_t* retry_count;
+    uint32_t ok_in_blocks;   // nmcu_ok counts whole blocks instead of whole MCUs (SyncSinks)
 };
 
 // The dense form (coefficient lines: amvhip_huffman_decode_dev's output).
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(kWave* 16) void amv_huffman_sync_kernel(
             atomicMax(&stats[2], (unsigned long long)rounds);
         }
         status[frame] = (int32_t)st;
-        nmcu_ok[frame] = good_blocks / 6u;
+        nmcu_ok[frame] = out.ok_in_blocks ? good_blocks : good_blocks / 6u;
     }
     }   // next task
 }
@@ -1089,7 +1090,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_fast_kernel(
                 out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
             } else {
                 status[frame] = (int32_t)st;
-                nmcu_ok[frame] = end_blocks / 6u;
+                nmcu_ok[frame] = out.ok_in_blocks ? end_blocks : end_blocks / 6u;
                 out.rec_count[frame] = recpos;
             }
         }
@@ -1500,7 +1501,7 @@ __global__ __launch_bounds__(kWave * 16) void amv_huffman_sync2_kernel(
                 out.retry_list[atomicAdd(out.retry_count, 1u)] = frame;
             } else {
                 status[frame] = (int32_t)st;
-                nmcu_ok[frame] = good_blocks / 6u;
+                nmcu_ok[frame] = out.ok_in_blocks ? good_blocks : good_blocks / 6u;
                 out.rec_count[frame] = rec_total | ((uint32_t)(L - 1) << 24);   // (a frame holds < 2^21 records: amvhip_api.hip)
             }
         }
@@ -1670,7 +1671,7 @@ void launch_huffman_sync(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t 
     if (n == 0) return;
     const uint32_t per_row = (g.mcu_cols + kSegMcus - 1u) / kSegMcus;
     SyncOut out{sinks.coef, sinks.rec, sinks.rec_line, sinks.seg_start, sinks.lane_tab, SegGeom{g.mcu_cols, per_row, per_row * g.mcu_rows},
-                sinks.lanes, sinks.rec_count, sinks.retry_list, sinks.retry_count};
+                sinks.lanes, sinks.rec_count, sinks.retry_list, sinks.retry_count, sinks.ok_in_blocks};
 #define AMV_SYNC_ARGS ws, ws_bytes, n, list, list_count, g, ws_line, d_img, out, status, nmcu_ok, queue, stats, cus, s
     if (sinks.rec) {
         switch (lanes_per_frame) {

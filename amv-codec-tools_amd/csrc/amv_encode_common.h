@@ -126,7 +126,8 @@ static_assert(kPlaneSamples * 2 == 64 * 128, "a segment's planes and its 64 coef
 struct Weights { int y0, y2, u0, u2, v0, v2; };
 
 __device__ __forceinline__ int luma(const Weights& k, int c0, int c1, int c2) {
-    return ((k.y0 * c0 + 601 * c1 + k.y2 * c2 + 512) >> 10) - 128;
+    // ((sum + 512) >> 10) - 128 with the level shift inside the (arithmetic) shift: 128 * 1024 is a multiple of 1024
+    return (k.y0 * c0 + 601 * c1 + k.y2 * c2 + (512 - 128 * 1024)) >> 10;
 }
 __device__ __forceinline__ int chroma_u(const Weights& k, int s0, int s1, int s2) {   // 2x2 sums, shift 2
     return (k.u0 * s0 - 339 * s1 + k.u2 * s2 + 2047) >> 12;                           // +128 -128

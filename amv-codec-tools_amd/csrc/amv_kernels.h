@@ -8,7 +8,7 @@ namespace amv {
 
 // status bits, same values as AMVHIP_ST_* in include/amvhip.h
 enum : uint32_t { kStFormat = 1u, kStOverrun = 2u, kStTruncated = 4u };
-enum : uint32_t { kFlagZigzagFixed = 1u, kFlagFfmpeg = 2u };
+enum : uint32_t { kFlagZigzagFixed = 1u, kFlagFfmpeg = 2u, kFlagFfmpegKeep = 4u };
 
 // ---- decode -------------------------------------------------------------------------------
 // entropy stage: one lane per frame, coefficients staged per block in LDS and written out as
@@ -19,7 +19,7 @@ void launch_huffman(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
                     const uint32_t* lens, uint32_t n, const FrameGeom& g,
                     const HuffDecodeImage* d_img, int16_t* coef, int32_t* status,
                     uint32_t* nmcu_ok, const uint32_t* list, const uint32_t* list_count, uint32_t base, uint32_t items,
-                    bool by_slot, hipStream_t s);
+                    bool by_slot, bool ok_in_blocks, hipStream_t s);
 // entropy stage with parallelism inside a frame (amv_decode_sync.hip): unstuff into a workspace
 // (frame i in the 16-byte pieces ws_line[i] .. ws_line[i + 1] of ws, ws_bytes[i] = unstuffed length or ~0 when the frame is handed to
 // launch_huffman through retry_list / *retry_count), then L lanes per frame synchronise and decode.
@@ -53,6 +53,9 @@ struct SyncSinks {
     uint32_t* rec_count;
     uint32_t* retry_list;
     uint32_t* retry_count;
+    // AMVHIP_FLAG_FFMPEG_KEEP: nmcu_ok[] counts whole BLOCKS decoded before a frame's first error, not whole MCUs (the
+    // entropy kernels write it so, the reconstruction reads it so) -- an internal array then, never a caller's
+    uint32_t ok_in_blocks;
 };
 // Space per frame from the frame's own chunk length, for the unstuffed scans (a) and, when b.line != nullptr, for the record
 // hand-over (b) alike: min(hi, per_byte_x2 / 2 * lens[i] + add) units, rounded up to whole lines of 1 << unit_shift units;

@@ -87,7 +87,10 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
     if (load_segment_blocks(in, f, slot, kRound, g, my * pm.nseg + seg, g.mcu_rows * pm.nseg, mcu0, cnt, ok, lane, s_img, c, skip)) {
     const uint32_t m = lane / 6u, k6 = lane % 6u;
     const bool chroma = k6 >= 4u;
-    const bool decoded = mcu0 + m < ok;
+    // decoded: MCUs before the frame's first error -- or, AMVHIP_FLAG_FFMPEG_KEEP (ok counts blocks then), every whole block
+    // before it: what mjpeg_decode_scan has put into the picture when decode_block fails (mjpegdec.c:699-716)
+    const bool keep = in.ok_in_blocks != 0u;
+    const bool decoded = keep ? (mcu0 + m) * 6u + k6 < ok : mcu0 + m < ok;
 
     // decode_block's dequantisation (mjpegdec.c:388-390,417,424): out[natural] = (DCTELEM)(level * q); the DC
     // arrives as the running sum of differences, FFmpeg keeps 1024 + q0 * that sum (:805) -- equal modulo 2^16,
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(kWave) void amv_reconstruct_yuv_kernel(
     for (int i = 0; i < 8; ++i) {
         const int p = start - (sy + i);
         if (p < 0 || p >= (int)ph) continue;
+        if (keep && !decoded) continue;      // the caller's buffer is left as it was (FFmpeg: whatever the picture held)
         uint32_t lo = 0, hi = 0;
         if (decoded) {   // MCUs at or after a frame's first error stay zero
             lo = (uint32_t)v[8 * i] | ((uint32_t)v[8 * i + 1] << 8) | ((uint32_t)v[8 * i + 2] << 16) | ((uint32_t)v[8 * i + 3] << 24);

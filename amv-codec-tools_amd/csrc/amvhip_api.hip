@@ -455,7 +455,7 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     {   // the caller's array has a place for every frame: one launch, lines at the frames' own places
         Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
         launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, d_coef, d_status, d_nmcu_ok, fb.list, fb.count, 0u,
-                       fb.items, false, st);
+                       fb.items, false, false, st);
     }
     return check_launch(c, "huffman");
 }
@@ -473,6 +473,7 @@ static int reconstruct_launch(amvhip_ctx* c, const SyncSinks& sinks, const uint3
 // bytes of the output no kernel writes are cleared first: row padding (AMVDec.c:283), and in FFmpeg mode the plane
 // rows mjpegdec.c:672-677 leaves untouched for some heights
 static int clear_unwritten(amvhip_ctx* c, uint32_t n, const FrameGeom& g, uint32_t flags, uint8_t* d_out, hipStream_t st) {
+    if (flags & AMVHIP_FLAG_FFMPEG_KEEP) return AMVHIP_OK;   // what no block covers stays as the caller had it
     if (flags & AMVHIP_FLAG_FFMPEG) {
         if (!yuv_store_covers_planes(g)) HIP_TRY(c, hipMemsetAsync(d_out, 0, amvhip_yuv420_frame_bytes(g.width, g.height) * n, st));
     } else if (g.stride != g.width * 3) {
@@ -506,8 +507,10 @@ struct DecodeBufs {
 };
 
 static int decode_args_ok(amvhip_ctx* c, const uint8_t* d_blob, const uint64_t* d_offs, const uint32_t* d_lens, uint32_t n, uint32_t w,
-                          uint32_t h, const uint8_t* d_out, const int32_t* d_status) {
+                          uint32_t h, uint32_t flags, const uint8_t* d_out, const int32_t* d_status) {
     if (!size_ok(w, h)) return fail(c, AMVHIP_ERR_ARG, "decode: bad size %ux%u", w, h);
+    if ((flags & AMVHIP_FLAG_FFMPEG_KEEP) && !(flags & AMVHIP_FLAG_FFMPEG))
+        return fail(c, AMVHIP_ERR_ARG, "decode: AMVHIP_FLAG_FFMPEG_KEEP is a mode of AMVHIP_FLAG_FFMPEG");
     if (n == 0) return AMVHIP_OK;
     if (!d_blob || !d_offs || !d_lens || !d_out || !d_status) return fail(c, AMVHIP_ERR_ARG, "decode: null argument");
     if (((uintptr_t)d_blob & 3u) || ((uintptr_t)d_out & 3u)) return fail(c, AMVHIP_ERR_ARG, "decode: blob and out must be 4-byte aligned");
@@ -560,6 +563,7 @@ static int decode_core(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes
     if (int r = ensure(c, b.rec_count, (size_t)n * 4)) return r;
     SyncSinks sinks{(int16_t*)c->coef.p, (uint32_t*)b.rec.p, (const uint32_t*)b.rec_line.p, (uint32_t*)b.seg_start.p, (uint32_t*)b.lane_tab.p, tab_lanes,
                     (uint32_t*)b.rec_count.p, nullptr, nullptr};
+    sinks.ok_in_blocks = (flags & AMVHIP_FLAG_FFMPEG_KEEP) ? 1u : 0u;   // b.nmcu is the context's own array: whole blocks, not whole MCUs
     uint32_t* d_nmcu = (uint32_t*)b.nmcu.p;
     c->last_decode_retry = &b.retry;
     Fallback fb;
@@ -581,7 +585,7 @@ static int decode_core(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes
         {
             Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
             launch_huffman(d_blob, blob_bytes, d_offs, d_lens, n, g, c->d_dec, sinks.coef, d_status, d_nmcu, fb.list, fb.count, base,
-                           items, true, st);
+                           items, true, sinks.ok_in_blocks != 0u, st);
         }
         if (int r = check_launch(c, "huffman")) return r;
         if (int r = reconstruct_launch(c, sinks, d_nmcu, n, FrameSel{fb.list, fb.count, base, items}, items, g, flags, d_out, st)) return r;
@@ -597,7 +601,7 @@ extern "C" int amvhip_decode_batch_dev(amvhip_ctx* c, const uint8_t* d_blob, uin
                                        uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out,
                                        int32_t* d_status, void* stream) {
     if (!c) return AMVHIP_ERR_ARG;
-    if (int r = decode_args_ok(c, d_blob, d_offs, d_lens, n, w, h, d_out, d_status)) return r;
+    if (int r = decode_args_ok(c, d_blob, d_offs, d_lens, n, w, h, flags, d_out, d_status)) return r;
     if (n == 0) return AMVHIP_OK;
     if (int r = use_device(c)) return r;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -618,7 +622,7 @@ extern "C" int amvhip_decode_submit_dev(amvhip_ctx* c, const uint8_t* d_blob, ui
                                         uint32_t w, uint32_t h, uint32_t flags, uint8_t* d_out,
                                         int32_t* d_status, void* stream) {
     if (!c) return AMVHIP_ERR_ARG;
-    if (int r = decode_args_ok(c, d_blob, d_offs, d_lens, n, w, h, d_out, d_status)) return r;
+    if (int r = decode_args_ok(c, d_blob, d_offs, d_lens, n, w, h, flags, d_out, d_status)) return r;
     if (int r = select_device(c)) return r;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->submitted - c->collected >= 2) return fail(c, AMVHIP_ERR_ARG, "decode_submit: two batches are in flight, collect one first");
@@ -694,6 +698,8 @@ extern "C" int amvhip_decode_batch_async(amvhip_ctx* c, const uint8_t* blob, uin
     HIP_TRY(c, hipMemcpyAsync(c->h_in.p, blob, blob_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->h_offs.p, offs, (size_t)n * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->h_lens.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    // AMVHIP_FLAG_FFMPEG_KEEP: what no block covers stays as the CALLER had it -- the caller's frames go up first
+    if (flags & AMVHIP_FLAG_FFMPEG_KEEP) HIP_TRY(c, hipMemcpyAsync(d_frames.p, out, fb * n, hipMemcpyHostToDevice, st));
     if (int r = amvhip_decode_batch_dev(c, (const uint8_t*)c->h_in.p, blob_bytes, (const uint64_t*)c->h_offs.p,
                                         (const uint32_t*)c->h_lens.p, n, w, h, flags, (uint8_t*)d_frames.p, (int32_t*)d_st.p, st))
         return r;

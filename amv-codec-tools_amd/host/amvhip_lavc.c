@@ -16,7 +16,9 @@
  * include/amvhip.h are where throughput lives.
  *
  *   decode (video)  AMVHIP_FLAG_FFMPEG: FFmpeg's own AMV arithmetic (Q60 tables, simple_idct, flipped planes),
- *                   so a transcode through this plugin shows the pictures the reference's decoder shows.
+ *                   so a transcode through this plugin shows the pictures the reference's decoder shows; with
+ *                   AMVHIP_FLAG_FFMPEG_KEEP, so that a damaged chunk leaves in the picture what mjpegdec.c leaves: the
+ *                   blocks in front of the failing one, the buffer's own bytes everywhere else.
  *   encode (video)  planar YUVJ420P or YUVJ422P in, as pix_fmts declares (mjpegenc.c:493).  Differences from the
  *                   reference's encoder are the documented ones of DESIGN.md section 2 (amvlib's quantiser tables,
  *                   true level shift): the reference's own output does not survive any AMV decoder (SURVEY.md fact
@@ -119,10 +121,6 @@ static int amvhip_video_decode_frame(AVCodecContext *avctx, void *data, int *dat
         s->staging_size = s->staging ? need : 0;
         if (!s->staging) return -1;
     }
-    if (amvhip_decode_batch(s->ctx, buf, len, &off, &len, 1, w, h, AMVHIP_FLAG_FFMPEG, s->staging, &status) != AMVHIP_OK)
-        return -1;
-    /* a damaged chunk: FFmpeg logs ("error dc" / "error count", mjpegdec.c:384,420) and shows what it has */
-
     release_picture(avctx, s);
     if (avctx->get_buffer) {                                 /* mjpegdec.c:330-334 */
         s->picture.reference = 0;
@@ -134,7 +132,7 @@ static int amvhip_video_decode_frame(AVCodecContext *avctx, void *data, int *dat
             const size_t bytes = (size_t)pw[i] * ph[i];
             if (bytes > s->own_size[i]) {
                 free(s->own[i]);
-                s->own[i] = malloc(bytes);
+                s->own[i] = calloc(1, bytes);                /* (what a damaged chunk leaves untouched is read back: AMVHIP_FLAG_FFMPEG_KEEP) */
                 s->own_size[i] = s->own[i] ? bytes : 0;
                 if (!s->own[i]) return -1;
             }
@@ -145,12 +143,28 @@ static int amvhip_video_decode_frame(AVCodecContext *avctx, void *data, int *dat
     s->picture.pict_type = FF_I_TYPE;
     s->picture.key_frame = 1;
     {
-        const uint8_t *src = s->staging;
+        /* A damaged chunk: FFmpeg logs ("error dc" / "error count", mjpegdec.c:384,420) and shows what it has -- the blocks in
+         * front of the failing one in a picture that otherwise holds whatever the buffer held (mjpeg_decode_scan returns at
+         * the failing block, :699-716).  AMVHIP_FLAG_FFMPEG_KEEP is that: the buffer's planes go in, come back with the
+         * decoded blocks put into them. */
+        uint8_t *stage = s->staging;
         const int pw[3] = {w, cw, cw}, ph[3] = {h, ch, ch};
+        int rc;
         for (i = 0; i < 3; i++) {
             for (y = 0; y < ph[i]; y++)
-                memcpy(s->picture.data[i] + (ptrdiff_t)y * s->picture.linesize[i], src + (size_t)y * pw[i], pw[i]);
-            src += (size_t)pw[i] * ph[i];
+                memcpy(stage + (size_t)y * pw[i], s->picture.data[i] + (ptrdiff_t)y * s->picture.linesize[i], pw[i]);
+            stage += (size_t)pw[i] * ph[i];
+        }
+        rc = amvhip_decode_batch(s->ctx, buf, len, &off, &len, 1, w, h, AMVHIP_FLAG_FFMPEG | AMVHIP_FLAG_FFMPEG_KEEP, s->staging, &status);
+        if (rc != AMVHIP_OK) {
+            release_picture(avctx, s);
+            return -1;
+        }
+        stage = s->staging;
+        for (i = 0; i < 3; i++) {
+            for (y = 0; y < ph[i]; y++)
+                memcpy(s->picture.data[i] + (ptrdiff_t)y * s->picture.linesize[i], stage + (size_t)y * pw[i], pw[i]);
+            stage += (size_t)pw[i] * ph[i];
         }
     }
     *(AVFrame *)data = s->picture;                           /* mjpegdec.c:1266-1268 */

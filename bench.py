@@ -235,7 +235,7 @@ def kernel_times(E, ids, ctx=None, steps=1):
     return kern
 
 
-TRAFFIC_ROUND = "r05"   # profiles/<round>_traffic*.json: this round's PMC passes (tools/profile_round.sh)
+TRAFFIC_ROUND = "r06"   # profiles/<round>_traffic*.json: this round's PMC passes (tools/profile_round.sh)
 
 
 def profiled_traffic(tag, dom):

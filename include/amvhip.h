@@ -174,6 +174,16 @@ typedef struct amvhip_ctx amvhip_ctx;
  * per frame the Y plane (w*h), then Cb and Cr ((w+1)/2 x (h+1)/2 each), rows tight.  The two reference decoders
  * do NOT agree with each other; amvlib's output is the default and the headline target. */
 #define AMVHIP_FLAG_FFMPEG 2u
+/* ... and, with it, what the patched FFmpeg leaves in the picture when a chunk is damaged: mjpeg_decode_scan returns at
+ * the block whose decode_block fails (mjpegdec.c:699-706) with every block before it already put into the picture
+ * (:708-716) and everything else as the picture buffer was.  So: every whole block before the frame's first error is
+ * written -- the blocks of the failing MCU in front of the failing one included -- and every other byte of the frame in
+ * d_out stays as the caller had it (no plane row is cleared either, not even for an undamaged frame: a host that wants
+ * FFmpeg's "shows what it has" hands in the picture before).  Without this flag AMVHIP_FLAG_FFMPEG zero-fills from the
+ * failing MCU on, as amvlib does (AMVDec.c:283).  WHERE a chunk fails is this library's strict decoder's verdict
+ * (status bits above) in both modes -- mjpegdec.c's own (:384 "error dc", :420 "error count", no truncation check: it
+ * reads what lies behind the chunk) is not a function of the chunk alone.  AMVHIP_ERR_ARG without AMVHIP_FLAG_FFMPEG. */
+#define AMVHIP_FLAG_FFMPEG_KEEP 4u
 
 /* encode quantiser bias in 1/256 of a step: 0 = the reference's AMV setting
  * (mpegvideo_enc.c:492-496), 128 = its MJPEG setting (round to nearest, :488-490). */

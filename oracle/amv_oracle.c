@@ -503,8 +503,50 @@ uint32_t amvo_yuv420_frame_bytes(uint32_t w, uint32_t h) { return w * h + 2 * ((
  * rows the formula sends outside the plane fall into FFmpeg's edge area and are dropped here; columns beyond
  * the plane width likewise).  Errors, statuses and nmcu_ok are defined as in amvo_decode_frame: MCUs before the
  * first error are stored, the rest stays zero (FFmpeg logs the error and keeps whatever the buffer held). */
+/* the entropy stage alone, block by block (HufBlock + the DC prediction of DecodeMCUBlock, AmvJpeg.c:939-974,1200-1221):
+ * coef[b] = block b's 64 quantised coefficients in scan order, for every WHOLE block before the first error -- the blocks
+ * of a failing MCU in front of the failing one too, which amvo_decode_frame does not hand out.  Returns the count. */
+uint32_t amvo_entropy_blocks(const uint8_t *chunk, uint32_t len, uint32_t nblocks, int16_t *coef, uint32_t *status)
+{
+    hufbounds hb[4];
+    bitrd b;
+    int16_t pred[3] = { 0, 0, 0 };
+    static const int comp_of[6] = { 0, 0, 0, 0, 1, 2 };
+    uint32_t st = 0, done = 0;
+    for (int t = 0; t < 4; t++) build_bounds(&hb[t], k_bits[t]);
+    memset(&b, 0, sizeof b);
+    b.buf = chunk; b.len = len; b.pos = 2;
+    for (; done < nblocks; done++) {
+        int c = comp_of[done % 6];
+        int16_t *blk = coef + (size_t)done * 64;
+        int r = huf_block(&b, hb, c ? 1 : 0, c ? 3 : 2, blk);
+        if (r) { st |= (uint32_t)r; break; }
+        blk[0] = (int16_t)(blk[0] + pred[c]);
+        pred[c] = blk[0];
+    }
+    if (b.consumed > b.valid) st |= AMVO_ST_TRUNCATED;
+    if (status) *status = st;
+    return done;
+}
+
+static int decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
+                               uint8_t *out, uint32_t *nmcu_ok, uint32_t *status, int keep);
 int amvo_decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
                              uint8_t *out, uint32_t *nmcu_ok, uint32_t *status)
+{
+    return decode_frame_ffmpeg(chunk, len, w, h, out, nmcu_ok, status, 0);
+}
+/* The same with what mjpegdec.c leaves behind on a damaged chunk (AMVHIP_FLAG_FFMPEG_KEEP): mjpeg_decode_scan returns
+ * at the block whose decode_block fails (:699-706); the blocks before it -- of the same MCU too -- have been put into the
+ * picture (:708-716), nothing else of `out` is touched (not cleared first either).  blocks_ok: whole blocks decoded.
+ * Where the chunk fails is amvo_decode_frame's rule, as in the plain mode.  RESTATEMENT ONLY: no reference build pins it. */
+int amvo_decode_frame_ffmpeg_keep(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
+                                  uint8_t *out, uint32_t *blocks_ok, uint32_t *status)
+{
+    return decode_frame_ffmpeg(chunk, len, w, h, out, blocks_ok, status, 1);
+}
+static int decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
+                               uint8_t *out, uint32_t *nmcu_ok, uint32_t *status, int keep)
 {
     hufbounds hb[4];
     bitrd b;
@@ -513,26 +555,29 @@ int amvo_decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uin
     uint8_t *plane[3] = { out, out + (size_t)w * h, out + (size_t)w * h + (size_t)cw * chh };
     const uint32_t pw[3] = { w, cw, cw }, ph[3] = { h, chh, chh };
     int16_t pred[3] = { 0, 0, 0 };
-    uint32_t st = 0, mcu = 0;
+    uint32_t st = 0, mcu = 0, blocks = 0;
     static const int comp_of[6] = { 0, 0, 0, 0, 1, 2 };
 
     for (int t = 0; t < 4; t++) build_bounds(&hb[t], k_bits[t]);
-    memset(out, 0, amvo_yuv420_frame_bytes(w, h));
+    if (!keep) memset(out, 0, amvo_yuv420_frame_bytes(w, h));
     memset(&b, 0, sizeof b);
     b.buf = chunk; b.len = len; b.pos = 2;                                    /* sp5xdec.c:75-77 copies [2, n-2) */
 
     for (uint32_t my = 0; my < mch && !st; my++) {
         for (uint32_t mx = 0; mx < mcw; mx++) {
             int16_t mcub[6][64];
+            int good = 0;                                                      /* whole blocks of this MCU */
             for (int k = 0; k < 6 && !st; k++) {
                 int c = comp_of[k];
                 int r = huf_block(&b, hb, c ? 1 : 0, c ? 3 : 2, mcub[k]);
                 if (r) { st |= (uint32_t)r; break; }
                 mcub[k][0] = (int16_t)(mcub[k][0] + pred[c]);
                 pred[c] = mcub[k][0];
+                good++;
             }
-            if (st) break;
-            for (int k = 0; k < 6; k++) {
+            blocks += (uint32_t)good;
+            if (st && !keep) break;
+            for (int k = 0; k < good; k++) {
                 int c = comp_of[k];
                 int v = c == 0 ? 2 : 1;
                 int16_t blk[64];
@@ -550,11 +595,12 @@ int amvo_decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uin
                         if (sx + j < pw[c]) plane[c][(size_t)p * pw[c] + sx + j] = px[8 * i + j];
                 }
             }
+            if (st) break;
             mcu++;
         }
     }
     if (b.consumed > b.valid) st |= AMVO_ST_TRUNCATED;
-    if (nmcu_ok) *nmcu_ok = mcu;
+    if (nmcu_ok) *nmcu_ok = keep ? blocks : mcu;
     if (status) *status = st;
     return st ? -1 : 0;
 }

@@ -84,6 +84,11 @@ uint32_t amvo_yuv420_frame_bytes(uint32_t w, uint32_t h);
 /* whole frame: YUVJ420P planes (Y, Cb, Cr; tight rows), flipped per mjpegdec.c:672-677 */
 int amvo_decode_frame_ffmpeg(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
                              uint8_t *out, uint32_t *nmcu_ok, uint32_t *status);
+/* the entropy stage alone: coef[b][64] (scan order, DC predicted) of every whole block before the first error; returns their number */
+uint32_t amvo_entropy_blocks(const uint8_t *chunk, uint32_t len, uint32_t nblocks, int16_t *coef, uint32_t *status);
+/* AMVHIP_FLAG_FFMPEG_KEEP: blocks before the first error written, `out` otherwise untouched; blocks_ok = whole blocks decoded */
+int amvo_decode_frame_ffmpeg_keep(const uint8_t *chunk, uint32_t len, uint32_t w, uint32_t h,
+                                  uint8_t *out, uint32_t *blocks_ok, uint32_t *status);
 
 /* ---- picture rescale (the sws_scale shim of libavcodec/imgresample.c) ---------------- */
 /* av_build_filter (resample2.c:93-140) as img_resample_full_init calls it (imgresample.c:468-471): 16 phases x 4 taps */

@@ -69,6 +69,8 @@ def lib():
             "amvo_ffmpeg_dequant_block": (None, [_vp, _int, _vp]),
             "amvo_yuv420_frame_bytes": (_u32, [_u32, _u32]),
             "amvo_decode_frame_ffmpeg": (_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+            "amvo_decode_frame_ffmpeg_keep": (_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+            "amvo_entropy_blocks": (_u32, [_vp, _u32, _u32, _vp, _vp]),
             "amvo_build_resample_filter": (None, [_vp, _int, _int]),
             "amvo_img_resample_yuv420": (None, [_vp, _int, _int, _vp, _int, _int]),
             "amvo_adpcm_decode_chunk": (_int, [_vp, _u32, _vp, _vp]),
@@ -195,6 +197,28 @@ def decode_frame_ffmpeg(chunk, w, h):
     out = np.zeros(L.amvo_yuv420_frame_bytes(w, h), np.uint8)
     ok, st = _u32(), _u32()
     L.amvo_decode_frame_ffmpeg(chunk, len(chunk), w, h, out.ctypes.data, ctypes.byref(ok), ctypes.byref(st))
+    return out, st.value, ok.value
+
+
+def entropy_blocks(chunk, nblocks):
+    """the entropy stage alone -> (coef [done, 64] int16 of the whole blocks before the first error, status)"""
+    L = lib()
+    chunk = bytes(chunk)
+    coef = np.zeros((nblocks, 64), np.int16)
+    st = _u32()
+    done = L.amvo_entropy_blocks(chunk, len(chunk), nblocks, coef.ctypes.data, ctypes.byref(st))
+    return coef[:done], st.value
+
+
+def decode_frame_ffmpeg_keep(chunk, w, h, before):
+    """AMVHIP_FLAG_FFMPEG_KEEP: `before` (a YUVJ420P frame buffer) with every whole block ahead of the chunk's first error
+    put into it, nothing else touched -> (buffer, status, whole blocks decoded)"""
+    L = lib()
+    chunk = bytes(chunk)
+    out = np.array(before, dtype=np.uint8, copy=True).reshape(-1)
+    assert out.size == L.amvo_yuv420_frame_bytes(w, h)
+    ok, st = _u32(), _u32()
+    L.amvo_decode_frame_ffmpeg_keep(chunk, len(chunk), w, h, out.ctypes.data, ctypes.byref(ok), ctypes.byref(st))
     return out, st.value, ok.value
 
 

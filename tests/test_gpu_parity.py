@@ -810,6 +810,89 @@ def test_ffmpeg_compat_decode_amv1(ctx, pkg, orc, amv1):
     assert (got == want).all()
 
 
+def test_ffmpeg_keep_leaves_what_mjpegdec_leaves(pkg, orc, amv1):
+    """AMVHIP_FLAG_FFMPEG_KEEP (mjpegdec.c:699-716: mjpeg_decode_scan returns at the failing block, the blocks before it are
+    in the picture, the rest of the picture is as it was): damaged and truncated chunks of the reference's clip and of two
+    synthetic geometries (a height whose bottom rows the flip formula never reaches among them) decoded over a buffer the
+    caller filled -- every byte as the oracle's restatement leaves it: blocks in front of the failing one written, those
+    of the failing MCU included, every other byte the caller's; undamaged frames beside them in the same batch.  Through
+    the parallel entropy kernels (several lane counts), the serial one, and the host-buffer entry point; the flag without
+    AMVHIP_FLAG_FFMPEG is refused."""
+    import os
+    import torch
+    rng = np.random.default_rng(4242)
+    cases = [(128, 96, list(amv1["video"][:60]))]
+    for w, h in ((160, 120), (46, 30)):
+        cases.append((w, h, [orc.encode_frame(orc.synth_frame(SEED, 7 * t, w + (w & 1), h + (h & 1)), w + (w & 1), h + (h & 1)) for t in range(30)]))
+    keep = {k: os.environ.get(k) for k in ("AMVHIP_SYNC_LANES",)}
+    ctxs = {}
+    try:
+        for lanes in (None, "1", "4", "64"):
+            if lanes is None:
+                os.environ.pop("AMVHIP_SYNC_LANES", None)
+            else:
+                os.environ["AMVHIP_SYNC_LANES"] = lanes
+            ctxs[lanes] = pkg.Context(0)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        for w, h, chunks in cases:
+            damaged = []
+            for i, c in enumerate(chunks):
+                c = bytearray(c)
+                if i % 3 != 0 and len(c) > 40:                      # flipped bits somewhere in the scan (one alone usually resynchronises)
+                    for _ in range(3):
+                        c[int(rng.integers(8, len(c) - 4))] ^= 1 << int(rng.integers(0, 8))
+                if i % 3 == 2:                                       # ... and the chunk cut short
+                    c = c[: int(rng.integers(6, len(c) - 2))]
+                damaged.append(bytes(c))
+            fb = ctxs[None].yuv420_frame_bytes(w, h)
+            before = rng.integers(0, 256, (len(damaged), fb), dtype=np.uint8)
+            want, want_st, part = [], [], 0
+            for i, c in enumerate(damaged):
+                o, st, blocks = orc.decode_frame_ffmpeg_keep(c, w, h, before[i])
+                want.append(o)
+                want_st.append(st)
+                part += 1 if (st and blocks % 6) else 0
+                if not st:                                           # an undamaged frame: the plain mode's bytes wherever it writes
+                    plain = orc.decode_frame_ffmpeg(c, w, h)[0]
+                    changed = o != before[i]
+                    assert (o[changed] == plain[changed]).all()
+            want, want_st = np.stack(want), np.array(want_st, np.int32)
+            assert (want_st != 0).sum() >= 3 and part >= 1, (w, h, want_st, part)   # some fail inside an MCU
+            blob, offs, lens, nbytes = _blob_of(damaged, 1)
+            for key, c in ctxs.items():
+                for mode in ((pkg.ENTROPY_AUTO, pkg.ENTROPY_SERIAL) if key is None else (pkg.ENTROPY_AUTO,)):
+                    c.set_entropy_mode(mode)
+                    d_out = torch.from_numpy(before.copy()).to("cuda:0")
+                    d_st = torch.full((len(damaged),), -1, dtype=torch.int32, device="cuda:0")
+                    c.decode_batch_dev(_t(blob), nbytes, _t(offs), _t(lens), len(damaged), w, h, pkg.FLAG_FFMPEG | pkg.FLAG_FFMPEG_KEEP,
+                                       d_out, d_st, torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    assert (d_st.cpu().numpy() == want_st).all(), (w, h, key, mode)
+                    got = d_out.cpu().numpy()
+                    bad = np.nonzero((got != want).any(axis=1))[0]
+                    assert bad.size == 0, (w, h, key, mode, bad[:5])
+                    c.set_entropy_mode(pkg.ENTROPY_AUTO)
+            # the host-buffer form
+            out = before.copy()
+            st = np.full(len(damaged), -1, np.int32)
+            ctxs[None].decode_batch(blob, nbytes, offs, lens, len(damaged), w, h, pkg.FLAG_FFMPEG | pkg.FLAG_FFMPEG_KEEP, out, st)
+            assert (st == want_st).all() and (out == want).all()     # (the caller's frames go up to the staging buffer first)
+        with pytest.raises(Exception):
+            d_out = torch.zeros((1, ctxs[None].frame_bytes(128, 96)), dtype=torch.uint8, device="cuda:0")
+            d_st = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+            ctxs[None].decode_batch_dev(_t(blob), nbytes, _t(offs), _t(lens), 1, 128, 96, pkg.FLAG_FFMPEG_KEEP, d_out, d_st,
+                                        torch.cuda.current_stream().cuda_stream)
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
 @pytest.mark.parametrize("w,h,n", [(160, 120, 40), (320, 240, 6), (176, 144, 3), (130, 98, 3), (16, 16, 2), (336, 32, 2),
                                    (46, 30, 3), (33, 31, 3), (640, 480, 2)])
 def test_ffmpeg_compat_decode_matches_oracle(ctx, pkg, orc, w, h, n):

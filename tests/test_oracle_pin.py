@@ -402,6 +402,70 @@ def test_ffmpeg_compat_decode_properties(orc, amv1):
                 assert (plane[p] == want).all(), (w, h, comp, p)
 
 
+def test_ffmpeg_keep_restatement_properties(orc, amv1):
+    """amvo_decode_frame_ffmpeg_keep (AMVHIP_FLAG_FFMPEG_KEEP; mjpegdec.c:699-716) -- RESTATEMENT ONLY, no reference build
+    pins this slice -- against the plain FFmpeg-compat decode and the geometry of mjpegdec.c:672-677: (1) an undamaged chunk
+    writes exactly the plain mode's bytes wherever a block lands and nothing else; (2) a damaged chunk fails where the plain
+    mode fails (same status, blocks_ok // 6 == nmcu_ok), every whole MCU in front holds the plain mode's bytes, the failing
+    MCU's blocks in front of the failing one hold dequantised + simple_idct'ed coefficients at their place, and every other
+    byte is the buffer's own."""
+    L = orc.lib()
+    rng = np.random.default_rng(99)
+    seen_partial = 0
+    for w, h, chunks in ((128, 96, amv1["video"][:60]), (46, 30, [orc.encode_frame(orc.synth_frame(SEED, t, 46, 30), 46, 30) for t in range(24)])):
+        mcw, mch = (w + 15) // 16, (h + 15) // 16
+        cw, chh = (w + 1) // 2, (h + 1) // 2
+        fb = w * h + 2 * cw * chh
+
+        def block_bytes(block):                 # frame-buffer positions of block number `block` (MCU-major, Y0..Y3 Cb Cr)
+            m, k = divmod(block, 6)
+            my, mx = divmod(m, mcw)
+            comp = 0 if k < 4 else k - 3
+            v = 2 if comp == 0 else 1
+            pw, ph = (w, h) if comp == 0 else (cw, chh)
+            base = 0 if comp == 0 else w * h + (comp - 1) * cw * chh
+            sy = (2 * my + (k >> 1) if comp == 0 else my) * 8
+            sx = (2 * mx + (k & 1) if comp == 0 else mx) * 8
+            start = v * (8 * mch - ((h // 2) & 7)) - 1
+            pos = {}
+            for i in range(8):
+                p = start - (sy + i)
+                if 0 <= p < ph:
+                    for j in range(8):
+                        if sx + j < pw:
+                            pos[base + p * pw + sx + j] = (i, j)
+            return pos, comp
+
+        for t, chunk in enumerate(chunks):
+            c = bytearray(chunk)
+            if t % 3 != 0:                          # (one flipped bit usually decodes to the end: the codes resynchronise)
+                for _ in range(3):
+                    c[int(rng.integers(8, len(c) - 4))] ^= 1 << int(rng.integers(0, 8))
+            if t % 3 == 2:
+                c = c[: int(rng.integers(6, len(c) - 2))]
+            c = bytes(c)
+            before = rng.integers(0, 256, fb, dtype=np.uint8)
+            got, st, blocks = orc.decode_frame_ffmpeg_keep(c, w, h, before)
+            plain, pst, nmcu = orc.decode_frame_ffmpeg(c, w, h)
+            assert st == pst and blocks // 6 == nmcu and (st != 0 or blocks == 6 * mcw * mch)
+            expect = before.copy()
+            coef, est = orc.entropy_blocks(c, 6 * mcw * mch)          # the entropy stage alone, block by block
+            assert est == st and len(coef) == blocks
+            for blk in range(blocks):
+                pos, comp = block_bytes(blk)
+                seen_partial += blk >= 6 * nmcu
+                deq = np.zeros(64, np.int16)
+                L.amvo_ffmpeg_dequant_block(np.ascontiguousarray(coef[blk]).ctypes.data, comp, deq.ctypes.data)
+                px = np.zeros(64, np.uint8)
+                L.amvo_simple_idct_put(px.ctypes.data, 8, deq.ctypes.data)
+                for q, (i, j) in pos.items():
+                    expect[q] = px[8 * i + j]
+                    if blk < 6 * nmcu:
+                        assert plain[q] == px[8 * i + j]                # a whole MCU in front: the plain mode's bytes
+            assert (got == expect).all(), (w, h, t, st, blocks)
+    assert seen_partial >= 3
+
+
 def test_oracle_under_sanitizers(amv1):
     """the restatement, built with -fsanitize=address,undefined, over every chunk of the reference
     clip, truncated / damaged / random chunks, wrong geometries and the encoders -- where the reference itself reads out

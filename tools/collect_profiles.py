@@ -9,11 +9,11 @@ import shutil
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 for name in ("bench", "bench_encode", "bench_coresident", "bench_adpcm", "bench_amvlib", "bench_decode320", "bench_decode10k",
-             "bench_strong_world1", "bench_mixed", "bench_amv1"):
+             "bench_strong_world1", "bench_mixed", "bench_amv1", "bench_torchrun_world1", "bench_decode1250"):
     p = os.path.join(src, "%s_%s.json" % (tag, name))
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, "%s_%s.json" % (tag, name)))
@@ -38,4 +38,9 @@ for kind, name in (("sqenc", "encode"), ("sqadpcm", "adpcm")):
     if all(os.path.isdir(d) for d in sq):
         with open(os.path.join(dst, "%s_sq_counters_%s.json" % (tag, name)), "w") as out:
             subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_sq.py")] + sq, check=True, stdout=out)
+for size in ("10k", "1250"):
+    npy, js = os.path.join(src, "%s_trace_%s.npy" % (tag, size)), os.path.join(src, "%s_trace_%s.json" % (tag, size))
+    if os.path.exists(npy) and os.path.exists(js):
+        subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_entropy_trace.py"), npy, js,
+                        os.path.join(dst, "%s_entropy_trace_%s.json" % (tag, size))], check=True, stdout=subprocess.DEVNULL)
 print("\n".join(sorted(os.listdir(dst))))

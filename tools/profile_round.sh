@@ -6,7 +6,7 @@
 #                                           tools/collect_profiles.py copies the summaries to profiles/; the parts fit
 #                                           one gpurun call each)
 set -e
-tag=${1:-r05}
+tag=${1:-r06}
 part=${2:-all}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
@@ -22,6 +22,11 @@ python3 bench.py --frames 10000 --no-cpu-baseline > $out/${tag}_bench_decode10k.
 python3 bench.py --strong --frames 20000 --no-cpu-baseline > $out/${tag}_bench_strong_world1.json 2>> $out/${tag}_bench.err
 python3 bench.py --stream mixed --no-secondary > $out/${tag}_bench_mixed.json 2>> $out/${tag}_bench.err
 python3 bench.py --stream amv1 --frames 200000 --no-secondary > $out/${tag}_bench_amv1.json 2>> $out/${tag}_bench.err
+# the line an N-rank run leaves, rehearsed at world size 1 under the launcher the driver uses (RCCL, one rank)
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --strong > $out/${tag}_bench_torchrun_world1.json 2>> $out/${tag}_bench.err
+python3 bench.py --frames 1250 --no-cpu-baseline > $out/${tag}_bench_decode1250.json 2>> $out/${tag}_bench.err
+python3 tools/time_kernels.py --frames 10000 --trace $out/${tag}_trace_10k.npy > $out/${tag}_trace_10k.json 2>> $out/${tag}_bench.err
+python3 tools/time_kernels.py --frames 1250 --trace $out/${tag}_trace_1250.npy > $out/${tag}_trace_1250.json 2>> $out/${tag}_bench.err
 echo "benches done"
 fi
 cd /tmp && export TMPDIR=/tmp
