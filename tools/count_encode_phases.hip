@@ -55,7 +55,7 @@ extern "C" __global__ void probe_rows_base(const uint32_t* in, int* out) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const uint4 q = reinterpret_cast<const uint4*>(in)[threadIdx.x * 8 + r];
-        d[r][0] = q.x; d[r][1] = q.y; d[r][2] = q.z; d[r][3] = q.w; d[r][4] = q.x + 1; d[r][5] = q.y + 1; d[r][6] = q.z + 1; d[r][7] = q.w + 1;
+        d[r][0] = q.x; d[r][1] = q.y; d[r][2] = q.z; d[r][3] = q.w; d[r][4] = q.x; d[r][5] = q.y; d[r][6] = q.z; d[r][7] = q.w;
     }
 #pragma unroll
     for (int i = 0; i < 64; ++i) out[threadIdx.x * 64 + i] = d[i >> 3][i & 7];

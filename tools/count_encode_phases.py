@@ -57,3 +57,7 @@ print(row("stage 2 as the kernels run it", "probe_transform_block", "probe_unpac
 print()
 print("per ten-MCU segment (five trips of 4x2-pixel patches per lane):")
 print(row("colour conversion (rgb24 -> planes)", "probe_colour", "probe_colour_base"))
+print("  (a STATIC count: it includes the byte-by-byte path of a picture's right edge, which a width that is a multiple of 16 never")
+print("   runs, once per trip; the path every patch of the bench stream takes is ~135 instructions per trip -- 8 luma samples of 5,")
+print("   2 x 2 chroma samples of 2 x 2-pixel sums, unpacking by SDWA operands, 4 LDS writes -- plus ~40 of placement and the two")
+print("   12-byte loads: ~875 per segment, as the round-5 review's 360 + 250 counted them per round of one wave)")
