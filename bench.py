@@ -69,6 +69,11 @@ EXIT_FAILED = 4         # a leg raised a device / RCCL error: the line is writte
 EXIT_HUNG = 3           # a leg did not end: the line is written by the watchdog, the run is not clean
 EXIT_USAGE = 2          # --gpus asks for more devices than there are
 LAUNCH_GRACE_SECONDS = float(os.environ.get("AMV_BENCH_LAUNCH_GRACE", "60"))   # launch_ranks: after one rank failed
+# A rehearsal of the N-rank flow where there is ONE GPU: AMV_BENCH_BACKEND=gloo (torch.distributed's gloo moves device tensors
+# too) and AMV_BENCH_ONE_DEVICE=1 (every rank on device 0) run the real ranks, the real kernels, the real exchange and the real
+# record -- everything but RCCL and xGMI.  The line says so (config.rehearsal); it is never a scaling figure.
+BACKEND = os.environ.get("AMV_BENCH_BACKEND", "nccl")
+ONE_DEVICE = os.environ.get("AMV_BENCH_ONE_DEVICE", "") not in ("", "0")
 LAUNCH_LIMIT_SECONDS = float(os.environ.get("AMV_BENCH_LAUNCH_LIMIT", "3600"))  # launch_ranks: the whole run, whatever it waits for
 # what a leg beside the headline (a few seconds of work each) gets before the line leaves without it
 LEG_SECONDS = float(os.environ.get("AMV_BENCH_LEG_SECONDS", "300"))
@@ -1148,7 +1153,7 @@ def launch_ranks(args, argv):
     import subprocess
     import threading
     n = args.gpus
-    if not os.environ.get("AMV_BENCH_CHILD"):
+    if not os.environ.get("AMV_BENCH_CHILD") and not ONE_DEVICE:
         have = torch.cuda.device_count()
         if have < n:
             sys.stderr.write("bench.py: --gpus %d: %d devices needed, %d visible -- not measuring fewer GPUs under that name\n" % (n, n, have))
@@ -1276,7 +1281,7 @@ def main():
     E = Env()
     E.world = int(os.environ.get("WORLD_SIZE", "1"))
     E.rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if ONE_DEVICE else int(os.environ.get("LOCAL_RANK", "0"))
     # the one JSON line must be alone on stdout: RCCL prints a version banner there when a communicator comes up, so
     # descriptor 1 points at stderr for the length of the run and the line goes out through the saved descriptor
     sys.stdout.flush()
@@ -1293,8 +1298,11 @@ def main():
     if E.dist:          # --strong with one process: the same RCCL code path, world size 1 (a rehearsal on a one-GPU box)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=E.rank, world_size=E.world,    # RCCL over xGMI
-                                device_id=torch.device("cuda", local))
+        if BACKEND == "nccl":
+            dist.init_process_group("nccl", rank=E.rank, world_size=E.world,    # RCCL over xGMI
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(BACKEND, rank=E.rank, world_size=E.world)   # (a rehearsal: see BACKEND above)
         E.peers = Peers(E, dist.distributed_c10d._get_default_store())
     E.dev = torch.device("cuda", local)
     E.pkg = entry.load_package()
@@ -1304,6 +1312,9 @@ def main():
 
     try:
         result = run_workload(E, args)
+        if E.dist and (BACKEND != "nccl" or ONE_DEVICE):
+            result["config"]["rehearsal"] = "backend %s%s: the ranks, kernels, exchange and record of an N-rank run without RCCL / xGMI -- not a scaling figure" % (
+                BACKEND, ", every rank on device 0" if ONE_DEVICE else "")
     except BaseException as e:          # a gate's SystemExit included: the peers must not wait for a rank that has left
         if E.peers and not isinstance(e, KeyboardInterrupt):
             E.peers.raise_flag("%s: %s" % (type(e).__name__, str(e)[:300]))
