@@ -95,13 +95,25 @@ def _world():
     return 0, 1
 
 
+def _host_transport(tensors):
+    """gloo given device tensors (bench.py's one-GPU rehearsal of the N-rank flow): it reads and writes them from the host,
+    knowing nothing of streams -- so the device must have finished what produces a tensor before it is posted, and the
+    host must have finished a receive before a kernel reads it.  RCCL orders its transfers on streams: nothing to do."""
+    return (dist.is_initialized() and dist.get_backend() == "gloo" and any(t is not None and t.is_cuda for t in tensors))
+
+
 def _exchange(ops):
     """one grouped point-to-point call (RCCL: one fused launch); returns when the transfers are done or, on a device,
     ordered on the current stream"""
     if not ops:
         return
+    host = _host_transport([op.tensor for op in ops])
+    if host:
+        torch.cuda.synchronize()
     for w in dist.batch_isend_irecv(ops):
         w.wait()
+    if host:
+        torch.cuda.synchronize()
 
 
 _INDEX_CACHE = {}
@@ -231,11 +243,15 @@ class FrameGather:
                 self.works += dist.batch_isend_irecv(ops)
         elif b > a:
             self.keep = getattr(self, "keep", []) + [frames]        # alive until the send has gone
+            if _host_transport([frames]):
+                torch.cuda.synchronize()                            # (gloo reads the frames from the host: the decode must be done)
             self.works += dist.batch_isend_irecv([dist.P2POp(dist.isend, frames, self.dst)])
 
     def finish(self):
         for w in self.works:
             w.wait()
+        if self.works and _host_transport([self.out] + getattr(self, "keep", [])):
+            torch.cuda.synchronize()
         self.works, self.keep = [], []
         return self.out
 
