@@ -17,6 +17,10 @@ for name in ("bench", "bench_encode", "bench_coresident", "bench_adpcm", "bench_
     p = os.path.join(src, "%s_%s.json" % (tag, name))
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, "%s_%s.json" % (tag, name)))
+for name in ("rehearsal_two_ranks_one_gpu_gloo", "rehearsal_two_ranks_one_gpu_gloo_torchrun"):
+    p = os.path.join(src, "%s_%s.json" % (tag, name))
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, "%s_%s.json" % (tag, name)))
 for kind in ("stats", "stats_encode", "stats_coresident", "stats_adpcm"):
     hits = glob.glob(os.path.join(src, "%s_%s" % (tag, kind), "**", "*kernel_stats.csv"), recursive=True)
     if hits:

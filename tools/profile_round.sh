@@ -25,6 +25,10 @@ python3 bench.py --stream amv1 --frames 200000 --no-secondary > $out/${tag}_benc
 # the line an N-rank run leaves, rehearsed at world size 1 under the launcher the driver uses (RCCL, one rank)
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --strong > $out/${tag}_bench_torchrun_world1.json 2>> $out/${tag}_bench.err
 python3 bench.py --frames 1250 --no-cpu-baseline > $out/${tag}_bench_decode1250.json 2>> $out/${tag}_bench.err
+# ... and with TWO real ranks on this one GPU: gloo instead of RCCL, both ranks on device 0 -- the launcher, the store, the side
+# channel, the kernels, the exchange and the record of an N-rank run, under bench.py's own launcher and under the driver's
+AMV_BENCH_BACKEND=gloo AMV_BENCH_ONE_DEVICE=1 timeout -k 10 900 python3 bench.py --gpus 2 --steps 3 --warmup 1 > $out/${tag}_rehearsal_two_ranks_one_gpu_gloo.json 2>> $out/${tag}_bench.err
+AMV_BENCH_BACKEND=gloo AMV_BENCH_ONE_DEVICE=1 timeout -k 10 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29621 bench.py --gpus 2 --steps 3 --warmup 1 > $out/${tag}_rehearsal_two_ranks_one_gpu_gloo_torchrun.json 2>> $out/${tag}_bench.err
 python3 tools/time_kernels.py --frames 10000 --trace $out/${tag}_trace_10k.npy > $out/${tag}_trace_10k.json 2>> $out/${tag}_bench.err
 python3 tools/time_kernels.py --frames 1250 --trace $out/${tag}_trace_1250.npy > $out/${tag}_trace_1250.json 2>> $out/${tag}_bench.err
 echo "benches done"
