@@ -1456,6 +1456,49 @@ def test_unstuffer_boundaries(ctx, orc):
         assert (got == want).all(), pad
 
 
+def test_entropy_trace_has_a_line_per_wave(pkg, orc):
+    """amvhip_entropy_trace (round 6: what a small batch's entropy launch lasts as long as): with gathering
+    on, a decode through the several-lanes kernel leaves one line per task -- begin before end on the constant-rate clock,
+    phase clocks that add up to less than the task's duration at any plausible shader clock, rounds within the loop's bound,
+    the lane count and share length of the launch -- and the pixels are the oracle's whether gathering is on or not"""
+    import os
+    import torch
+    w, h, n = 160, 120, 400
+    chunks = _synth_chunks(orc, n, w, h)
+    old = os.environ.get("AMVHIP_SYNC_LANES")
+    os.environ["AMVHIP_SYNC_LANES"] = "16"
+    try:
+        c = pkg.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("AMVHIP_SYNC_LANES", None)
+        else:
+            os.environ["AMVHIP_SYNC_LANES"] = old
+    try:
+        plain, st0 = _gpu_decode(c, chunks, w, h)
+        c.entropy_stats(True)
+        traced, st1 = _gpu_decode(c, chunks, w, h)
+        tr = c.entropy_trace(4096)
+        stats = c.entropy_stats(False)
+        assert (st0 == 0).all() and (st1 == 0).all() and (plain == traced).all()
+        want = np.stack([orc.decode_frame(ch, w, h)[0] for ch in chunks[:8]])
+        assert (traced[:8] == want).all()
+        tr = tr[tr[:, 1] != 0]
+        assert len(tr) == (n + 3) // 4 == stats["waves"]                       # four frames per wave at sixteen lanes
+        dur = (tr[:, 1] - tr[:, 0]).astype(np.int64)                           # 100 MHz ticks
+        assert (dur > 0).all() and (dur < 100 * 1000 * 50).all()               # under 50 ms each
+        phases = tr[:, 2:6].astype(np.int64).sum(axis=1)                       # shader clocks
+        assert (phases > 0).all() and (phases < dur * 40).all()                # a shader clock under 4 GHz
+        rounds = (tr[:, 6] & np.uint64(0xffffffff)).astype(np.int64)
+        share = (tr[:, 6] >> np.uint64(32)).astype(np.int64)
+        assert (rounds >= 1).all() and (rounds <= 17).all() and rounds.max() == stats["max_rounds"]
+        bits = np.array([8 * (len(ch) - 4) for ch in chunks])
+        assert share.min() >= 64 and share.max() <= ((bits.max() + 15) // 16 + 31) // 32 * 32
+        assert ((tr[:, 7] & np.uint64(0xffff)) == 16).all()
+    finally:
+        c.close()
+
+
 def test_every_lane_count_gives_the_same_bytes(pkg, orc):
     """4 000 chunks, a quarter of them damaged (bit flips, truncation, runs of FF spliced in), decoded with 1, 2, 4, 8, 16, 32
     and 64 lanes per frame (the one-lane kernel and every instantiation of the several-lanes one, whose lanes remember their
