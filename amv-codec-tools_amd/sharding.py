@@ -30,12 +30,12 @@ import torch.distributed as dist
 
 # How a stream is cut.  Equal contiguous ranges unless `configure` gives the rank that holds the stream a
 # larger one: that rank pays no link for its own frames -- its range is decoded in place in the gathered buffer -- while
-# every other rank's frames cross its ONE xGMI link to the source (~153 GB/s), and a rank's decode of configs[3]'s share is
-# nearly flat in the number of frames (a launch one wave deep: 0.22 ms for 1 250 frames, 0.25 for 2 500).  With 8 ranks and
-# the source keeping a share s of a 10 000-frame 160x120 stream the gather is (1 - s) / 7 x 576 MB per link: s = 1/8 ->
-# 72 MB = 0.47 ms, s = 1/4 -> 62 MB = 0.40 ms, s = 1/2 -> 41 MB = 0.27 ms, against the source's own decode of s x 10 000
-# frames (0.24 / 0.25 / 0.31 ms) -- DESIGN.md section 10 has the arithmetic; NOTHING of it has been measured on more than
-# one GPU.  A knob, not a claim.
+# every other rank decodes its frames and THEN sends them over its ONE xGMI link to the source (~153 GB/s), and a rank's
+# decode of configs[3]'s share grows slowly with its frames (a launch one generation deep: 0.31 ms for 1 250 frames, ~0.37 for
+# 2 500, ~0.49 for 5 000).  With 8 ranks and the source keeping a share s of a 10 000-frame 160x120 stream a sender needs
+# decode + (1 - s) / 7 x 576 MB / 153 GB/s: s = 1/8 -> 0.31 + 0.47 ms, s = 1/2 -> 0.29 + 0.27 ms beside the source's own
+# 0.49 ms for 5 000 frames -- ~0.61 ms end to end against 0.83 with equal ranges and 0.73 on one GPU.  DESIGN.md section 10
+# has the table; NOTHING of it has been measured on more than one GPU.  A knob, not a claim.
 _SPLIT = {"src": 0, "src_share": None}
 
 
