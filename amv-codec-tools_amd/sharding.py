@@ -20,8 +20,10 @@ over the frames, more time than the decode at world size one):
   sub-batch j + 1 decodes.  xGMI is point to point -- seven links of ~153 GB/s per GPU, one per peer --
   so the gather into rank 0 runs on seven links at once and is bound by each sender's ONE link:
   BASELINE configs[3] at 8 ranks moves 7 x 72 MB = 504 MB into rank 0, 72 MB / 153 GB/s = 0.47 ms per
-  link in parallel, against ~0.45 ms for the decode of a rank's 1 250 frames (a launch one wave deep);
-  DESIGN.md section 10 has the arithmetic.  No 1 -> 8 run has been measured.
+  link in parallel, against ~0.31 ms for the decode of a rank's 1 250 frames (a launch one wave deep);
+  DESIGN.md section 10 has the arithmetic.  No 1 -> 8 run has been measured;
+* the destination posts its receives BEFORE it decodes its own range (`FrameGather.expect`): RCCL's stream then waits for
+  nothing of the decode, and a destination that keeps a larger range (`configure`) decodes it beside the transfers.
 """
 import numpy as np
 import torch
@@ -206,8 +208,9 @@ class FrameGather:
 
     g = FrameGather(n_total, frame_shape, dtype, device, dst, k)
     for j, (a, b) in enumerate(g.pieces):          # this rank's sub-batches, global frame numbers
+        g.expect(j)                                # on dst: the receives of sub-batch j, posted before its own decode
         frames = decode(..., into=g.slot(j))       # on dst: a view of the buffer, decode writes in place; elsewhere None
-        g.post(j, frames)                          # send (or receive) sub-batch j; returns at once on a device
+        g.post(j, frames)                          # elsewhere: send sub-batch j; returns at once on a device
     full = g.finish()                              # on dst: the buffer, every range in place; elsewhere None
     """
 
@@ -216,6 +219,7 @@ class FrameGather:
         self.n_total, self.dst, self.k = n_total, dst, max(1, int(k))
         self.pieces = sub_ranges(*frame_range(n_total, self.rank, self.world), self.k)
         self.works = []
+        self.expected = set()
         self.out = None
         if self.rank == dst:
             shape = (n_total,) + tuple(frame_shape)
@@ -227,20 +231,28 @@ class FrameGather:
         a, b = self.pieces[j]
         return self.out[a:b]
 
+    def expect(self, j):
+        """on dst: post the receives of every other rank's sub-batch j (once; they land in slices no decode of this rank
+        writes).  Posted before this rank's own decode, they wait for nothing of it."""
+        if self.rank != self.dst or j in self.expected:
+            return
+        self.expected.add(j)
+        ops = []
+        for r in range(self.world):
+            if r == self.dst:
+                continue
+            ra, rb = sub_ranges(*frame_range(self.n_total, r, self.world), self.k)[j]
+            if rb > ra:
+                ops.append(dist.P2POp(dist.irecv, self.out[ra:rb], r))
+        if ops:
+            self.works += dist.batch_isend_irecv(ops)
+
     def post(self, j, frames):
         a, b = self.pieces[j]
         if self.rank == self.dst:
             if b > a and (frames.data_ptr() != self.out[a:b].data_ptr()):
                 self.out[a:b].copy_(frames)         # a decoder that did not take `into`
-            ops = []
-            for r in range(self.world):
-                if r == self.dst:
-                    continue
-                ra, rb = sub_ranges(*frame_range(self.n_total, r, self.world), self.k)[j]
-                if rb > ra:
-                    ops.append(dist.P2POp(dist.irecv, self.out[ra:rb], r))
-            if ops:
-                self.works += dist.batch_isend_irecv(ops)
+            self.expect(j)
         elif b > a:
             self.keep = getattr(self, "keep", []) + [frames]        # alive until the send has gone
             if _host_transport([frames]):
@@ -252,7 +264,7 @@ class FrameGather:
             w.wait()
         if self.works and _host_transport([self.out] + getattr(self, "keep", [])):
             torch.cuda.synchronize()
-        self.works, self.keep = [], []
+        self.works, self.keep, self.expected = [], [], set()
         return self.out
 
 
@@ -300,6 +312,8 @@ def strong_step(blob, offs, lens, n_total, device, decode, src=0, clock=None, fr
         if g is None and frame_shape is not None:
             g = FrameGather(n_total, frame_shape, dtype, device, src, k, out)
         into = g.slot(j) if g is not None else None
+        if g is not None:
+            g.expect(j)
         frames = decode(my_blob, my_offs[a:b], my_lens[a:b], lo, into)
         if g is None:                               # frame shape learnt from the first decode
             g = FrameGather(n_total, tuple(frames.shape[1:]), frames.dtype, device, src, k, out)

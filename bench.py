@@ -153,6 +153,25 @@ class Peers:
             leave(EXIT_FAILED)
 
 
+def balanced_src_share(world, n_total=10000, frame_bytes=57600, link_gb_s=153.0):
+    """The share of configs[3]'s stream the rank that holds it keeps so that its own decode ends with the others' decode + send
+    (DESIGN.md section 10's table, solved for s): a rank's decode of n of these frames takes 0.27 ms + 0.044 us x n on one
+    MI355X (0.31 / 0.37 / 0.49 / 0.73 ms at 1 250 / 2 500 / 5 000 / 10 000 frames, tools/time_kernels.py + the launches' gaps),
+    a sender's frames then cross its ONE xGMI link (~153 GB/s).  A model from single-GPU times: what it predicts is what the
+    second strong leg exists to measure."""
+    if world < 2:
+        return None
+    ms = lambda n: 0.27 + 0.044e-3 * n
+    cost = lambda s: max(ms(s * n_total), ms((1 - s) * n_total / (world - 1)) + (1 - s) * n_total / (world - 1) * frame_bytes / (link_gb_s * 1e6))
+    return min((i / 100.0 for i in range(101)), key=cost)
+
+
+def share_flat(strong, status):
+    """the second strong leg (the source keeps balanced_src_share of the stream), as flat scalars of config"""
+    return {"strong10k_srcshare": (strong or {}).get("src_share"), "strong10k_srcshare_status": status,
+            "strong10k_srcshare_ms": (strong or {}).get("ms_per_step"), "strong10k_srcshare_fps": (strong or {}).get("frames_per_s")}
+
+
 def strong_flat(strong, status):
     """configs[3] as stated, as FLAT scalars of `config` (a record that keeps scalars only still carries them, and a hang or
     an error of the exchange is a value one can read, not a missing key)"""
@@ -512,6 +531,15 @@ def run_decode(E, args):
         guarded_strong(E, result, lambda: run_strong(E, args, w, h))
         if E.failed:
             return result       # this rank is out of step with the others: no further collective (the CPU leg's barrier)
+        # ... and once more with the rank that holds the stream keeping the share that balances its own decode against the
+        # others' decode + send (it pays no link for its own frames): the measurement of DESIGN section 10's table
+        s = balanced_src_share(E.world, frame_bytes=h * ctx.stride(w))
+        if s is not None and not os.environ.get("AMV_BENCH_SRC_SHARE"):
+            guarded_strong(E, result, lambda: run_strong(E, args, w, h, share=s), flat=share_flat,
+                           key="config4_strong_10k_src_share", what="strong-scaling leg, source share %.2f" % s)
+            E.sh.configure(src_share=None)
+            if E.failed:
+                return result
 
     if cpu_leg(E, args):
         m = min(args.cpu_sample, n)
@@ -573,21 +601,23 @@ def guarded(E, result, body, seconds, verdict, what):
     return value
 
 
-def guarded_strong(E, result, body, seconds=None):
+def guarded_strong(E, result, body, seconds=None, flat=None, key="config4_strong_10k", what="strong-scaling leg"):
     """The exchange has never met more than one GPU: configs[3] as stated under guarded()'s contract.
-    The verdict is a flat scalar, strong10k_status = "ok" | "error: ..." | "hung in <phase> on rank r"."""
+    The verdict is a flat scalar, strong10k_status = "ok" | "error: ..." | "hung in <phase> on rank r" (flat: the function
+    that makes the leg's flat scalars, strong_flat unless given; key: where the leg's dictionary goes)."""
     E.strong_phase = "setup"
     box = {}
+    flat = flat or strong_flat
 
     def verdict(status):
-        result["config"].update(strong_flat(box.get("strong") if status == "ok" else None, status))
+        result["config"].update(flat(box.get("strong") if status == "ok" else None, status))
 
     def run():
         box["strong"] = body()
         return box["strong"]
 
-    strong = guarded(E, result, run, STRONG_LEG_SECONDS if seconds is None else seconds, verdict, "strong-scaling leg")
-    result["config"]["config4_strong_10k"] = strong if strong is not None else {"failed": E.failed}
+    strong = guarded(E, result, run, STRONG_LEG_SECONDS if seconds is None else seconds, verdict, what)
+    result["config"][key] = strong if strong is not None else {"failed": E.failed}
 
 
 def write_line_and_leave(E, result):
@@ -606,16 +636,17 @@ def write_line_and_leave(E, result):
         leave(EXIT_FAILED)
 
 
-def run_strong(E, args, w, h, n_total=10000):
+def run_strong(E, args, w, h, n_total=10000, share=None):
     """BASELINE.json configs[3] as it is stated: ONE 10 000-frame 160x120 stream, held by rank 0 in HBM, frame-sharded
     over the ranks: scatter-v of the chunks over RCCL, per-rank decode through the C ABI, gather of the BGR frames back
     to rank 0 -- timed end to end ("scaling": "strong").  Runs next to the weak-scaling line, never instead of it."""
     ctx, dev, stream, sh = E.ctx, E.dev, E.stream, E.sh
     d_blob = d_offs = d_lens = None
     # AMV_BENCH_SRC_SHARE: the fraction of the stream rank 0 -- which holds it and pays no link for its own frames -- keeps
-    # (sharding.configure; default: equal ranges).  Unmeasured on more than one GPU: a knob, not a claim.
-    share = os.environ.get("AMV_BENCH_SRC_SHARE")
-    sh.configure(src_share=float(share) if share else None)
+    # (sharding.configure; default: equal ranges).  Unmeasured on more than one GPU: a knob, not a claim.  share=: the second
+    # leg's, from balanced_src_share.
+    share = share if share is not None else (os.environ.get("AMV_BENCH_SRC_SHARE") or None)
+    sh.configure(src_share=float(share) if share is not None else None)
     E.strong_phase = "making the stream"
     if E.rank == 0:
         d_blob, cap, d_offs, d_lens, stream_bytes = make_video_stream(E, 0, n_total, w, h)
@@ -689,7 +720,7 @@ def run_strong(E, args, w, h, n_total=10000):
             "frames": n_total, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "frames_per_s": n_total * steps / elapsed,
             "phase_ms_max_over_ranks": phases, "backend": dist.get_backend(), "n_gpus": E.world, "sub_batches": k,
             "rccl_ranks": dist.get_world_size(),          # the communicator's size as the backend reports it
-            "src_share": float(share) if share else None, "frames_by_rank": [b - a for a, b in (sh.frame_range(n_total, r, E.world) for r in range(E.world))],
+            "src_share": float(share) if share is not None else None, "frames_by_rank": [b - a for a, b in (sh.frame_range(n_total, r, E.world) for r in range(E.world))],
             "exchange": "source sends slices of its blob (point to point, one grouped call), frames are received straight into "
                         "slices of one buffer on rank 0, whose own range is decoded in place",
             "gathered_bytes_per_step": n_total * h * ctx.stride(w)}
@@ -1127,7 +1158,8 @@ CONFIG_HEAD = ("workload", "parallelism",
 # first (the strong leg's and, in one scalar, every other leg's), configs[3] as stated, then the same sixteen -- all five
 # BASELINE configs inside the first 24 -- and the strong leg's phases behind them.
 CONFIG_HEAD_RANKS = ("workload", "rccl_ranks", "run_status", "strong10k_status", "strong10k_ms", "strong10k_fps") + CONFIG_HEAD[2:18] + (
-    "strong10k_decode_ms", "strong10k_gather_ms", "strong10k_scatter_ms", "parallelism") + CONFIG_HEAD[18:]
+    "strong10k_decode_ms", "strong10k_gather_ms", "strong10k_scatter_ms", "strong10k_srcshare", "strong10k_srcshare_status",
+    "strong10k_srcshare_ms", "strong10k_srcshare_fps", "parallelism") + CONFIG_HEAD[18:]
 
 
 def ordered_config(cfg):

@@ -120,6 +120,20 @@ def test_config_head_fits_the_window_that_records_keep():
     assert list(cfg) == ["workload", "rccl_ranks", "strong10k_status", "enc320_fps", "parallelism", "zzz"]
 
 
+def test_balanced_source_share_model():
+    """the share of configs[3]'s stream the source keeps in the second strong leg: none without peers, nearly everything with
+    one peer (whose one link carries all the rest), falling with the ranks, and never below an equal range"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.balanced_src_share(1) is None
+    shares = [bench.balanced_src_share(w) for w in (2, 3, 4, 8)]
+    assert shares == sorted(shares, reverse=True) and 0.85 <= shares[0] <= 0.95 and 0.5 <= shares[-1] <= 0.65
+    assert all(s > 1.0 / w for s, w in zip(shares, (2, 3, 4, 8)))
+    flat = bench.share_flat(None, "hung in timed exchange on rank 1")
+    assert flat["strong10k_srcshare_ms"] is None and flat["strong10k_srcshare_status"].startswith("hung")
+    assert set(flat) <= set(bench.CONFIG_HEAD_RANKS)
+
+
 # A rank of an N-rank run with everything that needs a GPU replaced: gloo instead of RCCL, the three workload functions
 # replaced by stand-ins that go through the SAME reductions, barriers, CPU-leg gate and result builders (base_result,
 # roofline, cpu_leg / cpu_leg_done, guarded_strong) as the real ones.  What runs for real: launch_ranks (the store it hosts,
@@ -159,6 +173,9 @@ RANK_STUB = """
             if metric.startswith("160x120") and E.dist and getattr(args, "strong_leg", True):
                 bench.guarded_strong(E, r, lambda: {"ms_per_step": 0.9, "frames_per_s": 1.1e7, "rccl_ranks": dist.get_world_size(),
                                                     "phase_ms_max_over_ranks": {"scatter": 0.1, "decode": 0.5, "gather": 0.3}})
+                share = bench.balanced_src_share(E.world)
+                bench.guarded_strong(E, r, lambda: {"ms_per_step": 0.6, "frames_per_s": 1.6e7, "src_share": share},
+                                     flat=bench.share_flat, key="config4_strong_10k_src_share", what="strong-scaling leg, source share")
             if bench.cpu_leg(E, args):
                 time.sleep(0.2)
                 r["cpu_baseline"] = {"value": 5.0, "unit": unit, "cores": 1, "kind": "port", "sample": "stand-in"}
@@ -204,6 +221,14 @@ def test_two_rank_line_carries_every_config_and_the_cpu_path(tmp_path):
     assert set(line["config"]["secondary"]) == {"decode_320x240", "decode_160x120_10k_stream", "decode_160x120_mixed",
                                                 "decode_amv1_looped", "encode_320x240", "coresident_320x240_adpcm", "adpcm"}
     assert list(line["config"])[-1] == "secondary"
+    # the second strong leg (the source keeps the balanced share): flat scalars behind the head, its dictionary beside the first's
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = line["config"]
+    assert cfg["strong10k_srcshare"] == bench.balanced_src_share(2) and cfg["strong10k_srcshare_status"] == "ok"
+    assert cfg["strong10k_srcshare_ms"] == 0.6 and cfg["strong10k_ms"] == 0.9
+    assert cfg["config4_strong_10k_src_share"]["src_share"] == cfg["strong10k_srcshare"]
+    assert list(cfg).index("strong10k_scatter_ms") < list(cfg).index("strong10k_srcshare") < list(cfg).index("parallelism")
 
 
 def test_a_rank_that_fails_in_a_leg_tells_its_peers_and_the_line_still_goes_out(tmp_path):
