@@ -1340,7 +1340,9 @@ extern "C" int amvhip_entropy_stats(amvhip_ctx* c, int enable, uint64_t out[10])
         if (c->last_decode_retry && c->last_decode_retry->p) HIP_TRY(c, hipMemcpy(&handed, c->last_decode_retry->p, 4, hipMemcpyDeviceToHost));
         out[3] = handed;
     }
-    HIP_TRY(c, hipMemset(c->stats.p, 0, 128));
+    // the counters always; the per-task lines too when gathering goes on, so that amvhip_entropy_trace finds zeros behind the
+    // tasks of the launches that follow (a fresh allocation holds whatever the pool last kept there)
+    HIP_TRY(c, hipMemset(c->stats.p, 0, enable ? amv::kStatsBytes : 128));
     c->want_stats = enable != 0;
     return AMVHIP_OK;
 }

@@ -675,6 +675,13 @@ def run_strong(E, args, w, h, n_total=10000, share=None):
         torch.cuda.synchronize()
         return time.perf_counter()
 
+    def phase_clock():
+        # between the phases of a step: what THIS rank's stream has been given (the scatter's and the gather's transfers are
+        # waited for on it), not the device -- rank 0's receives are posted before its own decode and are still in flight,
+        # on RCCL's stream, when that decode ends
+        torch.cuda.current_stream().synchronize()
+        return time.perf_counter()
+
     def one_step(timed_clock=None):
         return sh.strong_step(d_blob, d_offs, d_lens, n_total, dev, decode, clock=timed_clock, frame_shape=shape, k=k, out=d_full)
 
@@ -709,7 +716,7 @@ def run_strong(E, args, w, h, n_total=10000, share=None):
     dist.barrier()
     t0 = clock()
     for _ in range(steps):
-        _, ph = one_step(clock)
+        _, ph = one_step(phase_clock)
         for name in phases:
             phases[name] += ph[name]
     dist.barrier()

@@ -297,7 +297,8 @@ int amvhip_entropy_stats(amvhip_ctx *ctx, int enable, uint64_t out[10]);
 /* ... and, per task (wave) of the last launch of the several-lanes-per-frame kernel while gathering was on, a line of
  * eight words: {constant-rate clock (100 MHz) at the task's begin, at its end, shader clocks of the first walk, the
  * synchronisation rounds, the strict pass, the DC pass, rounds of the wave's worst frame | share length in bits << 32,
- * workgroup << 32 | wave << 16 | lanes per frame}.  out: 8 * tasks words; returns the lines copied (< 0: error).
+ * workgroup << 32 | wave << 16 | lanes per frame}.  out: 8 * tasks words; returns the lines copied (< 0: error).  Lines behind
+ * the launch's tasks are zero when no launch since gathering went on had more (amvhip_entropy_stats clears them then).
  * What a launch one generation of waves deep lasts as long as: its slowest task (tools/time_kernels.py --trace). */
 int amvhip_entropy_trace(amvhip_ctx *ctx, uint64_t *out, uint32_t tasks);
 /* A batch large enough to give every frame ONE entropy lane (a wave's 64 frames then finish together) gives the frames
