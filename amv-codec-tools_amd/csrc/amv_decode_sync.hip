@@ -1792,7 +1792,7 @@ __global__ __launch_bounds__(kLayoutBlock) void amv_layout_write_kernel(const ui
 // 5 us each of a 0.7-ms step, and of the 0.3 ms of a rank's 1 250-frame share of it.  Sixteen threads take a block of 256
 // frames, sixteen frames each; the arithmetic is the three kernels' own, saturation for saturation (a block's total
 // through sat32, the blocks' prefix clamped at the capacity, a frame's line = min(prefix + its place in the block, capacity)),
-// so the lines are the same numbers whatever route made them (tests/test_gpu_parity.py::test_layout_routes_agree).
+// so the lines are the same numbers whatever route made them (tests/test_gpu_parity.py::test_decode_lengths_that_overflow_the_layout runs both).
 // zero[0 .. nzero) is cleared on the way: the retry counter and the task queues of the kernels behind.
 constexpr uint32_t kLayoutSmall = 16384;
 __global__ __launch_bounds__(1024) void amv_layout_small_kernel(const uint32_t* __restrict__ lens, uint32_t n, LayoutSpec a, LayoutSpec b,
