@@ -8,6 +8,9 @@ line per mismatch and a summary, and exits non-zero if anything differed.
                  chain's list handling passed every test and showed up here within forty streams.
   decode LO HI   batches of random size and content (synthetic, noise, flat, noisy synthetic), a third of the chunks damaged
                  or cut, every entropy lane count, both output modes: pixels and statuses against the oracle.
+  ffmpeg LO HI   the same kind of batches through AMVHIP_FLAG_FFMPEG (planar YUVJ420P, the fork's own arithmetic and flip; odd
+                 sizes too), every second seed with AMVHIP_FLAG_FFMPEG_KEEP over a buffer of random bytes: every byte against
+                 the oracle's restatement -- whole blocks in front of a chunk's first error written, nothing else touched.
   encode LO HI   random geometries, strides, channel orders, quantiser biases and content: chunks against the oracle's.
 """
 import os
@@ -98,6 +101,59 @@ def soak_decode(pkg, orc, lo, hi):
     return bad
 
 
+def soak_ffmpeg(pkg, orc, lo, hi):
+    import torch
+    import test_gpu_parity as T
+    bad = 0
+    for seed in range(lo, hi):
+        rng = np.random.default_rng(seed)
+        w, h, n = int(rng.integers(16, 400)), int(rng.integers(16, 300)), int(rng.integers(3, 60))
+        ew, eh = w + (w & 1), h + (h & 1)            # (the encoder takes even sizes; the decoder is told the odd one)
+        chunks = []
+        for t in range(n):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                src = orc.synth_frame(SEED, 1000 * seed + t, ew, eh)
+            elif kind == 1:
+                src = rng.integers(0, 256, (eh, ew, 3)).astype(np.uint8)
+            else:
+                src = (orc.synth_frame(SEED, t, ew, eh).astype(np.int32) + rng.integers(-40, 41, (eh, ew, 3))).clip(0, 255).astype(np.uint8)
+            c = bytearray(orc.encode_frame(src, ew, eh, qbias=int(rng.integers(0, 2)) * 128))
+            if rng.random() < 0.4 and len(c) > 12:
+                for _ in range(int(rng.integers(1, 5))):
+                    c[int(rng.integers(4, len(c) - 2))] ^= 1 << int(rng.integers(0, 8))
+            if rng.random() < 0.15:
+                c = c[: int(rng.integers(2, len(c)))]
+            chunks.append(bytes(c))
+        keep = bool(seed & 1)
+        fb = orc.decode_frame_ffmpeg(chunks[0], w, h)[0].size
+        before = rng.integers(0, 256, (n, fb), dtype=np.uint8)
+        want, wst = [], []
+        for i, c in enumerate(chunks):
+            o, st, _ = orc.decode_frame_ffmpeg_keep(c, w, h, before[i]) if keep else orc.decode_frame_ffmpeg(c, w, h)
+            want.append(o)
+            wst.append(st)
+        want, wst = np.stack(want), np.array(wst, np.int32)
+        blob, offs, lens, nbytes = T._blob_of(chunks, int(rng.integers(0, 4)))
+        flags = pkg.FLAG_FFMPEG | (pkg.FLAG_FFMPEG_KEEP if keep else 0)
+        for lanes in ("1", "4", "64", None):
+            if lanes:
+                os.environ["AMVHIP_SYNC_LANES"] = lanes
+            else:
+                os.environ.pop("AMVHIP_SYNC_LANES", None)
+            ctx = pkg.Context(0)
+            d_out = torch.from_numpy(before.copy()).to("cuda:0")
+            d_st = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+            ctx.decode_batch_dev(T._t(blob), nbytes, T._t(offs), T._t(lens), n, w, h, flags, d_out, d_st, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ctx.close()
+            if not ((d_st.cpu().numpy() == wst).all() and (d_out.cpu().numpy() == want).all()):
+                bad += 1
+                print("MISMATCH ffmpeg seed", seed, w, h, n, "keep" if keep else "plain", "lanes", lanes, flush=True)
+    os.environ.pop("AMVHIP_SYNC_LANES", None)
+    return bad
+
+
 def soak_encode(pkg, orc, lo, hi):
     import torch
     import test_gpu_parity as T
@@ -145,13 +201,13 @@ def soak_encode(pkg, orc, lo, hi):
 
 
 def main():
-    if len(sys.argv) != 4 or sys.argv[1] not in ("adpcm", "decode", "encode"):
+    if len(sys.argv) != 4 or sys.argv[1] not in ("adpcm", "decode", "ffmpeg", "encode"):
         raise SystemExit(__doc__)
     what, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     pkg = entry.build()
     orc = entry.load_oracle()
     orc.lib()
-    bad = {"adpcm": soak_adpcm, "decode": soak_decode, "encode": soak_encode}[what](pkg, orc, lo, hi)
+    bad = {"adpcm": soak_adpcm, "decode": soak_decode, "ffmpeg": soak_ffmpeg, "encode": soak_encode}[what](pkg, orc, lo, hi)
     print("soak", what, "seeds", lo, "..", hi - 1, "mismatches:", bad)
     sys.exit(1 if bad else 0)
 
