@@ -1607,13 +1607,25 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     if (wanted == 1 || wanted == 2 || wanted == 4 || wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
     if (n >= cus * 230u) return 1;
     if (n >= cus * 150u) return 2;
+    // One generation of waves holds 13 tasks per compute unit (fast_waves: the LDS a task needs), and a launch whose tasks are
+    // all resident lasts as long as one task does.  Round 6, sweeps on one box (tools/sweep_lanes.sh, profiles/r06_lanes_sweep.txt;
+    // entropy kernel, ms): the step between "all resident" and "a second generation" is where the lane count should halve --
+    // 160x120, sixteen lanes / eight: 12 000 frames (3 000 tasks) 0.46 / 0.53, 14 000 (3 500 tasks) 0.58 / 0.56; 320x240:
+    // 11 000 frames 0.85 / 0.99, 13 000 1.02 / 1.04, 14 000 1.11 / 1.03 -- so the table counts in generations of 13 waves per
+    // unit (rounds 4 - 5 had counted ten, the workgroup the launch happened to get).
+    const uint64_t resident = (uint64_t)cus * fast_waves(8u);
+    // Short frames (160x120: 3.5 kB) beyond what eight lanes keep resident: two lanes.  Their launch stays one generation
+    // deep up to 106 000 frames and lasts 0.80 ms from 10 000 frames to 30 000 (one task per SIMD, half a frame per lane), where
+    // eight lanes in a second generation need 0.88 at 28 000 frames, 0.91 at 30 000 and 0.96 at 34 000 against 0.81 / 0.81 /
+    // 0.96.  Long frames do not follow: 320x240, 32 000 frames 2.32 with two lanes against 1.86 with eight (a lane's fixed
+    // cost of falling in step is a smaller part of a 14-kB frame's share, eight lanes stay efficient).
+    if (pixels <= 30000u && (uint64_t)n * 8u > resident * 64u) return 2;
     int full = 8;                                  // chip full: 8 lanes up to 320x240 (32 000 frames: 1.90 ms against 1.84 with 16)
     while (full < 64 && (uint64_t)full * 25000u <= pixels) full *= 2;
-    const uint64_t waves = (uint64_t)cus * 10u;
     int fill = 8;                                  // small batch: as many lanes as keep every task resident ...
-    if (n <= waves) fill = 64;
-    else if (n <= 2u * waves) fill = 32;
-    else if (n <= 4u * waves) fill = 16;
+    if (n <= resident) fill = 64;
+    else if (n <= 2u * resident) fill = 32;
+    else if (n <= 4u * resident) fill = 16;
     // ... but no share much shorter than the synchronisation length, or the re-walk rounds take over.  Round 5 (lanes that
     // remember their walks, finality by prefix scan, idle lanes walking candidates), 160x120, lanes 8 / 16 / 32 / 64:
     // 1 250 frames 0.45 / 0.31 / 0.24 / 0.22 ms with 1.2 / 2.2 / 3.5 / 5.3 rounds, 2 500: 0.45 / 0.33 / 0.25 / 0.29,
@@ -1622,7 +1634,7 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     // (round 4's kernel: 1 250 frames 0.32 / 0.27 / 0.33 with 16 / 32 / 64, 2 500: 0.37 / 0.34 / 0.46, 5 000: 0.38 / 0.41 / 0.56)
     int cap = 8;
     while (cap < 64 && (uint64_t)cap * 2u * 500u <= pixels) cap *= 2;
-    if (2u * (uint64_t)n <= waves) cap = 64;      // half a generation of waves or less: the shortest shares still win
+    if (n <= cus * 5u) cap = 64;                  // half of ten waves per unit or less: the shortest shares still win
     if (fill > cap) fill = cap;
     return fill > full ? fill : full;
 }
