@@ -44,6 +44,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -90,6 +91,7 @@ class Env:
     world = 1
     rank = 0
     dist = False
+    line_written = False    # emit_line: the one JSON line has gone out
 
 
 def leave(code):
@@ -102,6 +104,34 @@ def leave(code):
     os._exit(code)
 
 
+LINE_LOCK = threading.Lock()
+
+
+def emit_line(E, result):
+    """ONE JSON line per run, whichever thread gets to write it (the main thread at the end, a leg's watchdog, the peers'
+    watcher): the first caller writes, later ones find it written.  A watchdog or the watcher may come while the main thread
+    is adding keys to the dictionaries -- json.dumps then raises "dictionary changed size during iteration"; it is tried again
+    a few times (the main thread is about to block in a collective or has), and what goes out in the worst case is the
+    line's scalars with the reason in run_status."""
+    with LINE_LOCK:
+        if getattr(E, "line_written", False):
+            return
+        E.line_written = True
+        payload = None
+        for _ in range(8):
+            try:
+                result["config"] = ordered_config(result["config"])
+                payload = json.dumps(result)
+                break
+            except RuntimeError:
+                time.sleep(0.05)
+        if payload is None:
+            payload = json.dumps({k: v for k, v in list(result.items()) if isinstance(v, (int, float, str, bool, type(None)))}
+                                 | {"config": {"run_status": "error: the line was being written to while it had to leave"}})
+        if E.rank == 0 and E.json_fd is not None:
+            os.write(E.json_fd, (payload + "\n").encode())
+
+
 def write_line_now(E, status=None):
     """the line as far as it has got, from whichever thread has to write it (rank 0 only; the others write nothing)"""
     if E.result is None:
@@ -111,9 +141,7 @@ def write_line_now(E, status=None):
             E.verdict(status)
         else:
             E.result["config"]["run_status"] = status
-    E.result["config"] = ordered_config(E.result["config"])
-    if E.rank == 0 and E.json_fd is not None:
-        os.write(E.json_fd, (json.dumps(E.result) + "\n").encode())
+    emit_line(E, E.result)
 
 
 class Peers:
@@ -625,10 +653,8 @@ def write_line_and_leave(E, result):
     peers are told; the communicator may be in no state to be torn down).  Returns normally otherwise."""
     if E.dist:
         result["config"].setdefault("run_status", E.failed or "ok")     # every leg beside the headline, in one scalar
-    result["config"] = ordered_config(result["config"])
-    if E.rank == 0:
-        sys.stdout.flush()
-        os.write(E.json_fd, (json.dumps(result) + "\n").encode())
+    sys.stdout.flush()
+    emit_line(E, result)
     if E.failed:
         os.write(2, ("bench.py: rank %d: %s -- leaving with code %d\n" % (E.rank, E.failed, EXIT_FAILED)).encode())
         if E.peers:

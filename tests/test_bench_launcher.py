@@ -120,6 +120,53 @@ def test_config_head_fits_the_window_that_records_keep():
     assert list(cfg) == ["workload", "rccl_ranks", "strong10k_status", "enc320_fps", "parallelism", "zzz"]
 
 
+def test_the_line_goes_out_once_whichever_thread_writes_it(tmp_path, monkeypatch):
+    """emit_line: the main thread, a leg's watchdog and the peers' watcher may each come to write the line -- one line goes
+    out; a watchdog that meets the main thread adding keys (json.dumps raises "dictionary changed size during iteration")
+    tries again, and in the worst case the line's scalars leave with the reason in run_status"""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = tmp_path / "line.json"
+    E = bench.Env()
+    E.json_fd = os.open(str(out), os.O_WRONLY | os.O_CREAT)
+    E.result = {"metric": "m", "value": 1.0, "config": {"zzz": 1, "workload": "w"}}
+    real, calls = bench.json.dumps, []
+
+    def flaky(obj, *a, **k):
+        calls.append(1)
+        if len(calls) <= 2:
+            raise RuntimeError("dictionary changed size during iteration")
+        return real(obj, *a, **k)
+
+    monkeypatch.setattr(bench.json, "dumps", flaky)
+    bench.write_line_now(E, "hung in leg adpcm on rank 0")
+    monkeypatch.setattr(bench.json, "dumps", real)
+    bench.write_line_now(E, "error: a second writer")
+    bench.emit_line(E, E.result)
+    lines = out.read_text().splitlines()
+    assert len(lines) == 1 and len(calls) == 3
+    line = json.loads(lines[0])
+    assert line["config"]["run_status"].startswith("hung in leg adpcm") and list(line["config"])[0] == "workload"
+    # ... and when it never settles: the scalars, with the reason
+    E2 = bench.Env()
+    out2 = tmp_path / "line2.json"
+    E2.json_fd = os.open(str(out2), os.O_WRONLY | os.O_CREAT)
+    E2.result = {"metric": "m", "value": 2.0, "config": {"workload": "w"}, "roofline": {"frac": 0.3}}
+    state = {"n": 0}
+
+    def never(obj, *a, **k):
+        state["n"] += 1
+        if state["n"] <= 8:
+            raise RuntimeError("dictionary changed size during iteration")
+        return real(obj, *a, **k)
+
+    monkeypatch.setattr(bench.json, "dumps", never)
+    monkeypatch.setattr(bench.time, "sleep", lambda s: None)
+    bench.write_line_now(E2, "hung")
+    line2 = json.loads(out2.read_text())
+    assert line2["metric"] == "m" and line2["value"] == 2.0 and line2["config"]["run_status"].startswith("error: the line was being written")
+
+
 def test_balanced_source_share_model():
     """the share of configs[3]'s stream the source keeps in the second strong leg: none without peers, nearly everything with
     one peer (whose one link carries all the rest), falling with the ranks, and never below an equal range"""
