@@ -1603,7 +1603,7 @@ void launch_sync2(const uint32_t* ws, const uint32_t* ws_bytes, uint32_t n, cons
 // length and as many lanes as keep every task resident: 20 000: 0.67 with eight; 10 000: 0.49 with sixteen (0.52 / 0.63
 // with eight / thirty-two); 320x240: 32 000 frames 1.90 with eight (1.84 with sixteen), 8 000: 0.68 with sixteen,
 // 2 000: 0.32 with sixty-four.  `wanted` (a power of two up to 64) overrides.
-int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
+int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels, bool records) {
     if (wanted == 1 || wanted == 2 || wanted == 4 || wanted == 8 || wanted == 16 || wanted == 32 || wanted == 64) return wanted;
     if (n >= cus * 230u) return 1;
     if (n >= cus * 150u) return 2;
@@ -1613,13 +1613,15 @@ int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels) {
     // 160x120, sixteen lanes / eight: 12 000 frames (3 000 tasks) 0.46 / 0.53, 14 000 (3 500 tasks) 0.58 / 0.56; 320x240:
     // 11 000 frames 0.85 / 0.99, 13 000 1.02 / 1.04, 14 000 1.11 / 1.03 -- so the table counts in generations of 13 waves per
     // unit (rounds 4 - 5 had counted ten, the workgroup the launch happened to get).
-    const uint64_t resident = (uint64_t)cus * fast_waves(8u);
+    // (records: the records form, amv_huffman_sync2_kernel.  The dense form's kernel -- amvhip_huffman_decode_dev, nothing on the
+    // decode path -- holds ten waves per unit and was not swept: it keeps the table it had.)
+    const uint64_t resident = (uint64_t)cus * (records ? fast_waves(8u) : 10u);
     // Short frames (160x120: 3.5 kB) beyond what eight lanes keep resident: two lanes.  Their launch stays one generation
     // deep up to 106 000 frames and lasts 0.80 ms from 10 000 frames to 30 000 (one task per SIMD, half a frame per lane), where
     // eight lanes in a second generation need 0.88 at 28 000 frames, 0.91 at 30 000 and 0.96 at 34 000 against 0.81 / 0.81 /
     // 0.96.  Long frames do not follow: 320x240, 32 000 frames 2.32 with two lanes against 1.86 with eight (a lane's fixed
     // cost of falling in step is a smaller part of a 14-kB frame's share, eight lanes stay efficient).
-    if (pixels <= 30000u && (uint64_t)n * 8u > resident * 64u) return 2;
+    if (records && pixels <= 30000u && (uint64_t)n * 8u > resident * 64u) return 2;
     int full = 8;                                  // chip full: 8 lanes up to 320x240 (32 000 frames: 1.90 ms against 1.84 with 16)
     while (full < 64 && (uint64_t)full * 25000u <= pixels) full *= 2;
     int fill = 8;                                  // small batch: as many lanes as keep every task resident ...

@@ -27,7 +27,7 @@ void launch_unstuff(const uint8_t* blob, uint64_t blob_bytes, const uint64_t* of
                     const uint32_t* ws_line, uint32_t* ws, uint32_t* ws_bytes, uint32_t* retry_list, uint32_t* retry_count,
                     hipStream_t s);
 // lanes per frame for a batch of n frames of `pixels` pixels on a device with `cus` compute units (amv_decode_sync.hip)
-int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels);
+int huffman_sync_lanes(uint32_t n, uint32_t cus, int wanted, uint64_t pixels, bool records);
 // the statistics buffer of the synchronising entropy kernel (amvhip_entropy_stats / _trace): 16 words of counters, then
 // one line of eight 64-bit words per task (wave) for the first kTraceTasks tasks of a launch
 constexpr uint32_t kTraceBase = 16, kTraceTasks = 16384;

@@ -450,7 +450,7 @@ extern "C" int amvhip_huffman_decode_dev(amvhip_ctx* c, const uint8_t* d_blob, u
     SyncSinks sinks{d_coef, nullptr, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr};
     Fallback fb;
     if (int r = entropy_front(c, d_blob, blob_bytes, d_offs, d_lens, n, g, sinks, d_status, d_nmcu_ok, c->retry, st, fb,
-                              huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height)))
+                              huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height, false)))
         return r;
     {   // the caller's array has a place for every frame: one launch, lines at the frames' own places
         Timed t(c, AMVHIP_K_HUFFMAN_SERIAL, st);
@@ -540,7 +540,7 @@ static int decode_core(amvhip_ctx* c, const uint8_t* d_blob, uint64_t blob_bytes
         if (by_stream < cap_lines) cap_lines = by_stream;
         if (cap_lines > 0xffffffffull) cap_lines = 0xffffffffull;
     }
-    const uint32_t lanes = (uint32_t)huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height);
+    const uint32_t lanes = (uint32_t)huffman_sync_lanes(n, c->cus, c->sync_lanes, (uint64_t)g.width * g.height, true);
     // a batch that gets one lane per frame gives its heavy frames kHeavyLanes (entropy_front); AMVHIP_SPLIT=0: every frame one
     const uint32_t heavy_lanes = lanes == 1u && c->split_heavy ? c->heavy_lanes : 0u;
     const uint32_t tab_lanes = heavy_lanes ? heavy_lanes : lanes;       // a frame's row in lane_tab
