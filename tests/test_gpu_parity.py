@@ -531,6 +531,55 @@ def test_full_size_stream_properties(ctx, orc):
         assert (d_out[i].cpu().numpy() == orc.decode_frame(chunk, w, h)[0]).all()
 
 
+@pytest.mark.parametrize("w,h,n", [(160, 120, 6000), (160, 120, 12500), (160, 120, 30000), (320, 240, 6000), (320, 240, 12500)])
+def test_batches_in_the_lane_tables_windows(ctx, pkg, orc, w, h, n):
+    """batch sizes between the boundaries round 6 moved in huffman_sync_lanes' table (generations of 13 waves per unit;
+    two lanes for short frames beyond eight lanes' residency): the table's choice decodes every frame to the bytes the
+    serial entropy kernel gives -- compared frame by frame on the device --, every status clean, and a sample of frames is
+    the oracle's"""
+    import torch
+    dev = "cuda:0"
+    s = torch.cuda.current_stream().cuda_stream
+    pool = 2000                                            # distinct frames, repeated through the batch at a stride
+    d_src = torch.empty((pool, h, w, 3), dtype=torch.uint8, device=dev)
+    ctx.synth_frames_dev(SEED, 0, pool, w, h, d_src, s)
+    # (the batch's chunks overlap in the blob -- every pool chunk is used several times -- and the workspace is sized from the
+    # blob's bytes, include/amvhip.h: the blob is given room for the sum of the lengths, or frames would be handed to the serial kernel)
+    cap = pool * w * h + n * (w * h // 4)
+    d_blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    d_poffs = torch.zeros(pool, dtype=torch.int64, device=dev)
+    d_plens = torch.zeros(pool, dtype=torch.int32, device=dev)
+    ctx.encode_batch_dev(d_src, w * 3, 0, pool, w, h, 0, d_blob, cap, d_poffs, d_plens, s)
+    torch.cuda.synchronize()
+    del d_src
+    pick = (torch.arange(n, device=dev) * 7) % pool
+    d_offs, d_lens = d_poffs[pick].contiguous(), d_plens[pick].contiguous()
+    stride = ctx.stride(w)
+    d_out = torch.empty((n, h, stride), dtype=torch.uint8, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ctx.decode_batch_dev(d_blob, cap, d_offs, d_lens, n, w, h, 0, d_out, d_st, s)
+    torch.cuda.synchronize()
+    assert int((d_st != 0).sum()) == 0 and ctx.entropy_stats(False)["handed_to_serial"] == 0
+    # the serial kernel's bytes of the pool's frames, once; every frame of the batch against its pool frame's
+    ctx.set_entropy_mode(pkg.ENTROPY_SERIAL)
+    try:
+        d_ref = torch.empty((pool, h, stride), dtype=torch.uint8, device=dev)
+        d_rst = torch.full((pool,), -1, dtype=torch.int32, device=dev)
+        ctx.decode_batch_dev(d_blob, cap, d_poffs, d_plens, pool, w, h, 0, d_ref, d_rst, s)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_entropy_mode(pkg.ENTROPY_AUTO)
+    assert int((d_rst != 0).sum()) == 0
+    for lo in range(0, n, 4000):
+        hi = min(n, lo + 4000)
+        assert torch.equal(d_out[lo:hi], d_ref[pick[lo:hi]]), (w, h, n, lo)
+    offs, lens = d_poffs.cpu().numpy(), d_plens.cpu().numpy()
+    for i in (0, n // 2, n - 1):
+        p = int(pick[i])
+        chunk = d_blob[int(offs[p]):int(offs[p]) + int(lens[p])].cpu().numpy().tobytes()
+        assert (d_out[i].cpu().numpy() == orc.decode_frame(chunk, w, h)[0]).all()
+
+
 def test_adpcm_encode_long_stream_index_chain(ctx, orc):
     """the step index is carried through 700 chunks (three 256-chunk workgroup maps composed): every chunk
     equals the oracle's sequential encode, and decoding the device's chunks on the device equals the oracle's decode"""
