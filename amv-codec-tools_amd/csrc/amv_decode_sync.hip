@@ -1855,14 +1855,27 @@ __global__ __launch_bounds__(1024) void amv_layout_small_kernel(const uint32_t* 
     __syncthreads();
     // amv_layout_write_kernel: base of the block + the frame's place in it
     uint64_t atx = s_tx[blk] + (ix - mx), aty = s_ty[blk] + (iy - my);
+    uint32_t la[16], lb[16];
 #pragma unroll
     for (uint32_t k = 0; k < 16u; ++k) {
-        const uint32_t i = first + k;
-        if (i < n) {
-            a.line[i] = (uint32_t)min(atx, (uint64_t)a.cap_lines);
-            if (b.line) b.line[i] = (uint32_t)min(aty, (uint64_t)b.cap_lines);
-        }
+        la[k] = (uint32_t)min(atx, (uint64_t)a.cap_lines);
+        lb[k] = (uint32_t)min(aty, (uint64_t)b.cap_lines);
         atx += va[k]; aty += vb[k];
+    }
+    if (first + 16u <= n) {   // the thread's sixteen lines as four 16-byte stores (the arrays are the context's own: aligned)
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            reinterpret_cast<uint4*>(a.line + first)[q] = make_uint4(la[4 * q], la[4 * q + 1], la[4 * q + 2], la[4 * q + 3]);
+            if (b.line) reinterpret_cast<uint4*>(b.line + first)[q] = make_uint4(lb[4 * q], lb[4 * q + 1], lb[4 * q + 2], lb[4 * q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+            if (first + k < n) {
+                a.line[first + k] = la[k];
+                if (b.line) b.line[first + k] = lb[k];
+            }
+        }
     }
 }
 
@@ -1874,7 +1887,9 @@ void launch_layout(const uint32_t* lens, uint32_t n, const LayoutSpec& a, const 
                    bool force_large, hipStream_t s) {
     if (n == 0) return;
     if (n <= kLayoutSmall && !force_large) {
-        hipLaunchKernelGGL(amv_layout_small_kernel, dim3(1), dim3(1024), 0, s, lens, n, a, b, zero, nzero);
+        // a thread per sixteen frames, whole waves (the blocks' scan wants the first one whole): 1 250 frames are two waves
+        const uint32_t threads = (((n + 15u) / 16u) + 63u) & ~63u;
+        hipLaunchKernelGGL(amv_layout_small_kernel, dim3(1), dim3(threads), 0, s, lens, n, a, b, zero, nzero);
         return;
     }
     if (nzero) (void)hipMemsetAsync(zero, 0, (size_t)nzero * 4u, s);
